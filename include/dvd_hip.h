@@ -1,0 +1,97 @@
+/* dvd_hip.h - C ABI of libdvd_hip.so, the MI355X (gfx950) engine for the DvD
+ * coordinate-diffusion sampling path.
+ *
+ * The reference (hanquansanren/DvD) is pure Python on PyTorch and has no FFI of its own;
+ * the functions below sit UNDER the Python callables the reference's plug-in surface uses
+ *  and each names the reference call site it replaces.  Paths are relative
+ * to the reference root; idf/ = train_settings/dvd/improved_diffusion/.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no exceptions cross the boundary.
+ *   - Every function returns 0 on success or a negative DVD_E_* code; dvd_last_error()
+ *     returns a thread-local message for the last failure.
+ *   - All tensor pointers are BORROWED DEVICE pointers, valid for the duration of the call;
+ *     functions only ENQUEUE work on `stream` (a hipStream_t passed as void*) and never
+ *     synchronise, allocate or free device memory (workspaces are caller-provided), so every
+ *     entry point may be captured into a hipGraph.
+ *   - "tok" layouts are token-major [rows, channels] with `ld` = row stride in elements.
+ */
+#ifndef DVD_HIP_H
+#define DVD_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DVD_OK 0
+#define DVD_E_ARG (-1)     /* bad argument (null pointer, unsupported size/alignment) */
+#define DVD_E_LAUNCH (-2)  /* HIP reported a launch error */
+#define DVD_E_STATE (-3)   /* engine used out of order (weights missing, docs not prepared) */
+
+const char* dvd_last_error(void);
+/* library/ABI version: major*1000 + minor */
+int dvd_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Warps
+ * ---------------------------------------------------------------------------------------- */
+
+/* Drop-in for register_model2 / SpatialTransformer2.forward
+ * (datasets/utils/warping.py:14-23,50-73): F.grid_sample(src, grid.permute(0,2,3,1),
+ * mode='bilinear', padding_mode='zeros', align_corners=True).
+ * src [N,C,Hin,Win] f32, grid [N,2,H,W] f32 (channel 0 = x, 1 = y, normalised [-1,1]),
+ * out [N,C,H,W] f32.  src_batch_div: source image of sample n is n / src_batch_div
+ * (1 = reference behaviour; H_hyp lets the hypotheses of one document share one source). */
+int dvd_grid_sample_bilinear_zeros_ac(const float* src, const float* grid, float* out,
+                                      int n, int c, int hin, int win, int h, int w,
+                                      int src_batch_div, void* stream);
+
+/* Fused full-resolution unwarp tail (train_settings/dvd/evaluation.py:301-306 +
+ * utils_flow/visualization_utils.py:75-77):
+ *   s    = bilinear_upsample(flow[2,G,G] -> H x W, align_corners=True)
+ *   grid = ((s + base) * 2 - 1) * scale,  base_x = j/(W-1), base_y = i/(H-1)
+ *   out  = grid_sample(src, grid, bilinear, zeros, align_corners=True)
+ * f32 variant: src [3,H,W] f32 planar (values 0..255), out [H,W,3] f32 (HWC, what the
+ * reference hands to numpy); u8 variant: src [H,W,3] u8, out [H,W,3] u8 with C-style
+ * truncation of the f32 result (numpy .astype(uint8) on in-range values). */
+int dvd_unwarp_f32(const float* flow, int g, const float* src_chw, float* out_hwc,
+                   int h, int w, float scale, void* stream);
+int dvd_unwarp_u8(const float* flow, int g, const uint8_t* src_hwc, uint8_t* out_hwc,
+                  int h, int w, float scale, void* stream);
+/* Materialise the full-resolution sampling grid only ([2,H,W] f32), i.e. evaluation.py:301-306. */
+int dvd_unwarp_grid(const float* flow, int g, float* grid_out, int h, int w, float scale, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Scheduler step (idf/gaussian_diffusion.py:434-438,445-491 ddim_sample; :270-292 posterior
+ * mean for the DDPM variant).  One fused elementwise kernel over [n_elem] floats:
+ *   DDIM: eps = (c_recip*x_t - x0)/c_recipm1 ; x_prev = x0*sqrt_abar_prev + dir_coef*eps + sigma*noise
+ *   DDPM: x_prev = coef1*x0 + coef2*x_t + sigma*noise
+ * Coefficients are the float32 casts of the float64 schedule tables (`_extract_into_tensor`,
+ * :1181-1197); sigma already contains the (t != 0) mask.  noise may be NULL when sigma == 0.
+ * If next_grid != NULL it also receives (x0 + base_G)*2 - 1 ([N,2,G,G], idf/gaussian_diffusion.py:622),
+ * the sampling grid of the next step's feature warp. */
+typedef struct {
+  int kind;             /* 0 = DDIM, 1 = DDPM */
+  float c_recip;        /* sqrt(1/abar_t)        DDIM */
+  float c_recipm1;      /* sqrt(1/abar_t - 1)    DDIM */
+  float sqrt_abar_prev; /* sqrt(abar_{t-1})      DDIM */
+  float dir_coef;       /* sqrt(1 - abar_{t-1} - sigma^2) DDIM */
+  float coef1;          /* posterior_mean_coef1  DDPM */
+  float coef2;          /* posterior_mean_coef2  DDPM */
+  float sigma;          /* noise scale incl. (t != 0) mask */
+} dvd_sched_coef;
+
+int dvd_sched_step(const dvd_sched_coef* coef, const float* x_t, const float* x0, const float* noise,
+                   float* x_prev, float* next_grid, int n, int g, void* stream);
+
+/* mean over the H hypotheses of each document + clamp to [-1,1]
+ * (idf/gaussian_diffusion.py:639-640): x0 [docs*H,2,G,G] -> out [docs,2,G,G]. */
+int dvd_hyp_mean_clamp(const float* x0, float* out, int docs, int n_hyp, int g, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DVD_HIP_H */

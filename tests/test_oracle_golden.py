@@ -1,0 +1,149 @@
+"""Pins the CPU oracle (oracle/dvd_oracle.py) to the golden vectors produced by the REAL
+reference (oracle/ref_harness/gen_golden.py).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from dvd_amd import synth
+from oracle import dvd_oracle as O
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def load(name):
+    return np.load(os.path.join(GOLD, name), allow_pickle=False)
+
+
+# ----------------------------------------------------------------------------- G1
+@pytest.mark.parametrize("S", [3, 10, 50, 250])
+def test_schedule_tables(S):
+    g = load("schedule.npz")
+    sch = O.Schedule(S)
+    for name in ("betas", "alphas_cumprod", "alphas_cumprod_prev", "sqrt_recip_alphas_cumprod",
+                 "sqrt_recipm1_alphas_cumprod", "posterior_variance", "posterior_log_variance_clipped",
+                 "posterior_mean_coef1", "posterior_mean_coef2"):
+        np.testing.assert_allclose(getattr(sch, name), g[f"s{S}/{name}"], rtol=1e-13, atol=0, err_msg=name)
+    assert np.array_equal(sch.timestep_map, g[f"s{S}/timestep_map"])
+    tm = np.array([sch.t_model(i) for i in range(S)], dtype=np.float32)
+    assert np.array_equal(tm, g[f"s{S}/t_model_raw"])
+    assert np.array_equal(sch.fixed_large_variance.astype(np.float32), g[f"s{S}/fixed_large_var_f32"])
+    assert np.array_equal(sch.fixed_large_log_variance.astype(np.float32), g[f"s{S}/fixed_large_logvar_f32"])
+
+
+def test_t_rule_edges():
+    # cross_model.py:575-580: strictly >600 -> 2, strictly between -> 1, 600/300/<=300 raw
+    assert O.t_rule(600.0001) == 2.0 and O.t_rule(600.0) == 600.0
+    assert O.t_rule(599.9) == 1.0 and O.t_rule(300.0) == 300.0 and O.t_rule(300.1) == 1.0
+    assert O.t_rule(0.0) == 0.0 and O.t_rule(200.0) == 200.0
+
+
+def test_t_model_sequence_s10():
+    sch = O.Schedule(10)
+    seq = [O.t_rule(float(sch.t_model(i))) for i in range(9, -1, -1)]
+    assert seq == [2.0, 2.0, 2.0, 600.0, 1.0, 1.0, 300.0, 200.0, 100.0, 0.0]
+
+
+# ----------------------------------------------------------------------------- G4
+def test_ddim_step_all_t():
+    g = load("ddim_step.npz")
+    sch = O.Schedule(50)
+    x_t, x0 = torch.from_numpy(g["x_t"]), torch.from_numpy(g["x0"])
+    for i in range(50):
+        got = O.ddim_step(sch, i, x_t, x0).numpy()
+        np.testing.assert_allclose(got, g["ddim50/sample"][i], rtol=0, atol=2e-6, err_msg=f"t={i}")
+
+
+def test_ddpm_mean_logvar():
+    g = load("ddim_step.npz")
+    sch = O.Schedule(250)
+    x_t, x0 = torch.from_numpy(g["x_t"]), torch.from_numpy(g["x0"])
+    for i in range(250):
+        mean, lv = O.ddpm_mean_logvar(sch, i, x_t, x0)
+        np.testing.assert_allclose(mean.numpy(), g["ddpm250/mean"][i], rtol=0, atol=1e-6)
+        assert np.float32(lv) == g["ddpm250/log_variance"][i]
+
+
+# ----------------------------------------------------------------------------- G5 / G6
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_unwarp_tail(tag):
+    g = load("unwarp.npz")
+    flow = torch.from_numpy(g[f"{tag}/flow"])
+    src = torch.from_numpy(g[f"{tag}/src_u8"]).permute(2, 0, 1)[None].float()
+    grid, out, out_u8 = O.unwarp_tail(flow, src)
+    np.testing.assert_allclose(grid.numpy(), g[f"{tag}/grid"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(out.numpy(), g[f"{tag}/out_f32"], rtol=0, atol=2e-3)
+    assert (np.abs(out_u8.astype(int) - g[f"{tag}/out_u8"].astype(int)) <= 1).all()
+    assert (out_u8 != g[f"{tag}/out_u8"]).mean() < 1e-3
+
+
+def test_grid_sample_dropin():
+    g = load("grid_sample.npz")
+    feat = torch.from_numpy(synth.uniform("g6/feat", (2, 256, 16, 16), 0.0, 2.0, 1234))
+    x0 = torch.from_numpy(g["x0"])
+    base = O.base_grid(16, 16)
+    np.testing.assert_allclose(base.numpy(), g["base"], rtol=0, atol=1e-7)
+    grid = (x0 + base) * 2 - 1
+    np.testing.assert_allclose(O.grid_sample_ref(feat, grid).numpy(), g["out"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(O.grid_sample_manual(feat, grid).numpy(), g["out"], rtol=0, atol=2e-5)
+
+
+# ----------------------------------------------------------------------------- G2
+def _doc(grid):
+    d = synth.synth_document(0, grid, 1234)
+    return {k: torch.from_numpy(v)[None] for k, v in d.items()}
+
+
+@pytest.mark.parametrize("grid", [16, 32, 64])
+def test_forward_vs_reference(grid):
+    g = load(f"forward_g{grid}.npz")
+    sd = synth.synth_state_dict(grid, int(g["seed_w"]), blocks=[11])
+    orc = O.Oracle(sd, grid)
+    doc = _doc(grid)
+    inv1 = orc.prepare(doc["y512"], doc["mask_cat"], doc["mask_y512"], doc["line_msk"])
+    inv = {k: v.repeat(2, *([1] * (v.dim() - 1))) for k, v in inv1.items()}
+    x = torch.from_numpy(g["x"])
+    init_flow = torch.from_numpy(g["init_flow"])
+    init_feat = torch.from_numpy(synth.uniform("g2/init_feat", (2, 256, grid, grid), 0.0, 1.5, 1234))
+    np.testing.assert_allclose(inv1["feat"][0, ::16, ::max(1, grid // 16), ::max(1, grid // 16)].numpy(),
+                               g["feat/sub"], rtol=0, atol=2e-5)
+    for tag in ("t2", "t1", "raw0", "raw600", "raw200"):
+        ck = {}
+        x0, _ = orc.forward(x, float(g[f"{tag}/t_in"]), inv, init_flow, init_feat, ck=ck)
+        for name, v in ck.items():
+            key = f"{tag}/ck/{name}/head"
+            if key in g.files:
+                scale = max(1.0, float(g[f"{tag}/ck/{name}/stats"][2]))
+                np.testing.assert_allclose(v.reshape(-1)[:64].numpy(), g[key], rtol=0, atol=2e-5 * scale,
+                                           err_msg=f"{tag}/{name}")
+                np.testing.assert_allclose(v.reshape(-1)[-64:].numpy(), g[f"{tag}/ck/{name}/tail"], rtol=0,
+                                           atol=2e-5 * scale, err_msg=f"{tag}/{name} tail")
+        err = np.abs(x0.numpy() - g[f"{tag}/x0"]).max()
+        assert err < 2e-5, (tag, err)
+
+
+# ----------------------------------------------------------------------------- G3
+@pytest.mark.parametrize("grid,steps", [(16, 3), (32, 3), (64, 3)])
+def test_loop_vs_reference(grid, steps):
+    g = load(f"loop_g{grid}_s{steps}.npz")
+    sd = synth.synth_state_dict(grid, int(g["seed_w"]), blocks=[11])
+    orc = O.Oracle(sd, grid)
+    sch = O.Schedule(steps)
+    trace = []
+    out = orc.sample_loop(sch, torch.from_numpy(g["x_T"]), _doc(grid), mean_hyp=(grid == 64), trace=trace)
+    for k, x0 in enumerate(trace):
+        err = np.abs(x0.numpy() - g["x0_steps"][k]).max()
+        assert err < 5e-5, (k, err)
+    np.testing.assert_allclose(out.numpy(), g["sample"], rtol=0, atol=5e-5)
+
+
+@pytest.mark.slow
+def test_loop_s10_vs_reference():
+    g = load("loop_g64_s10.npz")
+    sd = synth.synth_state_dict(64, int(g["seed_w"]), blocks=[11])
+    orc = O.Oracle(sd, 64)
+    sch = O.Schedule(10)
+    assert [O.t_rule(float(t)) for t in g["t_model"]] == [2.0, 2.0, 2.0, 600.0, 1.0, 1.0, 300.0, 200.0, 100.0, 0.0]
+    out = orc.sample_loop(sch, torch.from_numpy(g["x_T"]), _doc(64))
+    np.testing.assert_allclose(out.numpy(), g["sample"], rtol=0, atol=1e-4)
