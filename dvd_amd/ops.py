@@ -1,0 +1,91 @@
+"""Thin torch-tensor wrappers over the op-level entry points of libdvd_hip.so.
+
+PyTorch supplies device memory and the current HIP stream; every computation happens in the
+HIP library.  These wrappers mirror the reference callables they replace:
+  grid_sample  <- register_model2(size,'bilinear')([img, grid])   datasets/utils/warping.py:14-23
+  unwarp_*     <- evaluation.py:301-306 + visualization_utils.py:75-77
+  sched_step   <- GaussianDiffusion.ddim_sample arithmetic         idf/gaussian_diffusion.py:470-489
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import lib
+from .lib import ptr, stream_ptr
+
+
+def _chk(t: torch.Tensor, dtype, name):
+    if not t.is_cuda:
+        raise lib.DvdError(f"{name}: expected a device tensor (the DvD engine has no CPU path)")
+    if t.dtype != dtype or not t.is_contiguous():
+        raise lib.DvdError(f"{name}: expected contiguous {dtype}, got {t.dtype} contiguous={t.is_contiguous()}")
+
+
+def grid_sample(src: torch.Tensor, grid_nchw: torch.Tensor, src_batch_div: int = 1) -> torch.Tensor:
+    _chk(src, torch.float32, "src")
+    _chk(grid_nchw, torch.float32, "grid")
+    n, two, h, w = grid_nchw.shape
+    ns, c, hin, win = src.shape
+    assert two == 2 and ns * src_batch_div == n
+    out = torch.empty((n, c, h, w), dtype=torch.float32, device=src.device)
+    lib.call("dvd_grid_sample_bilinear_zeros_ac", ptr(src), ptr(grid_nchw), ptr(out), n, c, hin, win, h, w,
+             src_batch_div, stream_ptr())
+    return out
+
+
+def unwarp_grid(flow: torch.Tensor, h: int, w: int, scale: float = 0.987) -> torch.Tensor:
+    _chk(flow, torch.float32, "flow")
+    g = flow.shape[-1]
+    out = torch.empty((1, 2, h, w), dtype=torch.float32, device=flow.device)
+    lib.call("dvd_unwarp_grid", ptr(flow), g, ptr(out), h, w, C.c_float(scale), stream_ptr())
+    return out
+
+
+def unwarp_f32(flow: torch.Tensor, src_chw: torch.Tensor, scale: float = 0.987) -> torch.Tensor:
+    """flow [1,2,G,G] (or [2,G,G]); src [1,3,H,W] f32 0..255 -> [H,W,3] f32."""
+    _chk(flow, torch.float32, "flow")
+    _chk(src_chw, torch.float32, "src")
+    h, w = src_chw.shape[-2:]
+    out = torch.empty((h, w, 3), dtype=torch.float32, device=src_chw.device)
+    lib.call("dvd_unwarp_f32", ptr(flow), flow.shape[-1], ptr(src_chw), ptr(out), h, w, C.c_float(scale), stream_ptr())
+    return out
+
+
+def unwarp_u8(flow: torch.Tensor, src_hwc: torch.Tensor, scale: float = 0.987) -> torch.Tensor:
+    """flow [1,2,G,G]; src [H,W,3] uint8 -> [H,W,3] uint8 (truncated like numpy astype)."""
+    _chk(flow, torch.float32, "flow")
+    _chk(src_hwc, torch.uint8, "src")
+    h, w = src_hwc.shape[:2]
+    out = torch.empty_like(src_hwc)
+    lib.call("dvd_unwarp_u8", ptr(flow), flow.shape[-1], ptr(src_hwc), ptr(out), h, w, C.c_float(scale), stream_ptr())
+    return out
+
+
+def sched_step(coef: lib.SchedCoef, x_t, x0, noise=None, want_grid=False):
+    _chk(x_t, torch.float32, "x_t")
+    _chk(x0, torch.float32, "x0")
+    n, _, g, _ = x_t.shape
+    out = torch.empty_like(x_t)
+    ngrid = torch.empty_like(x_t) if want_grid else None
+    if noise is not None:
+        _chk(noise, torch.float32, "noise")
+    lib.call("dvd_sched_step", C.byref(coef), ptr(x_t), ptr(x0), ptr(noise), ptr(out), ptr(ngrid), n, g, stream_ptr())
+    return (out, ngrid) if want_grid else out
+
+
+def hyp_mean_clamp(x0: torch.Tensor, n_hyp: int) -> torch.Tensor:
+    _chk(x0, torch.float32, "x0")
+    n, _, g, _ = x0.shape
+    docs = n // n_hyp
+    out = torch.empty((docs, 2, g, g), dtype=torch.float32, device=x0.device)
+    lib.call("dvd_hyp_mean_clamp", ptr(x0), ptr(out), docs, n_hyp, g, stream_ptr())
+    return out
+
+
+def selftest_mfma(a16, b16, vt16):
+    out = torch.empty(3072, dtype=torch.float32, device=a16.device)
+    lib.call("dvd_selftest_mfma", ptr(a16), ptr(b16), ptr(vt16), ptr(out), stream_ptr())
+    return out

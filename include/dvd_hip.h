@@ -91,6 +91,12 @@ int dvd_sched_step(const dvd_sched_coef* coef, const float* x_t, const float* x0
  * (idf/gaussian_diffusion.py:639-640): x0 [docs*H,2,G,G] -> out [docs,2,G,G]. */
 int dvd_hyp_mean_clamp(const float* x0, float* out, int docs, int n_hyp, int g, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Hardware self-test of the MFMA fragment layouts the kernels rely on (exact integer data).
+ * a16 [32,16], b16 [16,32], vt16 [32,32] f16; out [3072] f32 = {A.B, Vt.(A.B) via accumulator-as-
+ * operand, f32-MFMA A[:, :2].B[:2, :]}.  No reference counterpart (test infrastructure). */
+int dvd_selftest_mfma(const void* a16, const void* b16, const void* vt16, float* out3072, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

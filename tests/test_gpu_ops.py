@@ -1,0 +1,146 @@
+"""GPU parity of the op-level HIP entry points (through the C ABI) against the CPU oracle and
+the golden vectors made from the real reference."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from dvd_amd import synth
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from dvd_amd import ops as _ops
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    return _ops
+
+
+def load(name):
+    return np.load(os.path.join(GOLD, name), allow_pickle=False)
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def test_mfma_fragment_layouts(ops):
+    rng = np.random.RandomState(0)
+    A = rng.randint(-3, 4, size=(32, 16)).astype(np.float32)
+    B = rng.randint(-3, 4, size=(16, 32)).astype(np.float32)
+    Vt = rng.randint(-2, 3, size=(32, 32)).astype(np.float32)
+    out = ops.selftest_mfma(dev(A.astype(np.float16)), dev(B.astype(np.float16)), dev(Vt.astype(np.float16)))
+    out = out.cpu().numpy()
+    X = A @ B
+    assert np.array_equal(out[:1024].reshape(32, 32), X), "f16 MFMA A/B/C fragment map"
+    assert np.array_equal(out[1024:2048].reshape(32, 32), Vt @ X), "accumulator-as-operand k permutation"
+    assert np.array_equal(out[2048:].reshape(32, 32), A[:, :2] @ B[:2, :]), "f32 MFMA fragment map"
+
+
+def test_grid_sample_golden(ops):
+    g = load("grid_sample.npz")
+    feat = synth.uniform("g6/feat", (2, 256, 16, 16), 0.0, 2.0, 1234)
+    out = ops.grid_sample(dev(feat), dev(g["grid"])).cpu().numpy()
+    np.testing.assert_allclose(out, g["out"], rtol=0, atol=2e-5)
+
+
+@pytest.mark.parametrize("shape", [(1, 3, 37, 53, 41, 29), (3, 5, 16, 16, 16, 16), (2, 1, 7, 300, 300, 9)])
+def test_grid_sample_oracle(ops, shape):
+    from oracle import dvd_oracle as O
+    n, c, hin, win, h, w = shape
+    src = torch.from_numpy(synth.uniform("gs/src", (n, c, hin, win), -1, 1, 3))
+    grid = torch.from_numpy(synth.uniform("gs/grid", (n, 2, h, w), -1.3, 1.3, 3))
+    grid[0, 0, 0, 0] = -1.0      # exact corners / borders
+    grid[0, 1, 0, 0] = -1.0
+    grid[0, 0, -1, -1] = 1.0
+    grid[0, 1, -1, -1] = 1.0
+    ref = O.grid_sample_ref(src, grid).numpy()
+    out = ops.grid_sample(src.cuda(), grid.cuda()).cpu().numpy()
+    np.testing.assert_allclose(out, ref, rtol=0, atol=2e-6)
+
+
+def test_grid_sample_shared_source(ops):
+    from oracle import dvd_oracle as O
+    src = torch.from_numpy(synth.uniform("gs2/src", (2, 4, 12, 12), -1, 1, 3))
+    grid = torch.from_numpy(synth.uniform("gs2/grid", (6, 2, 12, 12), -1.1, 1.1, 3))
+    ref = O.grid_sample_ref(src.repeat_interleave(3, 0), grid).numpy()
+    out = ops.grid_sample(src.cuda(), grid.cuda(), src_batch_div=3).cpu().numpy()
+    np.testing.assert_allclose(out, ref, rtol=0, atol=2e-6)
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_unwarp_golden(ops, tag):
+    g = load("unwarp.npz")
+    flow = dev(g[f"{tag}/flow"])
+    src_u8 = g[f"{tag}/src_u8"]
+    H, W = src_u8.shape[:2]
+    grid = ops.unwarp_grid(flow, H, W).cpu().numpy()
+    np.testing.assert_allclose(grid, g[f"{tag}/grid"], rtol=0, atol=2e-6)
+    src_f = dev(src_u8.transpose(2, 0, 1)[None].astype(np.float32))
+    out = ops.unwarp_f32(flow, src_f).cpu().numpy()
+    np.testing.assert_allclose(out, g[f"{tag}/out_f32"], rtol=0, atol=2e-3)
+    out8 = ops.unwarp_u8(flow, dev(src_u8)).cpu().numpy()
+    diff = np.abs(out8.astype(int) - g[f"{tag}/out_u8"].astype(int))
+    assert diff.max() <= 1 and (diff != 0).mean() < 2e-3, (diff.max(), (diff != 0).mean())
+
+
+def test_unwarp_full_size_properties(ops):
+    """BASELINE config 5 size (3508x2480): identity flow reproduces the 0.987-scaled resample; a
+    constant image stays constant inside the valid region; u8 and f32 paths agree."""
+    H, W, G = 3508, 2480, 288
+    flow = torch.zeros(1, 2, G, G, device="cuda")
+    src8 = torch.from_numpy(synth.synth_document(1, 8, 1234, full_res=(H, W))["src_u8"]).cuda()
+    srcf = src8.permute(2, 0, 1)[None].float().contiguous()
+    of = ops.unwarp_f32(flow, srcf)
+    o8 = ops.unwarp_u8(flow, src8)
+    assert torch.equal(of.to(torch.int32).clamp(0, 255).to(torch.uint8), o8)
+    const = torch.full_like(srcf, 77.0)
+    oc = ops.unwarp_f32(flow, const)
+    assert float((oc - 77.0).abs().max()) < 1e-3      # 0.987 scale keeps every tap in range
+    # linearity in the source
+    of2 = ops.unwarp_f32(flow, srcf * 0.5)
+    assert float((of2 - 0.5 * of).abs().max()) < 1e-3
+
+
+def test_sched_step_golden(ops):
+    from dvd_amd import schedule
+    g = load("ddim_step.npz")
+    x_t, x0 = dev(g["x_t"]), dev(g["x0"])
+    tab = schedule.Tables(schedule.named_betas("cosine", 50))
+    for i in range(50):
+        out = ops.sched_step(tab.ddim_coef(i), x_t, x0).cpu().numpy()
+        np.testing.assert_allclose(out, g["ddim50/sample"][i], rtol=0, atol=2e-6, err_msg=f"t={i}")
+    tab = schedule.Tables(schedule.named_betas("cosine", 250))
+    for i in range(0, 250, 7):
+        c = tab.ddpm_coef(i)
+        c.sigma = 0.0
+        out = ops.sched_step(c, x_t, x0).cpu().numpy()
+        np.testing.assert_allclose(out, g["ddpm250/mean"][i], rtol=0, atol=1e-6)
+
+
+def test_sched_step_bit_exact_vs_oracle(ops):
+    from dvd_amd import schedule
+    from oracle import dvd_oracle as O
+    G = 32
+    x_t = torch.from_numpy(synth.normalish("ss/x", (4, 2, G, G), 5))
+    x0 = torch.from_numpy(synth.uniform("ss/x0", (4, 2, G, G), -1, 1, 5))
+    nz = torch.from_numpy(synth.normalish("ss/n", (4, 2, G, G), 5))
+    tab = schedule.Tables(schedule.named_betas("cosine", 10))
+    sch = O.Schedule(10)
+    for i in (9, 5, 1, 0):
+        out, grid = ops.sched_step(tab.ddim_coef(i), x_t.cuda(), x0.cuda(), want_grid=True)
+        assert torch.equal(out.cpu(), O.ddim_step(sch, i, x_t, x0)), i
+        ref_grid = (x0 + O.base_grid(G, G)) * 2 - 1
+        np.testing.assert_allclose(grid.cpu().numpy(), ref_grid.numpy(), rtol=0, atol=2.5e-7)
+        out = ops.sched_step(tab.ddpm_coef(i), x_t.cuda(), x0.cuda(), noise=nz.cuda())
+        np.testing.assert_allclose(out.cpu().numpy(), O.ddpm_step(sch, i, x_t, x0, nz).numpy(), rtol=0, atol=1e-6)
+
+
+def test_hyp_mean_clamp(ops):
+    x0 = torch.from_numpy(synth.uniform("hm/x0", (6, 2, 16, 16), -1.5, 1.5, 5))
+    out = ops.hyp_mean_clamp(x0.cuda(), 2).cpu()
+    ref = torch.stack([torch.clamp(x0[2 * d:2 * d + 2].mean(0), -1, 1) for d in range(3)])
+    assert torch.equal(out, ref)
