@@ -26,7 +26,11 @@ def timeit(fn, iters=20, warm=3):
 
 def bench_unwarp():
     H, W, G = 3508, 2480, 288
-    flow = torch.from_numpy(synth.uniform("b/flow", (1, 2, G, G), -0.05, 0.05, 1)).cuda()
+    # document-like displacement: smooth (bicubic-upsampled 6x6 control points), +-0.05 normalised
+    ctrl = torch.from_numpy(synth.uniform("b/flow", (1, 2, 6, 6), -0.05, 0.05, 1))
+    flow = torch.nn.functional.interpolate(ctrl, size=(G, G), mode="bicubic", align_corners=True).contiguous().cuda()
+    if os.environ.get("DVD_BENCH_RANDOM_FLOW"):
+        flow = torch.from_numpy(synth.uniform("b/flow", (1, 2, G, G), -0.05, 0.05, 1)).cuda()
     src8 = torch.from_numpy(synth.synth_document(0, 8, 1, full_res=(H, W))["src_u8"]).cuda()
     srcf = src8.permute(2, 0, 1)[None].float().contiguous()
     px = H * W
@@ -47,9 +51,24 @@ def bench_unwarp():
     return res
 
 
+def bench_gemm():
+    res = {}
+    for (M, N, K, dt) in [(16 * 20736, 1536, 1536, torch.float16), (16 * 20736, 4608, 1536, torch.float16),
+                          (16 * 20736, 2048, 1536, torch.float16), (4 * 16 * 20736 // 4, 1152, 384, torch.float16),
+                          (2048, 1536, 1536, torch.float16), (8 * 20736, 384, 1536, torch.float32)]:
+        a = torch.randn(M, K, device="cuda").to(dt)
+        b = torch.randn(N, K, device="cuda").to(dt)
+        out = torch.empty(M, N, dtype=torch.float16, device="cuda")
+        t = timeit(lambda: ops.gemm_nt(a, b, out16=out), iters=5, warm=2)
+        res[f"gemm_{'f16' if dt == torch.float16 else 'f32'}_{M}x{N}x{K}"] = {"ms": t * 1e3, "TFLOPs": 2.0 * M * N * K / t / 1e12}
+    return res
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["unwarp"]
     out = {}
     if "unwarp" in which:
         out.update(bench_unwarp())
+    if "gemm" in which:
+        out.update(bench_gemm())
     print(json.dumps(out, indent=1))

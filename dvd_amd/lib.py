@@ -10,6 +10,11 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+# torch must be imported BEFORE the library is loaded: the PyTorch-ROCm wheel bundles its own
+# libamdhip64.so.7 and libdvd_hip.so must bind to that same HIP runtime (same SONAME => the loader
+# reuses it); loading ours first would create a second runtime that sees no device.
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdvd_hip.so")
 
@@ -38,6 +43,19 @@ class SchedCoef(C.Structure):
                 ("coef2", C.c_float), ("sigma", C.c_float)]
 
 
+class GemmDesc(C.Structure):
+    _fields_ = [("dtype", C.c_int), ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("batch", C.c_int),
+                ("A", C.c_void_p), ("lda", C.c_int), ("strideA", C.c_long),
+                ("B", C.c_void_p), ("ldb", C.c_int), ("strideB", C.c_long),
+                ("C32", C.c_void_p), ("ldc", C.c_int), ("strideC32", C.c_long),
+                ("C16", C.c_void_p), ("ldc16", C.c_int), ("strideC16", C.c_long),
+                ("bias", C.c_void_p), ("bias_row", C.c_int), ("strideBias", C.c_long),
+                ("act", C.c_int),
+                ("pos", C.c_void_p), ("ldpos", C.c_int), ("pos_rows", C.c_int),
+                ("gate", C.c_void_p), ("ldgate", C.c_int), ("gate_rows", C.c_int), ("strideGate", C.c_long),
+                ("res", C.c_void_p), ("ldres", C.c_int), ("strideRes", C.c_long)]
+
+
 def _sig(name, argtypes, restype=C.c_int):
     fn = getattr(_lib, name)
     fn.argtypes = argtypes
@@ -58,6 +76,7 @@ SIGNATURES = {
     "dvd_sched_step": [C.POINTER(SchedCoef), c_void, c_void, c_void, c_void, c_void, C.c_int, C.c_int, c_void],
     "dvd_hyp_mean_clamp": [c_void, c_void, C.c_int, C.c_int, C.c_int, c_void],
     "dvd_selftest_mfma": [c_void, c_void, c_void, c_void, c_void],
+    "dvd_gemm_nt": [C.POINTER(GemmDesc), c_void],
 }
 
 

@@ -89,3 +89,37 @@ def selftest_mfma(a16, b16, vt16):
     out = torch.empty(3072, dtype=torch.float32, device=a16.device)
     lib.call("dvd_selftest_mfma", ptr(a16), ptr(b16), ptr(vt16), ptr(out), stream_ptr())
     return out
+
+
+def _addr(t):
+    return None if t is None else t.data_ptr()
+
+
+def gemm_nt(a, b, *, out32=None, out16=None, bias=None, bias_row=False, act=0, pos=None, gate=None,
+            gate_rows=0, res=None, batch=1, strides=None, M=None, N=None, K=None, lda=None, ldb=None):
+    """C = epi(A . B^T).  a [M,K] / b [N,K] f16 or f32 device tensors (2-D views may be strided in rows).
+    strides: dict of batch strides in elements (A,B,C32,C16,bias,gate,res)."""
+    assert a.dtype == b.dtype and a.dtype in (torch.float16, torch.float32)
+    d = lib.GemmDesc()
+    d.dtype = 1 if a.dtype == torch.float32 else 0
+    d.M = M if M is not None else a.shape[-2]
+    d.N = N if N is not None else b.shape[-2]
+    d.K = K if K is not None else a.shape[-1]
+    d.batch = batch
+    st = strides or {}
+    d.A, d.lda, d.strideA = _addr(a), (lda if lda is not None else a.stride(-2)), st.get("A", 0)
+    d.B, d.ldb, d.strideB = _addr(b), (ldb if ldb is not None else b.stride(-2)), st.get("B", 0)
+    if out32 is not None:
+        d.C32, d.ldc, d.strideC32 = _addr(out32), out32.stride(-2), st.get("C32", 0)
+    if out16 is not None:
+        d.C16, d.ldc16, d.strideC16 = _addr(out16), out16.stride(-2), st.get("C16", 0)
+    if bias is not None:
+        d.bias, d.bias_row, d.strideBias = _addr(bias), int(bias_row), st.get("bias", 0)
+    d.act = act
+    if pos is not None:
+        d.pos, d.ldpos, d.pos_rows = _addr(pos), pos.stride(-2), pos.shape[-2]
+    if gate is not None:
+        d.gate, d.ldgate, d.gate_rows, d.strideGate = _addr(gate), gate.stride(-2), gate_rows, st.get("gate", 0)
+    if res is not None:
+        d.res, d.ldres, d.strideRes = _addr(res), res.stride(-2), st.get("res", 0)
+    lib.call("dvd_gemm_nt", C.byref(d), stream_ptr())

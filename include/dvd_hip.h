@@ -92,6 +92,34 @@ int dvd_sched_step(const dvd_sched_coef* coef, const float* x_t, const float* x0
 int dvd_hyp_mean_clamp(const float* x0, float* out, int docs, int n_hyp, int g, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * GEMM with fused epilogue:  C[M,N] = epi(A[M,K] . B[N,K]^T)  - replaces every nn.Linear / 1x1 conv
+ * / patch-embed conv on the path together with the ATen ops that follow it in the reference:
+ *   timm Attention.qkv/proj, Mlp.fc1(+GELU tanh)/fc2 (idf/cross_model.py:163-174,268-292),
+ *   nn.MultiheadAttention in/out projections (:203-205,237-265), PatchEmbed + pos-embed (:571-605),
+ *   decoder linear_q/k/v/fc and conv1/conv2 + folded BatchNorm + ReLU (idf/cross_attn.py:52-57,197-221),
+ *   adaLN gate * (.) + residual (idf/cross_model.py:268-292).
+ * dtype 0: A,B f16, fp32 accumulate (MFMA 32x32x16 f16);  dtype 1: A,B f32, exact fp32 MFMA.
+ *   out = acc (+ bias[col] or bias[row]) -> act -> (+ pos[row % pos_rows][col]) -> (* gate[row / gate_rows][col])
+ *         -> (+ res[row][col]);  stored to C32 (f32) and/or C16 (f16).
+ * Batched over `batch` with element strides (0 = shared operand).  K % 64 == 0 (f16) / % 16 (f32);
+ * rows of A/B 16-byte aligned. */
+typedef struct {
+  int dtype;
+  int M, N, K, batch;
+  const void* A; int lda; long strideA;
+  const void* B; int ldb; long strideB;
+  float* C32; int ldc; long strideC32;
+  void* C16; int ldc16; long strideC16;
+  const float* bias; int bias_row; long strideBias;
+  int act;                                   /* 0 none, 1 GELU(tanh), 2 ReLU */
+  const float* pos; int ldpos; int pos_rows;
+  const float* gate; int ldgate; int gate_rows; long strideGate;
+  const float* res; int ldres; long strideRes;
+} dvd_gemm_desc;
+
+int dvd_gemm_nt(const dvd_gemm_desc* desc, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Hardware self-test of the MFMA fragment layouts the kernels rely on (exact integer data).
  * a16 [32,16], b16 [16,32], vt16 [32,32] f16; out [3072] f32 = {A.B, Vt.(A.B) via accumulator-as-
  * operand, f32-MFMA A[:, :2].B[:2, :]}.  No reference counterpart (test infrastructure). */
