@@ -1,0 +1,271 @@
+// Flash-style multi-head attention for the denoiser (f16 operands, fp32 softmax / accumulate):
+//   O = softmax(scale * Q K^T) V      per (batch, head), never materialising the T x T scores.
+// Replaces the three attention flavours on the path:
+//   nn.MultiheadAttention core   6 heads x 64   (idf/cross_model.py:203-205,237-265)
+//   timm Attention core          6 heads x 64   (idf/cross_model.py:163-165,268-289)
+//   SATRN ScaledDotProductAttention 6 heads x 256, temperature 16, all-ones mask
+//                                               (idf/cross_attn.py:73-83,197-221)
+// At the BASELINE grid (T = 20736 tokens) these are 83 % of all FLOPs of a denoiser step.
+//
+// Structure (one 256-thread workgroup = 4 waves = 128 query rows; one wave owns 32 query rows):
+//   * "swapped" first product  S^T[key][q] = K . Q^T  (A = K rows from LDS, B = Q fragments in
+//     registers), so the softmax axis (keys) lies in the accumulator registers of a lane and the
+//     query on the lane: row max / sum are register reductions + ONE cross-half exchange, and the
+//     online-softmax rescale factor is a per-lane scalar.
+//   * the S^T accumulator, converted to f16, IS the B operand of the second product
+//     O^T[d][q] = V^T . P^T  (guide section 3 "accumulator tile as the next MFMA's operand"); the k-order
+//     permutation this implies is absorbed by reading K rows in a bit-swapped order (kappa), so
+//     the V^T operand is a plain 16-byte LDS read.
+//   * V is consumed TRANSPOSED ([head_dim, T] per batch, keys contiguous): the projection GEMM
+//     writes it that way for free by swapping its operands (dvd_gemm_nt with A = W_v).
+//   * K / V^T tiles of 64 keys are double-buffered in LDS (rows padded by 16 B: conflict-free
+//     ds_read_b128), global loads for tile t+1 are issued before the MFMAs of tile t.
+//   * XCD-aware workgroup order: the q-blocks that run concurrently on one XCD belong to the same
+//     (batch, head), so its K/V stream is served from that XCD's L2.
+#include "common.h"
+#include "mfma.h"
+
+namespace dvd {
+
+struct AttnArgs {
+  const _Float16* Q;
+  const _Float16* K;
+  const _Float16* Vt;
+  _Float16* O;
+  long sQ, sK, sVt, sO;  // batch strides (elements)
+  int ldq, ldk, ldvt, ldo;
+  int heads, batch, tq, tk;
+  int kv_div;            // kv batch = b / kv_div
+  int nqb;               // query blocks per (b, h)
+  float c;               // scale * log2(e)
+};
+
+__device__ __forceinline__ int kappa(int r) {  // swap bits 2 and 3
+  return (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1);
+}
+
+template <int D>
+__global__ void __launch_bounds__(256, (D == 256 ? 1 : 2)) flash_attn_kernel(AttnArgs p) {
+  constexpr int KB = 64;                 // keys per tile
+  constexpr int KP = 2 * D + 16;         // K tile row pitch (bytes)
+  constexpr int VP = 2 * KB + 16;        // V^T tile row pitch (bytes)
+  constexpr int KBYTES = KB * KP, VBYTES = D * VP;
+  constexpr int KCH = D / 8;             // 16-B chunks per K row
+  constexpr int NK = KB * KCH / 256;     // K chunks per thread   (8 / 2)
+  constexpr int NV = D * 8 / 256;        // V^T chunks per thread (8 / 2)
+  constexpr int KS = D / 16;             // k-steps of the first product
+  constexpr int DT = D / 32;             // 32-row tiles of O^T
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][KBYTES + VBYTES]
+
+  const int nwg = gridDim.x;
+  int id = blockIdx.x;
+  {
+    const int q = nwg / 8, rr = nwg % 8, xcd = id % 8, k = id / 8;
+    id = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + k;
+  }
+  const int qb = id % p.nqb;
+  const int bh = id / p.nqb;
+  const int head = bh % p.heads, b = bh / p.heads;
+  const int kvb = b / p.kv_div;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+
+  const _Float16* Qg = p.Q + b * p.sQ + (size_t)head * D;
+  const _Float16* Kg = p.K + kvb * p.sK + (size_t)head * D;
+  const _Float16* Vg = p.Vt + kvb * p.sVt + (size_t)head * D * p.ldvt;
+
+  // ---- Q fragments (B operand of S^T = K . Q^T): lane (q = r, half h) holds Q[q][16 ks + 8 h + j]
+  const int qrow = min(qb * 128 + wave * 32 + r, p.tq - 1);
+  half8 qf[KS];
+  {
+    const _Float16* qp = Qg + (size_t)qrow * p.ldq + 8 * h;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const half8*)(qp + 16 * ks);
+  }
+
+  floatx16 o[DT];
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) o[dt][i] = 0.f;
+  float m_run = -1e30f, l_run = 0.f;
+
+  // ---- staging slots
+  u32x4 kreg[NK], vreg[NV];
+  int k_lofs[NK], v_lofs[NV];
+  int k_row[NK], k_col[NK], v_row[NV], v_col[NV];
+#pragma unroll
+  for (int i = 0; i < NK; ++i) {
+    const int cidx = tid + 256 * i;
+    k_row[i] = cidx / KCH;
+    k_col[i] = (cidx % KCH) * 8;
+    k_lofs[i] = k_row[i] * KP + (cidx % KCH) * 16;
+  }
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int cidx = tid + 256 * i;
+    v_row[i] = cidx / 8;
+    v_col[i] = (cidx % 8) * 8;
+    v_lofs[i] = KBYTES + v_row[i] * VP + (cidx % 8) * 16;
+  }
+  const int nt = (p.tk + KB - 1) / KB;
+
+#define DVD_ATTN_GLOAD(t_)                                                                  \
+  {                                                                                         \
+    const int key0 = (t_) * KB;                                                             \
+    _Pragma("unroll") for (int i = 0; i < NK; ++i) {                                        \
+      const int kr = min(key0 + k_row[i], p.tk - 1);                                        \
+      kreg[i] = *(const u32x4*)(Kg + (size_t)kr * p.ldk + k_col[i]);                        \
+    }                                                                                       \
+    _Pragma("unroll") for (int i = 0; i < NV; ++i) {                                        \
+      const int kc = key0 + v_col[i];                                                       \
+      u32x4 v = {0u, 0u, 0u, 0u};                                                           \
+      if (kc < p.tk) v = *(const u32x4*)(Vg + (size_t)v_row[i] * p.ldvt + kc);              \
+      vreg[i] = v;                                                                          \
+    }                                                                                       \
+  }
+#define DVD_ATTN_LSTORE(buf_)                                                               \
+  {                                                                                         \
+    char* base = smem + (buf_) * (KBYTES + VBYTES);                                         \
+    _Pragma("unroll") for (int i = 0; i < NK; ++i) *(u32x4*)(base + k_lofs[i]) = kreg[i];   \
+    _Pragma("unroll") for (int i = 0; i < NV; ++i) *(u32x4*)(base + v_lofs[i]) = vreg[i];   \
+  }
+
+  DVD_ATTN_GLOAD(0)
+  DVD_ATTN_LSTORE(0)
+  __syncthreads();
+
+  const int kr_ofs = kappa(r) * KP + 16 * h;   // byte offset of this lane's K fragment (kb = 0, ks = 0)
+  const int vr_ofs = KBYTES + r * VP + 16 * h; // byte offset of this lane's V^T fragment (dt = 0, kb = 0, s = 0)
+  int cur = 0;
+  for (int t = 0; t < nt; ++t) {
+    const bool more = t + 1 < nt;
+    if (more) DVD_ATTN_GLOAD(t + 1)
+    const char* base = smem + cur * (KBYTES + VBYTES);
+
+    // ---- S^T = K . Q^T   (two 32-key blocks)
+    floatx16 s[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) s[kb][i] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const half8 kf = *(const half8*)(base + kr_ofs + kb * 32 * KP + ks * 32);
+        s[kb] = mfma32_f16(kf, qf[ks], s[kb]);
+      }
+    }
+
+    // ---- online softmax over the 64 keys of this tile (query = lane column)
+    if (t == nt - 1 && (p.tk % KB) != 0) {
+      const int key0 = t * KB;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+          if (key0 + 32 * kb + kappa(cd_row(i, h)) >= p.tk) s[kb][i] = -1e30f;
+    }
+    float mx = -1e30f;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) mx = fmaxf(mx, s[kb][i]);
+    mx *= p.c;                                  // c > 0
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    m_run = m_new;
+    float rs = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const float pv = __builtin_amdgcn_exp2f(fmaf(s[kb][i], p.c, -m_new));
+        s[kb][i] = pv;
+        rs += pv;
+      }
+    l_run = l_run * alpha + rs;                 // per-lane partial (this half's keys)
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) o[dt][i] *= alpha;
+
+    // ---- O^T += V^T . P^T
+    half8 pf[2][2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) pf[kb][s2] = pack_acc_f16(s[kb], s2);
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const half8 vf = *(const half8*)(base + vr_ofs + dt * 32 * VP + (32 * kb + 16 * s2) * 2);
+          o[dt] = mfma32_f16(vf, pf[kb][s2], o[dt]);
+        }
+    }
+
+    if (more) DVD_ATTN_LSTORE(cur ^ 1)
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // ---- epilogue: O[q][d] = O^T[d][q] / l
+  const float l_tot = l_run + __shfl_xor(l_run, 32);
+  const float inv = 1.f / l_tot;
+  const int qglob = qb * 128 + wave * 32 + r;
+  if (qglob < p.tq) {
+    _Float16* op = p.O + b * p.sO + (size_t)qglob * p.ldo + (size_t)head * D;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        half4 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = (_Float16)(o[dt][4 * g4 + j] * inv);
+        *(half4*)(op + 32 * dt + 8 * g4 + 4 * h) = v;
+      }
+  }
+}
+
+}  // namespace dvd
+
+using namespace dvd;
+
+extern "C" int dvd_flash_attn(const dvd_attn_desc* d, void* stream) {
+  DVD_REQUIRE(d && d->Q && d->K && d->Vt && d->O, "flash_attn: null pointer");
+  DVD_REQUIRE(d->head_dim == 64 || d->head_dim == 256, "flash_attn: head_dim %d not in {64,256}", d->head_dim);
+  DVD_REQUIRE(d->heads > 0 && d->batch > 0 && d->tq > 0 && d->tk > 0 && d->kv_batch_div > 0, "flash_attn: bad shape");
+  DVD_REQUIRE(d->tk % 8 == 0, "flash_attn: tk=%d must be a multiple of 8", d->tk);
+  DVD_REQUIRE(d->ldq % 8 == 0 && d->ldk % 8 == 0 && d->ldvt % 8 == 0 && d->ldo % 4 == 0 &&
+                  d->strideQ % 8 == 0 && d->strideK % 8 == 0 && d->strideVt % 8 == 0 && d->strideO % 4 == 0 &&
+                  ((uintptr_t)d->Q % 16) == 0 && ((uintptr_t)d->K % 16) == 0 && ((uintptr_t)d->Vt % 16) == 0 &&
+                  ((uintptr_t)d->O % 8) == 0,
+              "flash_attn: operands must be 16-byte aligned");
+  AttnArgs p;
+  p.Q = (const _Float16*)d->Q; p.K = (const _Float16*)d->K; p.Vt = (const _Float16*)d->Vt; p.O = (_Float16*)d->O;
+  p.sQ = d->strideQ; p.sK = d->strideK; p.sVt = d->strideVt; p.sO = d->strideO;
+  p.ldq = d->ldq; p.ldk = d->ldk; p.ldvt = d->ldvt; p.ldo = d->ldo;
+  p.heads = d->heads; p.batch = d->batch; p.tq = d->tq; p.tk = d->tk;
+  p.kv_div = d->kv_batch_div;
+  p.nqb = cdiv(d->tq, 128);
+  p.c = d->scale * 1.4426950408889634f;
+  const long nwg = (long)p.nqb * d->heads * d->batch;
+  DVD_REQUIRE(nwg < (1l << 31), "flash_attn: grid too large");
+  if (d->head_dim == 256) {
+    constexpr int LDS = 2 * (64 * (2 * 256 + 16) + 256 * (2 * 64 + 16));
+    static bool once = false;
+    if (!once) {
+      hipFuncSetAttribute((const void*)flash_attn_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+      once = true;
+    }
+    flash_attn_kernel<256><<<(unsigned)nwg, 256, LDS, (hipStream_t)stream>>>(p);
+  } else {
+    constexpr int LDS = 2 * (64 * (2 * 64 + 16) + 64 * (2 * 64 + 16));
+    flash_attn_kernel<64><<<(unsigned)nwg, 256, LDS, (hipStream_t)stream>>>(p);
+  }
+  return check_launch("flash_attn");
+}

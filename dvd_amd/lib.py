@@ -56,6 +56,16 @@ class GemmDesc(C.Structure):
                 ("res", C.c_void_p), ("ldres", C.c_int), ("strideRes", C.c_long)]
 
 
+class AttnDesc(C.Structure):
+    _fields_ = [("head_dim", C.c_int), ("heads", C.c_int), ("batch", C.c_int), ("tq", C.c_int), ("tk", C.c_int),
+                ("kv_batch_div", C.c_int),
+                ("Q", C.c_void_p), ("ldq", C.c_int), ("strideQ", C.c_long),
+                ("K", C.c_void_p), ("ldk", C.c_int), ("strideK", C.c_long),
+                ("Vt", C.c_void_p), ("ldvt", C.c_int), ("strideVt", C.c_long),
+                ("O", C.c_void_p), ("ldo", C.c_int), ("strideO", C.c_long),
+                ("scale", C.c_float)]
+
+
 def _sig(name, argtypes, restype=C.c_int):
     fn = getattr(_lib, name)
     fn.argtypes = argtypes
@@ -77,6 +87,7 @@ SIGNATURES = {
     "dvd_hyp_mean_clamp": [c_void, c_void, C.c_int, C.c_int, C.c_int, c_void],
     "dvd_selftest_mfma": [c_void, c_void, c_void, c_void, c_void],
     "dvd_gemm_nt": [C.POINTER(GemmDesc), c_void],
+    "dvd_flash_attn": [C.POINTER(AttnDesc), c_void],
 }
 
 

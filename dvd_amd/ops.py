@@ -123,3 +123,17 @@ def gemm_nt(a, b, *, out32=None, out16=None, bias=None, bias_row=False, act=0, p
     if res is not None:
         d.res, d.ldres, d.strideRes = _addr(res), res.stride(-2), st.get("res", 0)
     lib.call("dvd_gemm_nt", C.byref(d), stream_ptr())
+
+
+def flash_attn(q, k, vt, out, heads, head_dim, scale, kv_batch_div=1):
+    """q [B,Tq,*] k [Bkv,Tk,*] (row-strided views ok), vt [Bkv, heads*hd, Tk], out [B,Tq,heads*hd]; all f16."""
+    d = lib.AttnDesc()
+    d.head_dim, d.heads, d.batch, d.tq, d.tk = head_dim, heads, q.shape[0], q.shape[1], k.shape[1]
+    d.kv_batch_div = kv_batch_div
+    d.Q, d.ldq, d.strideQ = q.data_ptr(), q.stride(1), q.stride(0)
+    d.K, d.ldk, d.strideK = k.data_ptr(), k.stride(1), k.stride(0)
+    d.Vt, d.ldvt, d.strideVt = vt.data_ptr(), vt.stride(1), vt.stride(0)
+    d.O, d.ldo, d.strideO = out.data_ptr(), out.stride(1), out.stride(0)
+    d.scale = scale
+    lib.call("dvd_flash_attn", C.byref(d), stream_ptr())
+    return out

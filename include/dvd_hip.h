@@ -120,6 +120,28 @@ typedef struct {
 int dvd_gemm_nt(const dvd_gemm_desc* desc, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Flash attention core  O = softmax(scale * Q K^T) V  per (batch, head); f16 in/out, fp32 softmax.
+ * Replaces the score/softmax/value products inside nn.MultiheadAttention (idf/cross_model.py:237-265),
+ * timm Attention (:268-289) and SATRN ScaledDotProductAttention (idf/cross_attn.py:73-83; its
+ * all-ones mask is a no-op and dropout is identity in eval mode).
+ *   Q  [batch, tq, heads*head_dim]  row stride ldq  (may point into a fused qkv buffer)
+ *   K  [kv_batch, tk, heads*head_dim] row stride ldk
+ *   Vt [kv_batch, heads*head_dim, tk] row stride ldvt  (V TRANSPOSED: keys contiguous)
+ *   O  [batch, tq, heads*head_dim]  row stride ldo
+ * kv batch of query batch b is b / kv_batch_div (hypotheses of one document share its conditioning
+ * K/V).  head_dim in {64, 256}; tk % 8 == 0. */
+typedef struct {
+  int head_dim, heads, batch, tq, tk, kv_batch_div;
+  const void* Q; int ldq; long strideQ;
+  const void* K; int ldk; long strideK;
+  const void* Vt; int ldvt; long strideVt;
+  void* O; int ldo; long strideO;
+  float scale;
+} dvd_attn_desc;
+
+int dvd_flash_attn(const dvd_attn_desc* desc, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Hardware self-test of the MFMA fragment layouts the kernels rely on (exact integer data).
  * a16 [32,16], b16 [16,32], vt16 [32,32] f16; out [3072] f32 = {A.B, Vt.(A.B) via accumulator-as-
  * operand, f32-MFMA A[:, :2].B[:2, :]}.  No reference counterpart (test infrastructure). */

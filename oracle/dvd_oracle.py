@@ -88,31 +88,42 @@ def t_rule(t_model: float):
     return float(t_model)
 
 
+def _extract(arr, i: int, like):
+    """`_extract_into_tensor` (idf/gaussian_diffusion.py:1181-1197): gather arr[t] for the batch of
+    (identical) timesteps, cast float64 -> float32, shape [N,1,1,1] so that every use below is a true
+    broadcast tensor op exactly as in the reference (NOT a python-scalar op, which ATen may evaluate
+    differently, e.g. division by a scalar as multiplication by its reciprocal)."""
+    t = torch.full((like.shape[0],), int(i), dtype=torch.long)
+    res = torch.from_numpy(np.asarray(arr, dtype=np.float64))[t].float()
+    while res.dim() < like.dim():
+        res = res[..., None]
+    return res
+
+
 def ddim_step(sch: Schedule, i: int, x_t, x0, eta: float = 0.0, noise=None):
-    """idf/gaussian_diffusion.py:434-438,470-489 (eta=0 on the path).  fp32 coefficients
-    gathered from the float64 tables (`_extract_into_tensor` :1191-1195)."""
-    f = lambda a: torch.tensor(a[i], dtype=torch.float64).float()  # noqa: E731
-    eps = (f(sch.sqrt_recip_alphas_cumprod) * x_t - x0) / f(sch.sqrt_recipm1_alphas_cumprod)
-    ab, abp = f(sch.alphas_cumprod), f(sch.alphas_cumprod_prev)
+    """idf/gaussian_diffusion.py:434-438,470-489 (eta=0 on the path)."""
+    eps = (_extract(sch.sqrt_recip_alphas_cumprod, i, x_t) * x_t - x0) / _extract(sch.sqrt_recipm1_alphas_cumprod, i, x_t)
+    ab, abp = _extract(sch.alphas_cumprod, i, x_t), _extract(sch.alphas_cumprod_prev, i, x_t)
     sigma = eta * torch.sqrt((1 - abp) / (1 - ab)) * torch.sqrt(1 - ab / abp)
     mean = x0 * torch.sqrt(abp) + torch.sqrt(1 - abp - sigma ** 2) * eps
     if noise is None:
         noise = torch.zeros_like(x_t)
-    return mean + (1.0 if i != 0 else 0.0) * sigma * noise
+    nonzero = torch.full((x_t.shape[0], 1, 1, 1), 1.0 if i != 0 else 0.0)
+    return mean + nonzero * sigma * noise
 
 
 def ddpm_mean_logvar(sch: Schedule, i: int, x_t, x0):
     """p_mean_variance with START_X / FIXED_LARGE (idf/gaussian_diffusion.py:270-292,365-415)."""
-    f = lambda a: torch.tensor(a[i], dtype=torch.float64).float()  # noqa: E731
-    mean = f(sch.posterior_mean_coef1) * x0 + f(sch.posterior_mean_coef2) * x_t
-    return mean, f(sch.fixed_large_log_variance)
+    mean = _extract(sch.posterior_mean_coef1, i, x_t) * x0 + _extract(sch.posterior_mean_coef2, i, x_t) * x_t
+    return mean, _extract(sch.fixed_large_log_variance, i, x_t)
 
 
 def ddpm_step(sch: Schedule, i: int, x_t, x0, noise):
     """Ancestral step.  The reference has NO p_sample; mean/log-variance are pinned
     by golden G4, the line below is the textbook improved-diffusion p_sample: PARITY UNPINNED."""
     mean, logvar = ddpm_mean_logvar(sch, i, x_t, x0)
-    return mean + (1.0 if i != 0 else 0.0) * torch.exp(0.5 * logvar) * noise
+    nonzero = torch.full((x_t.shape[0], 1, 1, 1), 1.0 if i != 0 else 0.0)
+    return mean + nonzero * torch.exp(0.5 * logvar) * noise
 
 
 # ----------------------------------------------------------------------------------------

@@ -1,0 +1,68 @@
+"""GPU parity of the flash-attention kernel vs an exact float64 softmax(QK^T)V on the same
+f16-rounded operands; includes a forced online-softmax rescale case (guide rule 26)."""
+import pytest
+import torch
+
+from dvd_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from dvd_amd import ops as _ops
+    return _ops
+
+
+def ref_attn(q, k, v, heads, hd, scale, kv_div):
+    B, Tq, _ = q.shape
+    qh = q.double().reshape(B, Tq, heads, hd).transpose(1, 2)
+    kh = k.double().reshape(k.shape[0], -1, heads, hd).transpose(1, 2).repeat_interleave(kv_div, 0)
+    vh = v.double().reshape(v.shape[0], -1, heads, hd).transpose(1, 2).repeat_interleave(kv_div, 0)
+    a = torch.softmax(qh @ kh.transpose(-1, -2) * scale, dim=-1)
+    return (a @ vh).transpose(1, 2).reshape(B, Tq, heads * hd)
+
+
+def run(ops, B, Bkv, Tq, Tk, heads, hd, scale, amp=1.0, spike=False):
+    C = heads * hd
+    q = torch.from_numpy(synth.normalish(f"aq{B}{Tq}{hd}", (B, Tq, C), 5)).half() * amp
+    k = torch.from_numpy(synth.normalish(f"ak{Bkv}{Tk}{hd}", (Bkv, Tk, C), 5)).half() * amp
+    v = torch.from_numpy(synth.normalish(f"av{Bkv}{Tk}{hd}", (Bkv, Tk, C), 5)).half()
+    if spike:   # one key late in the sequence dominates one query row: the running max jumps at that tile
+        k[0, Tk - 70, :hd] = q[0, 5, :hd] * 6
+    out = torch.zeros(B, Tq, C, dtype=torch.float16, device="cuda")
+    vt = v.transpose(1, 2).contiguous()
+    ops.flash_attn(q.cuda(), k.cuda(), vt.cuda(), out, heads, hd, scale, kv_batch_div=B // Bkv)
+    ref = ref_attn(q, k, v, heads, hd, scale, B // Bkv)
+    return (out.cpu().double() - ref).abs().max().item(), ref.abs().max().item()
+
+
+@pytest.mark.parametrize("hd,scale", [(64, 0.125), (256, 0.0625)])
+@pytest.mark.parametrize("Tq,Tk", [(64, 64), (256, 256), (1024, 1024), (200, 136), (128, 1000)])
+def test_attention_parity(ops, hd, scale, Tq, Tk):
+    err, mag = run(ops, 2, 2, Tq, Tk, 6, hd, scale)
+    assert err < 2e-3 * max(1.0, mag), (err, mag)
+
+
+def test_attention_shared_kv_and_strided_q(ops):
+    err, mag = run(ops, 4, 2, 256, 256, 6, 64, 0.125)
+    assert err < 2e-3 * max(1.0, mag), (err, mag)
+
+
+@pytest.mark.parametrize("hd,scale", [(64, 0.125), (256, 0.0625)])
+def test_attention_forced_rescale(ops, hd, scale):
+    err, mag = run(ops, 1, 1, 128, 512, 6, hd, scale, amp=1.5, spike=True)
+    assert err < 3e-3 * max(1.0, mag), (err, mag)
+
+
+def test_attention_fused_qkv_views(ops):
+    """q and k as column slices of one [B,T,2C] projection buffer (how the engine lays them out)."""
+    B, T, heads, hd = 2, 256, 6, 64
+    C = heads * hd
+    qk = torch.from_numpy(synth.normalish("aqk", (B, T, 2 * C), 5)).half().cuda()
+    v = torch.from_numpy(synth.normalish("avv", (B, T, C), 5)).half()
+    vt = v.transpose(1, 2).contiguous().cuda()
+    out = torch.zeros(B, T, C, dtype=torch.float16, device="cuda")
+    ops.flash_attn(qk[:, :, :C], qk[:, :, C:], vt, out, heads, hd, 0.125)
+    ref = ref_attn(qk[:, :, :C].cpu(), qk[:, :, C:].cpu(), v, heads, hd, 0.125, 1)
+    assert (out.cpu().double() - ref).abs().max() < 2e-3

@@ -33,7 +33,7 @@ def test_gemm_plain(ops, M, N, K, dt):
     out = torch.zeros(M, N, device="cuda")
     ops.gemm_nt(a.cuda(), b.cuda(), out32=out)
     err = (out.cpu().double() - ref).abs().max().item()
-    tol = 1e-4 * K ** 0.5 if dt == "f16" else 2e-6 * K ** 0.5
+    tol = 1e-4 * K ** 0.5 if dt == "f16" else 2e-7 * K
     assert err < tol, err
 
 
@@ -57,19 +57,22 @@ def test_gemm_epilogue_all(ops):
     # bias + GELU -> f16
     out16 = torch.zeros(M, N, dtype=torch.float16, device="cuda")
     ops.gemm_nt(a.cuda(), b.cuda(), out16=out16, bias=bias.cuda(), act=1)
-    assert (out16.cpu().double() - gelu_tanh(acc)).abs().max() < 4e-3
+    e1 = (out16.cpu().double() - gelu_tanh(acc)).abs().max().item()
+    assert e1 < 1.5e-2, ("gelu f16", e1)      # f16 store of values up to ~16: half-ulp 4e-3 + f16 operand rounding
     # bias + ReLU + pos
     out = torch.zeros(M, N, device="cuda")
     ops.gemm_nt(a.cuda(), b.cuda(), out32=out, bias=bias.cuda(), act=2, pos=pos.cuda())
     ref = torch.relu(acc) + pos.double().repeat(M // T, 1)
-    assert (out.cpu().double() - ref).abs().max() < 2e-3
+    e2 = (out.cpu().double() - ref).abs().max().item()
+    assert e2 < 2e-3, ("relu+pos", e2)
     # gate * (acc + bias) + residual, in place on the residual buffer, strided output (ld = 2N)
     big = torch.zeros(M, 2 * N, device="cuda")
     big[:, N:] = res.cuda()
     view = big[:, N:]
     ops.gemm_nt(a.cuda(), b.cuda(), out32=view, bias=bias.cuda(), gate=gate.cuda(), gate_rows=T, res=view)
     ref = gate.double().repeat_interleave(T, 0) * acc + res.double()
-    assert (view.cpu().double() - ref).abs().max() < 2e-3
+    e3 = (view.cpu().double() - ref).abs().max().item()
+    assert e3 < 2e-3, ("gate+res", e3)
     assert float(big[:, :N].abs().max()) == 0.0
 
 
