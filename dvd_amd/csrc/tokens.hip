@@ -1,0 +1,549 @@
+// Token-side (HBM-bound) kernels of the denoiser: everything between the MFMA GEMMs / attention.
+// One wave (64 lanes) owns one token row wherever a row reduction is needed (LayerNorm), so
+// reductions are DPP/shuffle-only and every global access is a contiguous 16-byte-per-lane run.
+//
+//   embed_obs_ln     K1+K7  patchify x_t (conv k=s=2, 2->384) + bias + pos-embed; LN (no affine)
+//   layernorm_rows   K7/K9/K10/K13/K14 LayerNorm (+affine) (+adaLN modulate) -> f16 GEMM operand
+//   build_r_rows     K18+K5r feature warp + concat[init_flow, init_feat] + 2x2 patch rows (f16)
+//   patch_rows       K3/K5  2x2 patch rows of a [C,G,G] or [G,G,C] map (f32)
+//   dwconv3x3        K14    depthwise 3x3 + folded BN + ReLU on the token grid
+//   colmean / posenc K12    adaptive 2-D positional encoding
+//   small_linear     K2/K6/K12/K15 tiny-M linears (t-embed MLP, adaLN, pos-enc scale MLPs)
+//   final_tokens     K15+K16 LN -> LN -> modulate -> Linear 1536->8 -> unpatchify + init_flow
+#include "common.h"
+#include "mfma.h"
+
+namespace dvd {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// ----------------------------------------------------------------------------------------------
+// K1 + K7: x_tok = PatchEmbed(x_t) + pos ; xq = LN(x_tok)  (idf/cross_model.py:571,238)
+// x [N,2,G,G] f32; w [384,8] (conv weight flattened c*4+p*2+q); pos [T,384]
+// ----------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) embed_obs_ln_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                           const float* __restrict__ bias,
+                                                           const float* __restrict__ pos, float* __restrict__ tok32,
+                                                           _Float16* __restrict__ ln16, int g, long rows) {
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63;
+  const int side = g >> 1, T = side * side;
+  const int n = (int)(row / T), t = (int)(row % T);
+  const int ty = t / side, tx = t % side;
+  float pv[8];
+#pragma unroll
+  for (int c = 0; c < 2; ++c)
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+        pv[c * 4 + p * 2 + q] = x[(((size_t)n * 2 + c) * g + (2 * ty + p)) * g + 2 * tx + q];
+  float v[6];
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    const int o = lane + 64 * j;
+    float acc = bias[o];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc += w[o * 8 + k] * pv[k];
+    acc += pos[(size_t)t * 384 + o];
+    v[j] = acc;
+    s += acc;
+  }
+  const float mean = wave_sum(s) * (1.f / 384.f);
+  float q2 = 0.f;
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    const float d = v[j] - mean;
+    q2 += d * d;
+  }
+  const float rstd = rsqrtf(wave_sum(q2) * (1.f / 384.f) + 1e-6f);
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    const int o = lane + 64 * j;
+    tok32[row * 384 + o] = v[j];
+    ln16[row * 384 + o] = (_Float16)((v[j] - mean) * rstd);
+  }
+}
+
+// ----------------------------------------------------------------------------------------------
+// LayerNorm over C (384 or 1536) channels of token rows, optional affine, optional adaLN modulate
+// y = LN(x) * (1 + scale[sample]) + shift[sample]   (idf/cross_model.py:13-14); f16 output.
+// Batched (blockIdx.y): in += z*sIn, out += z*sOut (stream slices of the 1536-wide buffer).
+// ----------------------------------------------------------------------------------------------
+template <int C>
+__global__ void __launch_bounds__(256) layernorm_rows_kernel(const float* __restrict__ in, int ldin, long sIn,
+                                                             _Float16* __restrict__ out, int ldout, long sOut,
+                                                             const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta,
+                                                             const float* __restrict__ shift,
+                                                             const float* __restrict__ scale, int ldmod,
+                                                             int mod_rows, float eps, long rows) {
+  constexpr int PER = C / 64;  // 6 or 24 floats per lane, as float2 / float4 runs
+  constexpr int V = (C == 384) ? 2 : 4;
+  constexpr int NV = PER / V;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63;
+  const float* ip = in + blockIdx.y * sIn + row * ldin;
+  float v[PER];
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int c0 = (k * 64 + lane) * V;
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      v[k * V + e] = ip[c0 + e];
+      s += v[k * V + e];
+    }
+  }
+  const float mean = wave_sum(s) * (1.f / C);
+  float q2 = 0.f;
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    const float d = v[k] - mean;
+    q2 += d * d;
+  }
+  const float rstd = rsqrtf(wave_sum(q2) * (1.f / C) + eps);
+  _Float16* op = out + blockIdx.y * sOut + row * ldout;
+  const float* sh = shift ? shift + (row / mod_rows) * ldmod : nullptr;
+  const float* sc = scale ? scale + (row / mod_rows) * ldmod : nullptr;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int c0 = (k * 64 + lane) * V;
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      float y = (v[k * V + e] - mean) * rstd;
+      if (gamma) y = y * gamma[c0 + e] + beta[c0 + e];
+      if (sc) y = y * (1.f + sc[c0 + e]) + sh[c0 + e];
+      op[c0 + e] = (_Float16)y;
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------------------------
+// K18 + K5r: rows of the r-embedder GEMM.  For sample n, token (ty,tx), patch position pq:
+//   row[pq*258 + 0..1]   = init_flow[n, c, 2ty+p, 2tx+q]
+//   row[pq*258 + 2..257] = init_feat = warp ? bilinear(feat_doc, grid(x0_prev)) : feat_doc
+// feat is channels-last [docs, G, G, 256] f32; flow [N,2,G,G] (x0_prev = init_flow);
+// the warp grid is (x0_prev + base)*2-1 (idf/gaussian_diffusion.py:618-624), zeros padding.
+// Output f16 [N*T, ldo] with ldo >= 1032 (pad columns zeroed).   One wave per (token, pq).
+// mode: 0 = init_feat is zero (first step with tv: never used since t>600 overrides) , 1 = feat
+// itself (t > 600, idf/cross_model.py:597-598), 2 = warped feat.
+// ----------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) build_r_rows_kernel(const float* __restrict__ feat,
+                                                           const float* __restrict__ flow,
+                                                           _Float16* __restrict__ out, int ldo, int g, int n_hyp,
+                                                           int mode, long items) {
+  const long item = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (item >= items) return;
+  const int lane = threadIdx.x & 63;
+  const int side = g >> 1, T = side * side;
+  const int pq = (int)(item & 3);
+  const long tokrow = item >> 2;
+  const int n = (int)(tokrow / T), t = (int)(tokrow % T);
+  const int y = 2 * (t / side) + (pq >> 1), x = 2 * (t % side) + (pq & 1);
+  const size_t gg = (size_t)g * g;
+  const float fx = flow[((size_t)n * 2 + 0) * gg + (size_t)y * g + x];
+  const float fy = flow[((size_t)n * 2 + 1) * gg + (size_t)y * g + x];
+  _Float16* orow = out + tokrow * ldo + pq * 258;
+  const float* fd = feat + (size_t)(n / n_hyp) * gg * 256;
+  float v[4] = {0.f, 0.f, 0.f, 0.f};   // channels 4*lane .. 4*lane+3
+  if (mode == 1) {
+    const floatx4 f = *(const floatx4*)(fd + ((size_t)y * g + x) * 256 + 4 * lane);
+    v[0] = f[0]; v[1] = f[1]; v[2] = f[2]; v[3] = f[3];
+  } else if (mode == 2) {
+    const float inv = 1.f / (float)(g - 1);
+    const float gx = sub_rn(mul_rn(add_rn(fx, (float)x * inv), 2.f), 1.f);
+    const float gy = sub_rn(mul_rn(add_rn(fy, (float)y * inv), 2.f), 1.f);
+    const float ix = ((gx + 1.f) * 0.5f) * (float)(g - 1), iy = ((gy + 1.f) * 0.5f) * (float)(g - 1);
+    float x0f = floorf(ix), y0f = floorf(iy);
+    const float wx1 = ix - x0f, wy1 = iy - y0f, wx0 = (x0f + 1.f) - ix, wy0 = (y0f + 1.f) - iy;
+    x0f = fminf(fmaxf(x0f, -2.f), (float)g);
+    y0f = fminf(fmaxf(y0f, -2.f), (float)g);
+    if (!(ix == ix)) x0f = -2.f;
+    if (!(iy == iy)) y0f = -2.f;
+    const int x0 = (int)x0f, y0 = (int)y0f;
+    const float wts[4] = {wx0 * wy0, wx1 * wy0, wx0 * wy1, wx1 * wy1};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int xx = x0 + (k & 1), yy = y0 + (k >> 1);
+      if (xx >= 0 && xx < g && yy >= 0 && yy < g) {
+        const floatx4 f = *(const floatx4*)(fd + ((size_t)yy * g + xx) * 256 + 4 * lane);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += f[e] * wts[k];
+      }
+    }
+  }
+  // columns 2 + 4*lane + e : 2-byte aligned only -> scalar f16 stores (coalesced across lanes)
+#pragma unroll
+  for (int e = 0; e < 4; ++e) orow[2 + 4 * lane + e] = (_Float16)v[e];
+  if (lane == 0) {
+    orow[0] = (_Float16)fx;
+    orow[1] = (_Float16)fy;
+  }
+  if (pq == 3) {  // zero the K padding once per row
+    for (int c = 1032 + lane; c < ldo; c += 64) out[tokrow * ldo + c] = (_Float16)0.f;
+  }
+}
+
+// ----------------------------------------------------------------------------------------------
+// 2x2 patch rows of a feature map with arbitrary element strides (NCHW or channels-last), f32:
+//   out[(n*T + t)*ldo + pq*C + c] = in[n*sn + c*sc + (2ty+p)*sy + (2tx+q)*sx]
+// ----------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) patch_rows_kernel(const float* __restrict__ in, long sn, long sc, long sy,
+                                                         long sx, float* __restrict__ out, int ldo, int c, int g,
+                                                         long total) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int k4 = 4 * c;
+  const long row = idx / k4;
+  const int col = (int)(idx % k4);
+  const int pq = col / c, ch = col % c;
+  const int side = g >> 1, T = side * side;
+  const int n = (int)(row / T), t = (int)(row % T);
+  const int y = 2 * (t / side) + (pq >> 1), x = 2 * (t % side) + (pq & 1);
+  out[row * ldo + col] = in[n * sn + ch * sc + y * sy + x * sx];
+}
+
+// ----------------------------------------------------------------------------------------------
+// K14 middle: depthwise 3x3 (pad 1) + folded BatchNorm + ReLU on the side x side token grid
+// (idf/cross_attn.py:33-41).  in/out f16 [N*T, C] token-major; w [9, C] f32 tap-major (BN scale
+// folded in), b [C].  One thread per (token, 8 channels): 16-byte loads/stores.
+// ----------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) dwconv3x3_kernel(const _Float16* __restrict__ in,
+                                                        _Float16* __restrict__ out, const float* __restrict__ w,
+                                                        const float* __restrict__ b, int side, int c, long total) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int c8 = c >> 3;
+  const long tok = idx / c8;
+  const int ch = (int)(idx % c8) * 8;
+  const int T = side * side;
+  const int t = (int)(tok % T);
+  const int ty = t / side, tx = t % side;
+  float acc[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = b[ch + e];
+#pragma unroll
+  for (int dy = -1; dy <= 1; ++dy) {
+    const int yy = ty + dy;
+    if (yy < 0 || yy >= side) continue;
+#pragma unroll
+    for (int dx = -1; dx <= 1; ++dx) {
+      const int xx = tx + dx;
+      if (xx < 0 || xx >= side) continue;
+      const half8 v = *(const half8*)(in + (tok + (long)dy * side + dx) * c + ch);
+      const float* wp = w + ((dy + 1) * 3 + (dx + 1)) * c + ch;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] += (float)v[e] * wp[e];
+    }
+  }
+  half8 o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = (_Float16)fmaxf(acc[e], 0.f);
+  *(half8*)(out + tok * c + ch) = o;
+}
+
+// ----------------------------------------------------------------------------------------------
+// K12: adaptive 2-D positional encoding (idf/cross_attn.py:143-157)
+// colsum_partial: part[n][chunk][c] = sum over the chunk's tokens of z[n,t,c]   (deterministic 2-stage)
+// colmean_final : pooled[n][c] = (sum_chunks part) / T
+// posenc_add    : z[n,t,c] += hs[n,c]*htab[ty][c] + ws[n,c]*wtab[tx][c]
+// ----------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) colsum_partial_kernel(const float* __restrict__ z, float* __restrict__ part,
+                                                             int T, int c, int chunks) {
+  const int n = blockIdx.z, chunk = blockIdx.y;
+  const int col = blockIdx.x * 256 + threadIdx.x;
+  if (col >= c) return;
+  const int per = (T + chunks - 1) / chunks;
+  const int t0 = chunk * per, t1 = min(T, t0 + per);
+  const float* p = z + ((size_t)n * T + t0) * c + col;
+  float s = 0.f;
+  for (int t = t0; t < t1; ++t, p += c) s += *p;
+  part[((size_t)n * chunks + chunk) * c + col] = s;
+}
+
+__global__ void __launch_bounds__(256) colmean_final_kernel(const float* __restrict__ part,
+                                                            float* __restrict__ pooled, int T, int c, int chunks,
+                                                            int total) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  const int n = idx / c, col = idx % c;
+  float s = 0.f;
+  for (int k = 0; k < chunks; ++k) s += part[((size_t)n * chunks + k) * c + col];
+  pooled[idx] = s / (float)T;
+}
+
+__global__ void __launch_bounds__(256) posenc_add_kernel(float* __restrict__ z, const float* __restrict__ hs,
+                                                         const float* __restrict__ ws,
+                                                         const float* __restrict__ htab,
+                                                         const float* __restrict__ wtab, int side, int c,
+                                                         long total4) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total4) return;
+  const int c4 = c >> 2;
+  const long tok = idx / c4;
+  const int ch = (int)(idx % c4) * 4;
+  const int T = side * side;
+  const int n = (int)(tok / T), t = (int)(tok % T);
+  const int ty = t / side, tx = t % side;
+  floatx4 v = *(floatx4*)(z + tok * c + ch);
+  const floatx4 a = *(const floatx4*)(hs + (size_t)n * c + ch), hb = *(const floatx4*)(htab + (size_t)ty * c + ch);
+  const floatx4 b = *(const floatx4*)(ws + (size_t)n * c + ch), wb = *(const floatx4*)(wtab + (size_t)tx * c + ch);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) v[e] = (v[e] + a[e] * hb[e]) + b[e] * wb[e];
+  *(floatx4*)(z + tok * c + ch) = v;
+}
+
+// ----------------------------------------------------------------------------------------------
+// Tiny-M linear:  y[m][o] = act_out( sum_k W[o][k] * act_in(x[m][(k % kmod)]) + b[o] ),  m < M <= 8 per pass.
+// One wave per output feature; W rows are read once per group of 8 samples.
+// act_in: 0 none, 1 SiLU, 2 timestep sinusoid (x is t[m]; k<half -> cos(t f_k), else sin(t f_{k-half})
+//         with f_k = exp(-ln(1e4) k / half), idf/cross_model.py:111-129)
+// act_out: 0 none, 1 SiLU, 2 ReLU, 3 sigmoid.   kmod: input width before tiling (t.repeat(1,4), :331).
+// ----------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) small_linear_kernel(const float* __restrict__ x, int ldx,
+                                                           const float* __restrict__ w,
+                                                           const float* __restrict__ b, float* __restrict__ y,
+                                                           int ldy, int M, int K, int N, int kmod, int act_in,
+                                                           int act_out) {
+  const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (o >= N) return;
+  const int lane = threadIdx.x & 63;
+  const float* wr = w + (size_t)o * K;
+  for (int m0 = 0; m0 < M; m0 += 8) {
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    for (int k = lane; k < K; k += 64) {
+      const float wv = wr[k];
+      const int kk = k % kmod;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if (m0 + j < M) {
+          float xv;
+          if (act_in == 2) {
+            const int half = kmod >> 1;
+            const float t = x[(m0 + j) * ldx];
+            const int kf = kk < half ? kk : kk - half;
+            const float fr = expf(-9.210340371976184f * (float)kf / (float)half);
+            xv = kk < half ? cosf(t * fr) : sinf(t * fr);
+          } else {
+            xv = x[(size_t)(m0 + j) * ldx + kk];
+            if (act_in == 1) xv = xv / (1.f + expf(-xv));
+          }
+          acc[j] += wv * xv;
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float s = wave_sum(acc[j]);
+      if (lane == 0 && m0 + j < M) {
+        float v = s + (b ? b[o] : 0.f);
+        if (act_out == 1) v = v / (1.f + expf(-v));
+        else if (act_out == 2) v = fmaxf(v, 0.f);
+        else if (act_out == 3) v = 1.f / (1.f + expf(-v));
+        y[(size_t)(m0 + j) * ldy + o] = v;
+      }
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------------------------
+// K15 + K16: z -> LN(affine, 1e-5) [decoder.layer_norm, idf/cross_attn.py:457] -> LN(no affine, 1e-6)
+// -> modulate(shift, scale) -> Linear 1536->8 + bias [FinalLayer2, idf/cross_model.py:329-336]
+// -> unpatchify nhwpqc->nchpwq [:553-566] -> + init_flow [:645-646].   One wave per token.
+// ----------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) final_tokens_kernel(const float* __restrict__ z,
+                                                           const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta,
+                                                           const float* __restrict__ shift,
+                                                           const float* __restrict__ scale, int ldmod,
+                                                           int mod_rows, const float* __restrict__ w,
+                                                           const float* __restrict__ b,
+                                                           const float* __restrict__ init_flow,
+                                                           float* __restrict__ x0, float* __restrict__ tok8, int g,
+                                                           long rows) {
+  constexpr int C = 1536, PER = 24;
+  const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63;
+  const float* ip = z + row * C;
+  float v[PER];
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    const floatx4 f = *(const floatx4*)(ip + (k * 64 + lane) * 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      v[k * 4 + e] = f[e];
+      s += f[e];
+    }
+  }
+  float mean = wave_sum(s) * (1.f / C);
+  float q2 = 0.f;
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    const float d = v[k] - mean;
+    q2 += d * d;
+  }
+  float rstd = rsqrtf(wave_sum(q2) * (1.f / C) + 1e-5f);
+  s = 0.f;
+#pragma unroll
+  for (int k = 0; k < 6; ++k)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int c = (k * 64 + lane) * 4 + e;
+      v[k * 4 + e] = (v[k * 4 + e] - mean) * rstd * gamma[c] + beta[c];
+      s += v[k * 4 + e];
+    }
+  mean = wave_sum(s) * (1.f / C);
+  q2 = 0.f;
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    const float d = v[k] - mean;
+    q2 += d * d;
+  }
+  rstd = rsqrtf(wave_sum(q2) * (1.f / C) + 1e-6f);
+  const float* sh = shift + (row / mod_rows) * ldmod;
+  const float* sc = scale + (row / mod_rows) * ldmod;
+  float dot[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) dot[j] = 0.f;
+#pragma unroll
+  for (int k = 0; k < 6; ++k)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int c = (k * 64 + lane) * 4 + e;
+      const float y = ((v[k * 4 + e] - mean) * rstd) * (1.f + sc[c]) + sh[c];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) dot[j] += y * w[j * C + c];
+    }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) dot[j] = wave_sum(dot[j]);
+  if (lane < 8) {
+    float o = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (lane == j) o = dot[j];
+    o += b[lane];
+    if (tok8) tok8[row * 8 + lane] = o;
+    const int side = g >> 1, T = side * side;
+    const int n = (int)(row / T), t = (int)(row % T);
+    const int p = lane >> 2, q = (lane >> 1) & 1, c = lane & 1;   // token channel = (p*2 + q)*2 + c
+    const size_t at = (((size_t)n * 2 + c) * g + 2 * (t / side) + p) * g + 2 * (t % side) + q;
+    x0[at] = o + (init_flow ? init_flow[at] : 0.f);
+  }
+}
+
+}  // namespace dvd
+
+using namespace dvd;
+
+#define LAUNCH_ROWS(rows) cdiv((rows), 4), 256, 0, (hipStream_t)stream
+
+extern "C" int dvd_embed_obs_ln(const float* x, const float* w, const float* bias, const float* pos, float* tok32,
+                                void* ln16, int n, int g, void* stream) {
+  DVD_REQUIRE(x && w && bias && pos && tok32 && ln16, "embed_obs_ln: null pointer");
+  DVD_REQUIRE(n > 0 && g >= 2 && g % 2 == 0, "embed_obs_ln: bad shape");
+  const long rows = (long)n * (g / 2) * (g / 2);
+  embed_obs_ln_kernel<<<LAUNCH_ROWS(rows)>>>(x, w, bias, pos, tok32, (_Float16*)ln16, g, rows);
+  return check_launch("embed_obs_ln");
+}
+
+extern "C" int dvd_layernorm_rows(const float* in, int ldin, long stride_in, void* out16, int ldout, long stride_out,
+                                  int batch, long rows, int c, const float* gamma, const float* beta,
+                                  const float* shift, const float* scale, int ldmod, int mod_rows, float eps,
+                                  void* stream) {
+  DVD_REQUIRE(in && out16, "layernorm_rows: null pointer");
+  DVD_REQUIRE(c == 384 || c == 1536, "layernorm_rows: C=%d not in {384,1536}", c);
+  DVD_REQUIRE((gamma == nullptr) == (beta == nullptr) && (shift == nullptr) == (scale == nullptr),
+              "layernorm_rows: affine / modulate pointers must come in pairs");
+  DVD_REQUIRE(!shift || mod_rows > 0, "layernorm_rows: mod_rows");
+  DVD_REQUIRE(rows > 0 && batch > 0 && batch < 65536, "layernorm_rows: bad rows/batch");
+  dim3 grid(cdiv(rows, 4), batch);
+  if (c == 384)
+    layernorm_rows_kernel<384><<<grid, 256, 0, (hipStream_t)stream>>>(in, ldin, stride_in, (_Float16*)out16, ldout,
+                                                                       stride_out, gamma, beta, shift, scale, ldmod,
+                                                                       mod_rows > 0 ? mod_rows : 1, eps, rows);
+  else
+    layernorm_rows_kernel<1536><<<grid, 256, 0, (hipStream_t)stream>>>(in, ldin, stride_in, (_Float16*)out16, ldout,
+                                                                        stride_out, gamma, beta, shift, scale, ldmod,
+                                                                        mod_rows > 0 ? mod_rows : 1, eps, rows);
+  return check_launch("layernorm_rows");
+}
+
+extern "C" int dvd_build_r_rows(const float* feat_nhwc, const float* flow, void* out16, int ldo, int n, int g,
+                                int n_hyp, int mode, void* stream) {
+  DVD_REQUIRE(feat_nhwc && flow && out16, "build_r_rows: null pointer");
+  DVD_REQUIRE(ldo >= 1032 && n > 0 && g >= 2 && g % 2 == 0 && n_hyp > 0 && mode >= 0 && mode <= 2,
+              "build_r_rows: bad arguments");
+  const long items = (long)n * (g / 2) * (g / 2) * 4;
+  build_r_rows_kernel<<<LAUNCH_ROWS(items)>>>(feat_nhwc, flow, (_Float16*)out16, ldo, g, n_hyp, mode, items);
+  return check_launch("build_r_rows");
+}
+
+extern "C" int dvd_patch_rows(const float* in, long sn, long sc, long sy, long sx, float* out, int ldo, int n, int c,
+                              int g, void* stream) {
+  DVD_REQUIRE(in && out, "patch_rows: null pointer");
+  DVD_REQUIRE(n > 0 && c > 0 && g >= 2 && g % 2 == 0 && ldo >= 4 * c, "patch_rows: bad shape");
+  const long total = (long)n * (g / 2) * (g / 2) * 4 * c;
+  patch_rows_kernel<<<cdiv(total, 256), 256, 0, (hipStream_t)stream>>>(in, sn, sc, sy, sx, out, ldo, c, g, total);
+  return check_launch("patch_rows");
+}
+
+extern "C" int dvd_dwconv3x3(const void* in16, void* out16, const float* w9c, const float* b, int n, int side, int c,
+                             void* stream) {
+  DVD_REQUIRE(in16 && out16 && w9c && b, "dwconv3x3: null pointer");
+  DVD_REQUIRE(n > 0 && side > 0 && c % 8 == 0, "dwconv3x3: bad shape");
+  const long total = (long)n * side * side * (c / 8);
+  dwconv3x3_kernel<<<cdiv(total, 256), 256, 0, (hipStream_t)stream>>>((const _Float16*)in16, (_Float16*)out16, w9c, b,
+                                                                      side, c, total);
+  return check_launch("dwconv3x3");
+}
+
+extern "C" int dvd_colmean(const float* z, float* partial, float* pooled, int n, int t, int c, int chunks,
+                           void* stream) {
+  DVD_REQUIRE(z && partial && pooled, "colmean: null pointer");
+  DVD_REQUIRE(n > 0 && n < 65536 && t > 0 && c > 0 && chunks > 0 && chunks < 65536, "colmean: bad shape");
+  dim3 grid(cdiv(c, 256), chunks, n);
+  colsum_partial_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(z, partial, t, c, chunks);
+  colmean_final_kernel<<<cdiv((long)n * c, 256), 256, 0, (hipStream_t)stream>>>(partial, pooled, t, c, chunks, n * c);
+  return check_launch("colmean");
+}
+
+extern "C" int dvd_posenc_add(float* z, const float* hs, const float* ws, const float* htab, const float* wtab,
+                              int n, int side, int c, void* stream) {
+  DVD_REQUIRE(z && hs && ws && htab && wtab, "posenc_add: null pointer");
+  DVD_REQUIRE(n > 0 && side > 0 && c % 4 == 0, "posenc_add: bad shape");
+  const long total4 = (long)n * side * side * (c / 4);
+  posenc_add_kernel<<<cdiv(total4, 256), 256, 0, (hipStream_t)stream>>>(z, hs, ws, htab, wtab, side, c, total4);
+  return check_launch("posenc_add");
+}
+
+extern "C" int dvd_small_linear(const float* x, int ldx, const float* w, const float* b, float* y, int ldy, int m,
+                                int k, int n, int kmod, int act_in, int act_out, void* stream) {
+  DVD_REQUIRE(x && w && y, "small_linear: null pointer");
+  DVD_REQUIRE(m > 0 && k > 0 && n > 0 && kmod > 0 && act_in >= 0 && act_in <= 2 && act_out >= 0 && act_out <= 3,
+              "small_linear: bad arguments");
+  small_linear_kernel<<<LAUNCH_ROWS(n)>>>(x, ldx, w, b, y, ldy, m, k, n, kmod, act_in, act_out);
+  return check_launch("small_linear");
+}
+
+extern "C" int dvd_final_tokens(const float* z, const float* gamma, const float* beta, const float* shift,
+                                const float* scale, int ldmod, int mod_rows, const float* w8, const float* b8,
+                                const float* init_flow, float* x0, float* tok8, int n, int g, void* stream) {
+  DVD_REQUIRE(z && gamma && beta && shift && scale && w8 && b8 && x0, "final_tokens: null pointer");
+  DVD_REQUIRE(n > 0 && g >= 2 && g % 2 == 0 && mod_rows > 0, "final_tokens: bad shape");
+  const long rows = (long)n * (g / 2) * (g / 2);
+  final_tokens_kernel<<<LAUNCH_ROWS(rows)>>>(z, gamma, beta, shift, scale, ldmod, mod_rows, w8, b8, init_flow, x0,
+                                             tok8, g, rows);
+  return check_launch("final_tokens");
+}

@@ -1,0 +1,114 @@
+"""Python handle of the HIP denoiser engine (dvd_engine_* in include/dvd_hip.h).
+
+PyTorch provides device memory (one flat weight blob, one workspace) and the stream; the forward
+pass itself is entirely inside libdvd_hip.so."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import lib, weights
+from .lib import ptr, stream_ptr
+
+
+class Engine:
+    def __init__(self, grid: int, docs: int, n_hyp: int, device="cuda"):
+        self.grid, self.docs, self.n_hyp, self.n = grid, docs, n_hyp, docs * n_hyp
+        self.device = torch.device(device)
+        h = C.c_void_p()
+        lib.call("dvd_engine_create", grid, docs, n_hyp, C.byref(h))
+        self._h = h
+        nbytes = lib.raw().dvd_engine_workspace_bytes(h)
+        self.workspace = torch.empty(nbytes + 256, dtype=torch.uint8, device=self.device)
+        off = (-self.workspace.data_ptr()) % 256
+        self._ws_ptr = self.workspace.data_ptr() + off
+        lib.call("dvd_engine_bind_workspace", h, C.c_void_p(self._ws_ptr), nbytes)
+        self.specs = []
+        name, dt, ne = C.c_char_p(), C.c_int(), C.c_long()
+        for i in range(lib.raw().dvd_engine_tensor_count(h)):
+            lib.call("dvd_engine_tensor_info", h, i, C.byref(name), C.byref(dt), C.byref(ne))
+            self.specs.append((name.value.decode(), dt.value, ne.value))
+        self.blob = None
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                lib.raw().dvd_engine_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    # ---- weights -------------------------------------------------------------------------
+    def blob_layout(self):
+        """(name, dtype, nelem, byte offset) of every tensor inside the flat weight blob (256-B aligned)."""
+        off, lay = 0, []
+        for name, dt, ne in self.specs:
+            lay.append((name, dt, ne, off))
+            off += (ne * (2 if dt == 1 else 4) + 255) // 256 * 256
+        return lay, off
+
+    def pack_blob(self, state_dict) -> torch.Tensor:
+        """Host blob (uint8) from a reference-named state_dict."""
+        packed = weights.pack(state_dict, self.grid)
+        lay, total = self.blob_layout()
+        blob = torch.zeros(total, dtype=torch.uint8)
+        for name, dt, ne, off in lay:
+            t = packed[name]
+            want = torch.float16 if dt == 1 else torch.float32
+            if t.dtype != want or t.numel() != ne:
+                raise lib.DvdError(f"packer produced {name}: {t.dtype} x{t.numel()}, engine expects {want} x{ne}")
+            raw = t.contiguous().view(-1).view(torch.uint8)
+            blob[off:off + raw.numel()] = raw
+        return blob
+
+    def bind_blob(self, blob_dev: torch.Tensor):
+        """Bind a device-resident blob (e.g. after the one-shot RCCL broadcast)."""
+        assert blob_dev.is_cuda and blob_dev.dtype == torch.uint8
+        lay, total = self.blob_layout()
+        assert blob_dev.numel() >= total and blob_dev.data_ptr() % 256 == 0
+        self.blob = blob_dev
+        for name, dt, ne, off in lay:
+            lib.call("dvd_engine_set_tensor", self._h, name.encode(), C.c_void_p(blob_dev.data_ptr() + off), ne)
+
+    def load_state_dict(self, state_dict):
+        self.bind_blob(self.pack_blob(state_dict).to(self.device))
+
+    # ---- compute -------------------------------------------------------------------------
+    def prepare(self, y512, mask_cat, mask_y512, line_msk):
+        for t, shp in ((y512, (self.docs, 3, 512, 512)), (mask_cat, (self.docs, 1, 512, 512)),
+                       (mask_y512, (self.docs, 384, self.grid, self.grid)),
+                       (line_msk, (self.docs, 64, self.grid, self.grid))):
+            if tuple(t.shape) != shp or t.dtype != torch.float32 or not t.is_cuda or not t.is_contiguous():
+                raise lib.DvdError(f"prepare: expected contiguous f32 device tensor of shape {shp}, got {tuple(t.shape)}")
+        lib.call("dvd_engine_prepare_docs", self._h, ptr(y512), ptr(mask_cat), ptr(mask_y512), ptr(line_msk),
+                 stream_ptr())
+
+    def feat_nchw(self):
+        out = torch.empty(self.docs, 256, self.grid, self.grid, dtype=torch.float32, device=self.device)
+        lib.call("dvd_engine_feat_nchw", self._h, ptr(out), stream_ptr())
+        return out
+
+    def denoise(self, x_t, t_embed: float, feat_mode: int, init_flow, out=None):
+        shp = (self.n, 2, self.grid, self.grid)
+        for t in (x_t, init_flow):
+            if tuple(t.shape) != shp or t.dtype != torch.float32 or not t.is_cuda or not t.is_contiguous():
+                raise lib.DvdError(f"denoise: expected contiguous f32 device tensor of shape {shp}")
+        if out is None:
+            out = torch.empty(shp, dtype=torch.float32, device=self.device)
+        lib.call("dvd_engine_denoise_step", self._h, ptr(x_t), C.c_float(t_embed), feat_mode, ptr(init_flow), ptr(out),
+                 stream_ptr())
+        return out
+
+    def debug_stop(self, stage: int):
+        lib.call("dvd_engine_debug_stop", self._h, stage)
+
+    def debug(self, name: str, dtype, shape):
+        p, nb = C.c_void_p(), C.c_long()
+        lib.call("dvd_engine_debug_buffer", self._h, name.encode(), C.byref(p), C.byref(nb))
+        n = int(np.prod(shape))
+        esz = torch.empty(0, dtype=dtype).element_size()
+        assert n * esz <= nb.value, (name, n * esz, nb.value)
+        off = p.value - self.workspace.data_ptr()
+        return self.workspace[off:off + n * esz].view(dtype).view(*shape)

@@ -75,6 +75,9 @@ def _sig(name, argtypes, restype=C.c_int):
 
 _lib.dvd_last_error.restype = C.c_char_p
 _lib.dvd_version.restype = C.c_int
+_lib.dvd_engine_workspace_bytes.restype = C.c_long
+_lib.dvd_engine_workspace_bytes.argtypes = [C.c_void_p]
+NON_STATUS = {"dvd_last_error", "dvd_version", "dvd_engine_workspace_bytes", "dvd_engine_tensor_count"}
 
 # name -> argtypes; kept in one table so tests can check every symbol of include/dvd_hip.h
 SIGNATURES = {
@@ -88,6 +91,34 @@ SIGNATURES = {
     "dvd_selftest_mfma": [c_void, c_void, c_void, c_void, c_void],
     "dvd_gemm_nt": [C.POINTER(GemmDesc), c_void],
     "dvd_flash_attn": [C.POINTER(AttnDesc), c_void],
+    "dvd_embed_obs_ln": [c_void, c_void, c_void, c_void, c_void, c_void, C.c_int, C.c_int, c_void],
+    "dvd_layernorm_rows": [c_void, C.c_int, C.c_long, c_void, C.c_int, C.c_long, C.c_int, C.c_long, C.c_int, c_void,
+                           c_void, c_void, c_void, C.c_int, C.c_int, C.c_float, c_void],
+    "dvd_build_r_rows": [c_void, c_void, c_void, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_void],
+    "dvd_patch_rows": [c_void, C.c_long, C.c_long, C.c_long, C.c_long, c_void, C.c_int, C.c_int, C.c_int, C.c_int,
+                       c_void],
+    "dvd_dwconv3x3": [c_void, c_void, c_void, c_void, C.c_int, C.c_int, C.c_int, c_void],
+    "dvd_colmean": [c_void, c_void, c_void, C.c_int, C.c_int, C.c_int, C.c_int, c_void],
+    "dvd_posenc_add": [c_void, c_void, c_void, c_void, c_void, C.c_int, C.c_int, C.c_int, c_void],
+    "dvd_small_linear": [c_void, C.c_int, c_void, c_void, c_void, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                         C.c_int, c_void],
+    "dvd_final_tokens": [c_void, c_void, c_void, c_void, c_void, C.c_int, C.c_int, c_void, c_void, c_void, c_void,
+                         c_void, C.c_int, C.c_int, c_void],
+    "dvd_im2col3x3": [c_void, C.c_long, C.c_long, C.c_long, c_void, C.c_int, C.c_int, C.c_int, C.c_int, c_void],
+    "dvd_maxpool2_nhwc": [c_void, c_void, C.c_int, C.c_int, C.c_int, c_void],
+    "dvd_resize_bilinear_nhwc": [c_void, c_void, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_void],
+    "dvd_nhwc_to_nchw": [c_void, c_void, C.c_int, C.c_int, C.c_int, c_void],
+    "dvd_engine_create": [C.c_int, C.c_int, C.c_int, C.POINTER(c_void)],
+    "dvd_engine_destroy": [c_void],
+    "dvd_engine_bind_workspace": [c_void, c_void, C.c_long],
+    "dvd_engine_tensor_count": [c_void],
+    "dvd_engine_tensor_info": [c_void, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int), C.POINTER(C.c_long)],
+    "dvd_engine_set_tensor": [c_void, C.c_char_p, c_void, C.c_long],
+    "dvd_engine_prepare_docs": [c_void, c_void, c_void, c_void, c_void, c_void],
+    "dvd_engine_feat_nchw": [c_void, c_void, c_void],
+    "dvd_engine_denoise_step": [c_void, c_void, C.c_float, C.c_int, c_void, c_void, c_void],
+    "dvd_engine_debug_buffer": [c_void, C.c_char_p, C.POINTER(c_void), C.POINTER(C.c_long)],
+    "dvd_engine_debug_stop": [c_void, C.c_int],
 }
 
 

@@ -1,0 +1,51 @@
+"""The sampling loop on the HIP engine - host-side mirror of
+GaussianDiffusion.ddim_sample_loop_progressive_only_mean (idf/gaussian_diffusion.py:537-644) for
+B documents x H hypotheses at once, plus the DDPM ancestral variant (BASELINE config 4)."""
+from __future__ import annotations
+
+import torch
+
+from . import ops, schedule
+from .engine import Engine
+
+
+def feat_mode_for(t_model: float, n: int, first_step: bool) -> int:
+    """Which init_feat the denoiser sees (idf/cross_model.py:596-601; idf/gaussian_diffusion.py:618-624):
+    1 = the pyramid features themselves, 2 = features warped by the previous x0, 0 = zeros."""
+    if t_model > 600 or (n > 1 and t_model == 2.0):
+        return 1
+    return 0 if first_step else 2
+
+
+def sample(engine: Engine, tables: schedule.Tables, x_T: torch.Tensor, sampler: str = "ddim", eta: float = 0.0,
+           noise_fn=None, mean_hyp: bool = True, trace=None):
+    """x_T [docs*H, 2, G, G] on the engine's device (sample index = doc*H + h).  The engine must have been
+    prepared for its documents.  noise_fn(step) -> [N,2,G,G] supplies the per-step noise (DDPM, or DDIM with
+    eta > 0).  Returns [docs,2,G,G] (hypothesis mean + clamp, :639-640) or the clamped per-sample maps."""
+    n = engine.n
+    S = tables.num_timesteps
+    img = x_T.contiguous()
+    zeros = torch.zeros_like(img)
+    x0_bufs = [torch.empty_like(img), torch.empty_like(img)]
+    x0 = None
+    for k, i in enumerate(range(S - 1, -1, -1)):
+        t_model = tables.model_time(i)
+        first = i == S - 1
+        flow = zeros if first else x0
+        out = x0_bufs[k & 1]
+        x0 = engine.denoise(img, schedule.embedded_time(t_model), feat_mode_for(t_model, n, first), flow, out=out)
+        if trace is not None:
+            trace.append(x0.clone())
+        if sampler == "ddim":
+            coef = tables.ddim_coef(i, eta)
+        elif sampler == "ddpm":
+            coef = tables.ddpm_coef(i)
+        else:
+            raise ValueError(f"unknown sampler {sampler!r}")
+        noise = noise_fn(i) if (coef.sigma != 0.0 and noise_fn is not None) else None
+        if coef.sigma != 0.0 and noise is None:
+            raise ValueError("this step needs noise: pass noise_fn")
+        img = ops.sched_step(coef, img, x0, noise)
+    if mean_hyp:
+        return ops.hyp_mean_clamp(x0, engine.n_hyp)
+    return torch.clamp(x0, -1, 1)

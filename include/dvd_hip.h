@@ -142,6 +142,94 @@ typedef struct {
 int dvd_flash_attn(const dvd_attn_desc* desc, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Token-side kernels (each also reachable on its own for parity tests).  "rows" = tokens of all
+ * samples, token-major; f16 outputs feed the GEMM / attention operands.
+ * ---------------------------------------------------------------------------------------- */
+
+/* obs_embedder (PatchEmbed k=s=2, 2->384) + bias + pos-embed, and cross_norm LayerNorm (no affine,
+ * eps 1e-6) of the result (idf/cross_model.py:571,238).  x [N,2,G,G]; w [384,8]; pos [T,384];
+ * tok32 [N*T,384] f32; ln16 [N*T,384] f16. */
+int dvd_embed_obs_ln(const float* x, const float* w, const float* bias, const float* pos, float* tok32,
+                     void* ln16, int n, int g, void* stream);
+
+/* LayerNorm over c in {384,1536} channels (+affine gamma/beta) (+adaLN modulate y*(1+scale)+shift with
+ * row / mod_rows selecting the modulation row) -> f16.  nn.LayerNorm + modulate() call sites:
+ * idf/cross_model.py:13-14,268-292; idf/cross_attn.py:386-391.  Batched over `batch` slices. */
+int dvd_layernorm_rows(const float* in, int ldin, long stride_in, void* out16, int ldout, long stride_out,
+                       int batch, long rows, int c, const float* gamma, const float* beta, const float* shift,
+                       const float* scale, int ldmod, int mod_rows, float eps, void* stream);
+
+/* Rows of the r_embedder GEMM: per token and 2x2 patch position the 258 channels
+ * cat([init_flow, init_feat]) (idf/cross_model.py:596-603) where init_feat is, by `mode`,
+ * 0: zeros, 1: feat itself (t > 600), 2: bilinear warp of feat by (init_flow + base)*2-1
+ * (idf/gaussian_diffusion.py:618-624).  feat is channels-last [docs,G,G,256]; out f16 [N*T, ldo>=1032]. */
+int dvd_build_r_rows(const float* feat_nhwc, const float* flow, void* out16, int ldo, int n, int g, int n_hyp,
+                     int mode, void* stream);
+
+/* 2x2 patch rows of a map with arbitrary element strides (PatchEmbed operand, idf/cross_model.py:585,594,605):
+ * out[(n*T+t)*ldo + (p*2+q)*c + ch] = in[n*sn + ch*sc + (2ty+p)*sy + (2tx+q)*sx]. */
+int dvd_patch_rows(const float* in, long sn, long sc, long sy, long sx, float* out, int ldo, int n, int c, int g,
+                   void* stream);
+
+/* Depthwise 3x3 (pad 1) + folded eval-mode BatchNorm + ReLU on the side x side token grid
+ * (LocalityAwareFeedforward.depthwise_conv, idf/cross_attn.py:33-41,54).  f16 [n*side*side, c]; w [9,c]. */
+int dvd_dwconv3x3(const void* in16, void* out16, const float* w9c, const float* b, int n, int side, int c,
+                  void* stream);
+
+/* Adaptive2DPositionalEncoding (idf/cross_attn.py:143-157): token mean per sample (deterministic two-stage),
+ * then z += hs[n,c]*htab[ty,c] + ws[n,c]*wtab[tx,c]. */
+int dvd_colmean(const float* z, float* partial, float* pooled, int n, int t, int c, int chunks, void* stream);
+int dvd_posenc_add(float* z, const float* hs, const float* ws, const float* htab, const float* wtab, int n, int side,
+                   int c, void* stream);
+
+/* Tiny-M linear y = act_out(W . act_in(x) + b): TimestepEmbedder (act_in 2 = sinusoid of x[m], idf/cross_model.py:111-139),
+ * adaLN_modulation (act_in 1 = SiLU, :175-177,325-327, kmod tiles the input: t.repeat(1,4) :331), pos-enc scale MLPs
+ * (act_out 2 ReLU / 3 sigmoid, idf/cross_attn.py:136-141). */
+int dvd_small_linear(const float* x, int ldx, const float* w, const float* b, float* y, int ldy, int m, int k, int n,
+                     int kmod, int act_in, int act_out, void* stream);
+
+/* decoder.layer_norm + FinalLayer2 + unpatchify + init_flow (idf/cross_attn.py:457; idf/cross_model.py:329-336,
+ * 553-566,645-646).  z [N*T,1536]; x0 [N,2,G,G]; tok8 (optional) [N*T,8]. */
+int dvd_final_tokens(const float* z, const float* gamma, const float* beta, const float* shift, const float* scale,
+                     int ldmod, int mod_rows, const float* w8, const float* b8, const float* init_flow, float* x0,
+                     float* tok8, int n, int g, void* stream);
+
+/* Conv pyramid pieces (idf/cross_model.py:18-95), channels-last f32. */
+int dvd_im2col3x3(const float* in, long sc, long sy, long sx, float* out, int ldo, int c, int h, int w, void* stream);
+int dvd_maxpool2_nhwc(const float* in, float* out, int c, int h, int w, void* stream);
+int dvd_resize_bilinear_nhwc(const float* in, float* out, int c, int hin, int win, int hout, int wout, void* stream);
+int dvd_nhwc_to_nchw(const float* in, float* out, int c, int h, int w, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Engine: DiT.forward of the live model (idf/cross_model.py:568-647) for docs x n_hyp samples.
+ *   create -> workspace_bytes -> bind_workspace -> set_tensor(every tensor of tensor_info) ->
+ *   prepare_docs (once per batch of documents) -> denoise_step (once per diffusion step).
+ * The engine owns no device memory.  Tensor names/sizes are enumerated by tensor_info; the host-side
+ * packer (dvd_amd/weights.py) derives them from a reference-named state_dict (model1852000.pt keys).
+ * ---------------------------------------------------------------------------------------- */
+int dvd_engine_create(int grid, int docs, int n_hyp, void** handle);
+int dvd_engine_destroy(void* handle);
+long dvd_engine_workspace_bytes(void* handle);
+int dvd_engine_bind_workspace(void* handle, void* workspace, long bytes);
+int dvd_engine_tensor_count(void* handle);
+int dvd_engine_tensor_info(void* handle, int index, const char** name, int* dtype /*0 f32, 1 f16*/, long* nelem);
+int dvd_engine_set_tensor(void* handle, const char* name, const void* dev_ptr, long nelem);
+/* y512 [docs,3,512,512] (0..1), mask_cat [docs,1,512,512], mask_y512 [docs,384,G,G], line_msk [docs,64,G,G]
+ * (kwargs of the denoiser call, train_settings/dvd/evaluation.py:106-115). */
+int dvd_engine_prepare_docs(void* handle, const float* y512, const float* mask_cat, const float* mask_y512,
+                            const float* line_msk, void* stream);
+/* feat as the reference returns it: [docs,256,G,G] (idf/cross_model.py:647). */
+int dvd_engine_feat_nchw(void* handle, float* out, void* stream);
+/* x_t, init_flow, x0_out [N,2,G,G].  t_embed = value fed to the timestep embedder after the override rule
+ * (idf/cross_model.py:575-580); feat_mode as in dvd_build_r_rows. */
+int dvd_engine_denoise_step(void* handle, const float* x_t, float t_embed, int feat_mode, const float* init_flow,
+                            float* x0_out, void* stream);
+/* Internal activation buffers by name (parity tests only); debug_stop makes denoise_step return after
+ * stage k: 1 cross-attention streams, 2 DiT block, 3 decoder pos-enc, 4+j decoder layer j (0 = run all). */
+int dvd_engine_debug_buffer(void* handle, const char* name, void** ptr, long* bytes);
+int dvd_engine_debug_stop(void* handle, int stage);
+
+/* ------------------------------------------------------------------------------------------
  * Hardware self-test of the MFMA fragment layouts the kernels rely on (exact integer data).
  * a16 [32,16], b16 [16,32], vt16 [32,32] f16; out [3072] f32 = {A.B, Vt.(A.B) via accumulator-as-
  * operand, f32-MFMA A[:, :2].B[:2, :]}.  No reference counterpart (test infrastructure). */
