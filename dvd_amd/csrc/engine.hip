@@ -56,7 +56,8 @@ static std::vector<TensorSpec> tensor_specs(int G) {
   const long T = (long)(G / 2) * (G / 2), side = G / 2;
   std::vector<TensorSpec> v;
   auto f32 = [&](const std::string& n, long e) { v.push_back({n, 0, e}); };
-  auto f16 = [&](const std::string& n, long e) { v.push_back({n, 1, e}); };
+  // every f16 weight comes as a (hi, lo) pair: W = hi + 2^-11 * lo  (see dvd_gemm_desc.B_lo)
+  auto f16 = [&](const std::string& n, long e) { v.push_back({n, 1, e}); v.push_back({n + "_lo", 1, e}); };
   f32("obs_w", HID * 8); f32("obs_b", HID); f32("pos", T * HID);
   f16("r_w16", (long)HID * RK); f32("r_b", HID);
   f32("c_w", (long)HID * 1024); f32("c_b", HID);
@@ -108,6 +109,7 @@ struct Engine {
   size_t ws_bytes = 0, need_bytes = 0;
   std::vector<Buf> bufs;
   bool prepared = false;
+  bool split_weights = true;   // use the lo parts (fp32-grade weights, 2x GEMM MFMAs)
   int debug_stop = 0;  // parity tests: return from denoise_step after stage k (0 = run everything)
 
   const void* W(const char* name) const {
@@ -117,6 +119,7 @@ struct Engine {
   }
   const float* Wf(const std::string& n) const { return (const float*)W(n.c_str()); }
   const void* Wh(const std::string& n) const { return W(n.c_str()); }
+  const void* Wl(const std::string& n) const { return split_weights ? W((n + "_lo").c_str()) : nullptr; }
   char* B(const char* name) const {
     for (auto& b : bufs)
       if (b.name == name) return ws + b.off;
@@ -165,9 +168,11 @@ static void plan(Engine* e) {
 static int gemm(int dtype, int M, int N, int K, int batch, const void* A, int lda, long sA, const void* Bm, int ldb,
                 long sB, float* C32, int ldc, long sC32, void* C16, int ldc16, long sC16, const float* bias,
                 int bias_row, int act, const float* pos, int pos_rows, const float* gate, int gate_rows,
-                const float* res, int ldres, long sRes, void* stream) {
+                const float* res, int ldres, long sRes, void* stream, const void* Alo = nullptr,
+                const void* Blo = nullptr) {
   dvd_gemm_desc d;
   memset(&d, 0, sizeof(d));
+  d.A_lo = Alo; d.B_lo = Blo; d.lo_scale = 1.f / 2048.f;
   d.dtype = dtype; d.M = M; d.N = N; d.K = K; d.batch = batch;
   d.A = A; d.lda = lda; d.strideA = sA;
   d.B = Bm; d.ldb = ldb; d.strideB = sB;
@@ -256,6 +261,14 @@ extern "C" int dvd_engine_set_tensor(void* handle, const char* name, const void*
       return DVD_OK;
     }
   set_error("engine_set_tensor: unknown tensor '%s'", name);
+  return DVD_E_ARG;
+}
+
+extern "C" int dvd_engine_set_option(void* handle, const char* name, int value) {
+  DVD_REQUIRE(handle && name, "engine_set_option: null pointer");
+  Engine* e = (Engine*)handle;
+  if (strcmp(name, "split_weights") == 0) { e->split_weights = value != 0; return DVD_OK; }
+  set_error("engine_set_option: unknown option '%s'", name);
   return DVD_E_ARG;
 }
 
@@ -429,15 +442,15 @@ extern "C" int dvd_engine_denoise_step(void* handle, const float* x_t, float t_e
   TRY(dvd_embed_obs_ln(x_t, e->Wf("obs_w"), e->Wf("obs_b"), e->Wf("pos"), xtok32, xq16, N, G, stream));
   TRY(dvd_build_r_rows((const float*)e->B("feat"), init_flow, arows16, RK, N, G, hyp, feat_mode, stream));
   TRY(gemm(0, (int)NT, HID, RK, 1, arows16, RK, 0, e->Wh("r_w16"), RK, 0, nullptr, 0, 0, rtok16, HID, 0, e->Wf("r_b"), 0,
-           0, e->Wf("pos"), T, nullptr, 0, nullptr, 0, 0, stream));
+           0, e->Wf("pos"), T, nullptr, 0, nullptr, 0, 0, stream, nullptr, e->Wl("r_w16")));
 
   // --- parallel cross-attention of the shared query against the 4 streams (:237-265) ---
   TRY(gemm(0, (int)NT, HID, HID, 1, xq16, HID, 0, e->Wh("ca_wq16"), HID, 0, nullptr, 0, 0, q16, HID, 0, e->Wf("ca_bq"),
-           0, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0, stream));
+           0, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0, stream, nullptr, e->Wl("ca_wq16")));
   TRY(gemm(0, (int)NT, HID, HID, 1, rtok16, HID, 0, e->Wh("ca_wk16"), HID, 0, nullptr, 0, 0, kr16, HID, 0,
-           e->Wf("ca_bk"), 0, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0, stream));
+           e->Wf("ca_bk"), 0, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0, stream, nullptr, e->Wl("ca_wk16")));
   TRY(gemm(0, HID, T, HID, N, e->Wh("ca_wv16"), HID, 0, rtok16, HID, (long)T * HID, nullptr, 0, 0, vtr16, T,
-           (long)HID * T, e->Wf("ca_bv"), 1, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0, stream));
+           (long)HID * T, e->Wf("ca_bv"), 1, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0, stream, e->Wl("ca_wv16"), nullptr));
   {
     const char* kn[3] = {"kc16", "km16", "kl16"};
     const char* vn[3] = {"vtc16", "vtm16", "vtl16"};
@@ -449,27 +462,27 @@ extern "C" int dvd_engine_denoise_step(void* handle, const float* x_t, float t_e
   }
   // x_s = x + out_proj(attn_s)  -> z[:, 384 s : 384 (s+1)]   (stream order cond, msk6, line, r == cat order :623)
   TRY(gemm(0, (int)NT, HID, HID, 4, att16, HID, NT * HID, e->Wh("ca_wo16"), HID, 0, z, DEC, HID, nullptr, 0, 0,
-           e->Wf("ca_bo"), 0, 0, nullptr, 0, nullptr, 0, xtok32, HID, 0, stream));
+           e->Wf("ca_bo"), 0, 0, nullptr, 0, nullptr, 0, xtok32, HID, 0, stream, nullptr, e->Wl("ca_wo16")));
 
   if (e->debug_stop == 1) return check_launch("engine_denoise_step(stop 1)");
   // --- per stream: gated self-attention (:268-289) ---
   TRY(dvd_layernorm_rows(z, DEC, HID, h16, HID, NT * HID, 4, NT, HID, nullptr, nullptr, sh_a, sc_a, 0, (int)NT, 1e-6f,
                          stream));
   TRY(gemm(0, (int)(4 * NT), 2 * HID, HID, 1, h16, HID, 0, e->Wh("sa_wqk16"), HID, 0, nullptr, 0, 0, qk16, 2 * HID, 0,
-           e->Wf("sa_bqk"), 0, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0, stream));
+           e->Wf("sa_bqk"), 0, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0, stream, nullptr, e->Wl("sa_wqk16")));
   TRY(gemm(0, HID, T, HID, 4 * N, e->Wh("sa_wv16"), HID, 0, h16, HID, (long)T * HID, nullptr, 0, 0, vt16, T,
-           (long)HID * T, e->Wf("sa_bv"), 1, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0, stream));
+           (long)HID * T, e->Wf("sa_bv"), 1, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0, stream, e->Wl("sa_wv16"), nullptr));
   TRY(attn(64, 6, 4 * N, T, T, 1, qk16, 2 * HID, (long)T * 2 * HID, qk16 + HID, 2 * HID, (long)T * 2 * HID, vt16, T,
            (long)HID * T, att16, HID, (long)T * HID, 0.125f, stream));
   TRY(gemm(0, (int)NT, HID, HID, 4, att16, HID, NT * HID, e->Wh("sa_wp16"), HID, 0, z, DEC, HID, nullptr, 0, 0,
-           e->Wf("sa_bp"), 0, 0, nullptr, 0, g_a, (int)NT, z, DEC, HID, stream));
+           e->Wf("sa_bp"), 0, 0, nullptr, 0, g_a, (int)NT, z, DEC, HID, stream, nullptr, e->Wl("sa_wp16")));
   // --- per stream: gated MLP (:271-292) ---
   TRY(dvd_layernorm_rows(z, DEC, HID, h16, HID, NT * HID, 4, NT, HID, nullptr, nullptr, sh_m, sc_m, 0, (int)NT, 1e-6f,
                          stream));
   TRY(gemm(0, (int)(4 * NT), 4 * HID, HID, 1, h16, HID, 0, e->Wh("fc1_w16"), HID, 0, nullptr, 0, 0, mlp16, 4 * HID, 0,
-           e->Wf("fc1_b"), 0, /*gelu*/ 1, nullptr, 0, nullptr, 0, nullptr, 0, 0, stream));
+           e->Wf("fc1_b"), 0, /*gelu*/ 1, nullptr, 0, nullptr, 0, nullptr, 0, 0, stream, nullptr, e->Wl("fc1_w16")));
   TRY(gemm(0, (int)NT, HID, 4 * HID, 4, mlp16, 4 * HID, NT * 4 * HID, e->Wh("fc2_w16"), 4 * HID, 0, z, DEC, HID,
-           nullptr, 0, 0, e->Wf("fc2_b"), 0, 0, nullptr, 0, g_m, (int)NT, z, DEC, HID, stream));
+           nullptr, 0, 0, e->Wf("fc2_b"), 0, 0, nullptr, 0, g_m, (int)NT, z, DEC, HID, stream, nullptr, e->Wl("fc2_w16")));
 
   if (e->debug_stop == 2) return check_launch("engine_denoise_step(stop 2)");
   // --- decoder: adaptive 2-D positional encoding (idf/cross_attn.py:143-157) ---
@@ -493,20 +506,20 @@ extern "C" int dvd_engine_denoise_step(void* handle, const float* x_t, float t_e
     TRY(dvd_layernorm_rows(z, DEC, 0, h16, DEC, 0, 1, NT, DEC, e->Wf(p + "n1w"), e->Wf(p + "n1b"), nullptr, nullptr, 0,
                            1, 1e-5f, stream));
     TRY(gemm(0, (int)NT, 2 * DEC, DEC, 1, h16, DEC, 0, e->Wh(p + "wqk16"), DEC, 0, nullptr, 0, 0, qk16, 2 * DEC, 0,
-             nullptr, 0, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0, stream));
+             nullptr, 0, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0, stream, nullptr, e->Wl(p + "wqk16")));
     TRY(gemm(0, DEC, T, DEC, N, e->Wh(p + "wv16"), DEC, 0, h16, DEC, (long)T * DEC, nullptr, 0, 0, vt16, T,
-             (long)DEC * T, nullptr, 0, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0, stream));
+             (long)DEC * T, nullptr, 0, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0, stream, e->Wl(p + "wv16"), nullptr));
     TRY(attn(256, 6, N, T, T, 1, qk16, 2 * DEC, (long)T * 2 * DEC, qk16 + DEC, 2 * DEC, (long)T * 2 * DEC, vt16, T,
              (long)DEC * T, att16, DEC, (long)T * DEC, 0.0625f, stream));
     TRY(gemm(0, (int)NT, DEC, DEC, 1, att16, DEC, 0, e->Wh(p + "wfc16"), DEC, 0, z, DEC, 0, nullptr, 0, 0, nullptr, 0,
-             0, nullptr, 0, nullptr, 0, z, DEC, 0, stream));
+             0, nullptr, 0, nullptr, 0, z, DEC, 0, stream, nullptr, e->Wl(p + "wfc16")));
     TRY(dvd_layernorm_rows(z, DEC, 0, h16, DEC, 0, 1, NT, DEC, e->Wf(p + "n2w"), e->Wf(p + "n2b"), nullptr, nullptr, 0,
                            1, 1e-5f, stream));
     TRY(gemm(0, (int)NT, FFN, DEC, 1, h16, DEC, 0, e->Wh(p + "c1w16"), DEC, 0, nullptr, 0, 0, f1, FFN, 0,
-             e->Wf(p + "c1b"), 0, 2, nullptr, 0, nullptr, 0, nullptr, 0, 0, stream));
+             e->Wf(p + "c1b"), 0, 2, nullptr, 0, nullptr, 0, nullptr, 0, 0, stream, nullptr, e->Wl(p + "c1w16")));
     TRY(dvd_dwconv3x3(f1, f2, e->Wf(p + "dww"), e->Wf(p + "dwb"), N, side, FFN, stream));
     TRY(gemm(0, (int)NT, DEC, FFN, 1, f2, FFN, 0, e->Wh(p + "c2w16"), FFN, 0, z, DEC, 0, nullptr, 0, 0,
-             e->Wf(p + "c2b"), 0, 2, nullptr, 0, nullptr, 0, z, DEC, 0, stream));
+             e->Wf(p + "c2b"), 0, 2, nullptr, 0, nullptr, 0, z, DEC, 0, stream, nullptr, e->Wl(p + "c2w16")));
     if (e->debug_stop == 4 + j) return check_launch("engine_denoise_step(stop 4+j)");
   }
 

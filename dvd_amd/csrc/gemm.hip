@@ -22,6 +22,9 @@ namespace dvd {
 struct GemmArgs {
   const void* A;      // [M,K] lda
   const void* B;      // [N,K] ldb
+  const void* Blo;    // optional low part of a split weight: B_true = B + lo_scale * Blo (same layout as B)
+  const void* Alo;    // ... or on the A side (swapped GEMMs put the weight in A); at most one of the two
+  float lo_scale;
   float* C32;         // optional [M,N] ldc
   _Float16* C16;      // optional [M,N] ldc16
   const float* bias;  // optional, per column (bias_row = 0) or per row (bias_row = 1)
@@ -66,6 +69,8 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(GemmArgs p) {
   const int z = blockIdx.y;
   const T* A = (const T*)p.A + z * p.sA;
   const T* B = (const T*)p.B + z * p.sB;
+  const T* Blo = p.Blo ? (const T*)p.Blo + z * p.sB : nullptr;
+  const T* Alo = p.Alo ? (const T*)p.Alo + z * p.sA : nullptr;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -75,6 +80,8 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(GemmArgs p) {
   // per-thread staging slots
   const T* ga[NLD];
   const T* gb[NLD];
+  const T* gbl[NLD];
+  const T* gal[NLD];
   int lofs[NLD];
 #pragma unroll
   for (int i = 0; i < NLD; ++i) {
@@ -83,6 +90,8 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(GemmArgs p) {
     const int ra = min(bm0 + row, p.M - 1), rb = min(bn0 + row, p.N - 1);
     ga[i] = A + (size_t)ra * p.lda + ch * EPC;
     gb[i] = B + (size_t)rb * p.ldb + ch * EPC;
+    gbl[i] = Blo ? Blo + (size_t)rb * p.ldb + ch * EPC : gb[i];
+    gal[i] = Alo ? Alo + (size_t)ra * p.lda + ch * EPC : ga[i];
     lofs[i] = row * LROW + ch * 16;
   }
   u32x4 ra_[NLD], rb_[NLD];
@@ -94,11 +103,15 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(GemmArgs p) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[m][n][i] = 0.f;
 
-  const int nk = p.K / BK;
+  // Split weights: the low parts are accumulated FIRST, the accumulator is scaled by lo_scale (a power of
+  // two: exact), then the high parts are added -> one accumulator, fp32-grade weights at 2x the MFMAs.
+  const int nkk = p.K / BK;
+  const int nlo = (Blo || Alo) ? nkk : 0;
+  const int nk = nkk + nlo;
 #pragma unroll
   for (int i = 0; i < NLD; ++i) {
-    ra_[i] = *(const u32x4*)(ga[i]);
-    rb_[i] = *(const u32x4*)(gb[i]);
+    ra_[i] = *(const u32x4*)(nlo ? gal[i] : ga[i]);
+    rb_[i] = *(const u32x4*)(nlo ? gbl[i] : gb[i]);
   }
 #pragma unroll
   for (int i = 0; i < NLD; ++i) {
@@ -110,10 +123,13 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(GemmArgs p) {
   for (int kt = 0; kt < nk; ++kt) {
     const bool more = kt + 1 < nk;
     if (more) {
+      const int tn = kt + 1;
+      const bool lo = tn < nlo;
+      const size_t kofs = (size_t)(lo ? tn : tn - nlo) * BK;
 #pragma unroll
       for (int i = 0; i < NLD; ++i) {
-        ra_[i] = *(const u32x4*)(ga[i] + (size_t)(kt + 1) * BK);
-        rb_[i] = *(const u32x4*)(gb[i] + (size_t)(kt + 1) * BK);
+        ra_[i] = *(const u32x4*)((lo ? gal[i] : ga[i]) + kofs);
+        rb_[i] = *(const u32x4*)((lo ? gbl[i] : gb[i]) + kofs);
       }
     }
     const char* sa = &smem[cur][0][(64 * wr + r) * LROW];
@@ -154,6 +170,14 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(GemmArgs p) {
         for (int m = 0; m < 2; ++m)
 #pragma unroll
           for (int n = 0; n < 2; ++n) acc[m][n] = mfma32_f32(a[m][s], b[n][s], acc[m][n]);
+    }
+    if (nlo && kt == nlo - 1) {
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) acc[m][n][i] *= p.lo_scale;
     }
     if (more) {
 #pragma unroll
@@ -215,6 +239,11 @@ extern "C" int dvd_gemm_nt(const dvd_gemm_desc* d, void* stream) {
   DVD_REQUIRE(!d->gate || d->gate_rows > 0, "gemm: gate needs gate_rows");
   DVD_REQUIRE(!d->pos || d->pos_rows > 0, "gemm: pos needs pos_rows");
   GemmArgs p;
+  DVD_REQUIRE(!(d->B_lo && d->A_lo), "gemm: only one operand may be split");
+  DVD_REQUIRE((!d->B_lo && !d->A_lo) ||
+                  (d->dtype == 0 && ((uintptr_t)d->B_lo % 16) == 0 && ((uintptr_t)d->A_lo % 16) == 0),
+              "gemm: split operands need dtype f16, 16-byte aligned");
+  p.Blo = d->B_lo; p.Alo = d->A_lo; p.lo_scale = d->lo_scale;
   p.A = d->A; p.B = d->B; p.C32 = d->C32; p.C16 = (_Float16*)d->C16;
   p.bias = d->bias; p.res = d->res; p.gate = d->gate; p.pos = d->pos;
   p.sA = d->strideA; p.sB = d->strideB; p.sC32 = d->strideC32; p.sC16 = d->strideC16;

@@ -101,6 +101,9 @@ class Engine:
                  stream_ptr())
         return out
 
+    def set_option(self, name: str, value: int):
+        lib.call("dvd_engine_set_option", self._h, name.encode(), int(value))
+
     def debug_stop(self, stage: int):
         lib.call("dvd_engine_debug_stop", self._h, stage)
 

@@ -47,6 +47,7 @@ class GemmDesc(C.Structure):
     _fields_ = [("dtype", C.c_int), ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("batch", C.c_int),
                 ("A", C.c_void_p), ("lda", C.c_int), ("strideA", C.c_long),
                 ("B", C.c_void_p), ("ldb", C.c_int), ("strideB", C.c_long),
+                ("B_lo", C.c_void_p), ("A_lo", C.c_void_p), ("lo_scale", C.c_float),
                 ("C32", C.c_void_p), ("ldc", C.c_int), ("strideC32", C.c_long),
                 ("C16", C.c_void_p), ("ldc16", C.c_int), ("strideC16", C.c_long),
                 ("bias", C.c_void_p), ("bias_row", C.c_int), ("strideBias", C.c_long),
@@ -119,6 +120,7 @@ SIGNATURES = {
     "dvd_engine_denoise_step": [c_void, c_void, C.c_float, C.c_int, c_void, c_void, c_void],
     "dvd_engine_debug_buffer": [c_void, C.c_char_p, C.POINTER(c_void), C.POINTER(C.c_long)],
     "dvd_engine_debug_stop": [c_void, C.c_int],
+    "dvd_engine_set_option": [c_void, C.c_char_p, C.c_int],
 }
 
 

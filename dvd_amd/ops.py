@@ -96,7 +96,8 @@ def _addr(t):
 
 
 def gemm_nt(a, b, *, out32=None, out16=None, bias=None, bias_row=False, act=0, pos=None, gate=None,
-            gate_rows=0, res=None, batch=1, strides=None, M=None, N=None, K=None, lda=None, ldb=None):
+            gate_rows=0, res=None, batch=1, strides=None, M=None, N=None, K=None, lda=None, ldb=None, b_lo=None,
+            a_lo=None, lo_scale=2.0 ** -11):
     """C = epi(A . B^T).  a [M,K] / b [N,K] f16 or f32 device tensors (2-D views may be strided in rows).
     strides: dict of batch strides in elements (A,B,C32,C16,bias,gate,res)."""
     assert a.dtype == b.dtype and a.dtype in (torch.float16, torch.float32)
@@ -109,6 +110,10 @@ def gemm_nt(a, b, *, out32=None, out16=None, bias=None, bias_row=False, act=0, p
     st = strides or {}
     d.A, d.lda, d.strideA = _addr(a), (lda if lda is not None else a.stride(-2)), st.get("A", 0)
     d.B, d.ldb, d.strideB = _addr(b), (ldb if ldb is not None else b.stride(-2)), st.get("B", 0)
+    if b_lo is not None:
+        d.B_lo, d.lo_scale = _addr(b_lo), lo_scale
+    if a_lo is not None:
+        d.A_lo, d.lo_scale = _addr(a_lo), lo_scale
     if out32 is not None:
         d.C32, d.ldc, d.strideC32 = _addr(out32), out32.stride(-2), st.get("C32", 0)
     if out16 is not None:

@@ -48,7 +48,16 @@ def pack(sd, grid: int):
     side = grid // 2
     T = side * side
     W = lambda k: _t(sd[k]).float()  # noqa: E731
-    out = {}
+
+    class _Out(dict):
+        """records the fp32 source of every f16 tensor so it can be split into (hi, lo) at the end"""
+        def __setitem__(self, k, v):
+            if k.endswith("16"):
+                full32[k] = v.float().contiguous()
+                v = v.half()
+            super().__setitem__(k, v)
+    full32 = {}
+    out = _Out()
     out["obs_w"] = W("obs_embedder.proj.weight").reshape(HID, 8)
     out["obs_b"] = W("obs_embedder.proj.bias")
     pos = W("noised_obs_pos_embed").reshape(-1, HID)
@@ -57,7 +66,7 @@ def pack(sd, grid: int):
     out["pos"] = pos
     rw = torch.zeros(HID, RK)
     rw[:, :1032] = _patch_w(W("r_embedder.proj.weight"))
-    out["r_w16"] = rw.half()
+    out["r_w16"] = rw
     out["r_b"] = W("r_embedder.proj.bias")
     for n, e in (("c", "c_embedder"), ("m", "m_embedder"), ("l", "l_embedder")):
         out[n + "_w"] = _patch_w(W(e + ".proj.weight"))
@@ -67,17 +76,17 @@ def pack(sd, grid: int):
     b = f"blocks.{live_block_index(sd)}."
     out["ada_w"], out["ada_b"] = W(b + "adaLN_modulation.1.weight"), W(b + "adaLN_modulation.1.bias")
     ipw, ipb = W(b + "cross_attn.in_proj_weight"), W(b + "cross_attn.in_proj_bias")
-    out["ca_wq16"], out["ca_bq"] = ipw[:HID].half(), ipb[:HID]
-    out["ca_wk16"], out["ca_bk"] = ipw[HID:2 * HID].half(), ipb[HID:2 * HID]
-    out["ca_wv16"], out["ca_bv"] = ipw[2 * HID:].half(), ipb[2 * HID:]
+    out["ca_wq16"], out["ca_bq"] = ipw[:HID], ipb[:HID]
+    out["ca_wk16"], out["ca_bk"] = ipw[HID:2 * HID], ipb[HID:2 * HID]
+    out["ca_wv16"], out["ca_bv"] = ipw[2 * HID:], ipb[2 * HID:]
     out["ca_wk32"], out["ca_wv32"] = ipw[HID:2 * HID], ipw[2 * HID:]
-    out["ca_wo16"], out["ca_bo"] = W(b + "cross_attn.out_proj.weight").half(), W(b + "cross_attn.out_proj.bias")
+    out["ca_wo16"], out["ca_bo"] = W(b + "cross_attn.out_proj.weight"), W(b + "cross_attn.out_proj.bias")
     qkv_w, qkv_b = W(b + "attn.qkv.weight"), W(b + "attn.qkv.bias")
-    out["sa_wqk16"], out["sa_bqk"] = qkv_w[:2 * HID].half(), qkv_b[:2 * HID]
-    out["sa_wv16"], out["sa_bv"] = qkv_w[2 * HID:].half(), qkv_b[2 * HID:]
-    out["sa_wp16"], out["sa_bp"] = W(b + "attn.proj.weight").half(), W(b + "attn.proj.bias")
-    out["fc1_w16"], out["fc1_b"] = W(b + "mlp.fc1.weight").half(), W(b + "mlp.fc1.bias")
-    out["fc2_w16"], out["fc2_b"] = W(b + "mlp.fc2.weight").half(), W(b + "mlp.fc2.bias")
+    out["sa_wqk16"], out["sa_bqk"] = qkv_w[:2 * HID], qkv_b[:2 * HID]
+    out["sa_wv16"], out["sa_bv"] = qkv_w[2 * HID:], qkv_b[2 * HID:]
+    out["sa_wp16"], out["sa_bp"] = W(b + "attn.proj.weight"), W(b + "attn.proj.bias")
+    out["fc1_w16"], out["fc1_b"] = W(b + "mlp.fc1.weight"), W(b + "mlp.fc1.bias")
+    out["fc2_w16"], out["fc2_b"] = W(b + "mlp.fc2.weight"), W(b + "mlp.fc2.bias")
     d = "decoder.position_dec."
     for hw in ("h", "w"):
         for j in (0, 2):
@@ -90,20 +99,20 @@ def pack(sd, grid: int):
     for j in range(6):
         p, o = f"decoder.layer_stack.{j}.", f"d{j}_"
         out[o + "n1w"], out[o + "n1b"] = W(p + "norm1.weight"), W(p + "norm1.bias")
-        out[o + "wqk16"] = torch.cat([W(p + "attn.linear_q.weight"), W(p + "attn.linear_k.weight")], 0).half()
-        out[o + "wv16"] = W(p + "attn.linear_v.weight").half()
-        out[o + "wfc16"] = W(p + "attn.fc.weight").half()
+        out[o + "wqk16"] = torch.cat([W(p + "attn.linear_q.weight"), W(p + "attn.linear_k.weight")], 0)
+        out[o + "wv16"] = W(p + "attn.linear_v.weight")
+        out[o + "wfc16"] = W(p + "attn.fc.weight")
         out[o + "n2w"], out[o + "n2b"] = W(p + "norm2.weight"), W(p + "norm2.bias")
         f = p + "feed_forward."
         s1, b1 = _fold_bn(sd, f + "conv1.")
-        out[o + "c1w16"] = (W(f + "conv1.conv.weight").reshape(FFN, DEC).double() * s1[:, None]).float().half()
+        out[o + "c1w16"] = (W(f + "conv1.conv.weight").reshape(FFN, DEC).double() * s1[:, None]).float()
         out[o + "c1b"] = b1.float()
         sd_, bd = _fold_bn(sd, f + "depthwise_conv.")
         dw = W(f + "depthwise_conv.conv.weight").reshape(FFN, 9).double() * sd_[:, None]
         out[o + "dww"] = dw.t().contiguous().float()          # [9, 2048] tap-major (ky*3+kx)
         out[o + "dwb"] = bd.float()
         s2, b2 = _fold_bn(sd, f + "conv2.")
-        out[o + "c2w16"] = (W(f + "conv2.conv.weight").reshape(DEC, FFN).double() * s2[:, None]).float().half()
+        out[o + "c2w16"] = (W(f + "conv2.conv.weight").reshape(DEC, FFN).double() * s2[:, None]).float()
         out[o + "c2b"] = b2.float()
     out["dec_nw"], out["dec_nb"] = W("decoder.layer_norm.weight"), W("decoder.layer_norm.bias")
     out["fin_ada_w"] = W("final_layer2.adaLN_modulation.1.weight")
@@ -118,4 +127,9 @@ def pack(sd, grid: int):
         wp[:, :flat.shape[1]] = flat
         out[f"pyr{i}_w"] = wp
         out[f"pyr{i}_b"] = W(f"pyramid.{n}.bias")
+    # split every f16 weight into hi + 2^-11 * lo (both f16): removes the systematic f16 weight-rounding error
+    # (which accumulates linearly over the diffusion steps) at 2x the GEMM MFMAs - see dvd_gemm_desc.B_lo
+    for k in [k for k in out if k.endswith("16")]:
+        hi = out[k]
+        out[k + "_lo"] = ((full32[k] - hi.float()) * 2048.0).half()
     return {k: v.contiguous() for k, v in out.items()}

@@ -101,6 +101,9 @@ int dvd_hyp_mean_clamp(const float* x0, float* out, int docs, int n_hyp, int g, 
  * dtype 0: A,B f16, fp32 accumulate (MFMA 32x32x16 f16);  dtype 1: A,B f32, exact fp32 MFMA.
  *   out = acc (+ bias[col] or bias[row]) -> act -> (+ pos[row % pos_rows][col]) -> (* gate[row / gate_rows][col])
  *         -> (+ res[row][col]);  stored to C32 (f32) and/or C16 (f16).
+ * B_lo/lo_scale: weights split into two f16 parts (hi + 2^-11 * lo) give fp32-grade weights at twice the MFMA
+ * work; used for every per-step weight because f16 weight rounding is a SYSTEMATIC error that accumulates
+ * linearly over the diffusion steps (precision).
  * Batched over `batch` with element strides (0 = shared operand).  K % 64 == 0 (f16) / % 16 (f32);
  * rows of A/B 16-byte aligned. */
 typedef struct {
@@ -108,6 +111,8 @@ typedef struct {
   int M, N, K, batch;
   const void* A; int lda; long strideA;
   const void* B; int ldb; long strideB;
+  const void* B_lo; const void* A_lo; float lo_scale; /* optional split weight (f16 only), on ONE side:
+                                                          X_true = X + lo_scale * X_lo */
   float* C32; int ldc; long strideC32;
   void* C16; int ldc16; long strideC16;
   const float* bias; int bias_row; long strideBias;
@@ -214,6 +219,8 @@ int dvd_engine_bind_workspace(void* handle, void* workspace, long bytes);
 int dvd_engine_tensor_count(void* handle);
 int dvd_engine_tensor_info(void* handle, int index, const char** name, int* dtype /*0 f32, 1 f16*/, long* nelem);
 int dvd_engine_set_tensor(void* handle, const char* name, const void* dev_ptr, long nelem);
+/* options: "split_weights" (default 1): use the (hi, lo) f16 weight pairs -> fp32-grade weights, 2x GEMM MFMAs. */
+int dvd_engine_set_option(void* handle, const char* name, int value);
 /* y512 [docs,3,512,512] (0..1), mask_cat [docs,1,512,512], mask_y512 [docs,384,G,G], line_msk [docs,64,G,G]
  * (kwargs of the denoiser call, train_settings/dvd/evaluation.py:106-115). */
 int dvd_engine_prepare_docs(void* handle, const float* y512, const float* mask_cat, const float* mask_y512,

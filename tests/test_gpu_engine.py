@@ -122,6 +122,39 @@ def test_sampling_loop_vs_reference_golden(grid, steps):
     assert err < 1e-3, (err, per_step)
 
 
+@pytest.mark.parametrize("grid,steps", [(16, 50), (32, 50)])
+def test_long_loop_vs_oracle(grid, steps):
+    """BASELINE's 50-step DDIM (not reference-runnable natively: local.py has 3 steps) against the CPU oracle."""
+    from dvd_amd import sampler, schedule
+    from oracle import dvd_oracle as O
+    eng, orc, doc_t, inv1 = setup(grid)
+    tab = schedule.Tables(schedule.named_betas("cosine", steps))
+    xT = torch.from_numpy(synth.synth_noise(0, 2, grid, SEED_IN))
+    tr_ref, tr = [], []
+    ref = orc.sample_loop(O.Schedule(steps), xT, {k: v[:1] for k, v in doc_t.items()}, trace=tr_ref)
+    out = sampler.sample(eng, tab, xT.cuda(), trace=tr)
+    per = [float((a.cpu() - b).pow(2).mean().sqrt()) for a, b in zip(tr, tr_ref)]
+    err = float((out.cpu() - ref).pow(2).mean().sqrt())
+    print("long loop rmse", grid, steps, err, "per-step[::7]", per[::7], "last", per[-1])
+    assert err < 1e-3, (err, per[-1])
+
+
+def test_ddpm_loop_vs_oracle():
+    """BASELINE config 4 sampler (DDPM ancestral, FIXED_LARGE) at a small size against the oracle."""
+    from dvd_amd import sampler, schedule
+    from oracle import dvd_oracle as O
+    grid, steps = 16, 25
+    eng, orc, doc_t, inv1 = setup(grid)
+    tab = schedule.Tables(schedule.named_betas("cosine", steps))
+    xT = torch.from_numpy(synth.synth_noise(0, 2, grid, SEED_IN))
+    noises = {i: torch.from_numpy(synth.synth_noise(0, 2, grid, SEED_IN, step=i)) for i in range(steps)}
+    ref = orc.sample_loop(O.Schedule(steps), xT, {k: v[:1] for k, v in doc_t.items()}, sampler="ddpm", noises=noises)
+    out = sampler.sample(eng, tab, xT.cuda(), sampler="ddpm", noise_fn=lambda i: noises[i].cuda())
+    err = float((out.cpu() - ref).pow(2).mean().sqrt())
+    print("ddpm loop rmse", err)
+    assert err < 1e-3, err
+
+
 def test_batched_documents_match_single():
     """Two documents x two hypotheses in one engine == each document alone (no cross-document math)."""
     from dvd_amd import sampler, schedule

@@ -87,3 +87,23 @@ def test_gemm_batched_swapped_rowbias(ops):
     for z in range(Z):
         ref = w.double() @ x[z * T:(z + 1) * T].double().t() + bias.double()[:, None]
         assert (out[z].cpu().double() - ref).abs().max() < 2e-2
+
+
+def test_gemm_split_weights(ops):
+    """W = hi + 2^-11 lo (both f16): result matches the fp32-weight product to activation-rounding level."""
+    M, N, K = 256, 384, 1536
+    a = rnd("sa", (M, K)).half()
+    w = rnd("sw", (N, K)) * 0.05
+    hi = w.half()
+    lo = ((w - hi.float()) * 2048.0).half()
+    ref = a.double() @ w.double().t()
+    out = torch.zeros(M, N, device="cuda")
+    ops.gemm_nt(a.cuda(), hi.cuda(), out32=out)
+    e_plain = (out.cpu().double() - ref).abs().max().item()
+    ops.gemm_nt(a.cuda(), hi.cuda(), out32=out, b_lo=lo.cuda())
+    e_split = (out.cpu().double() - ref).abs().max().item()
+    out_t = torch.zeros(N, M, device="cuda")
+    ops.gemm_nt(hi.cuda(), a.cuda(), out32=out_t, a_lo=lo.cuda())
+    e_split_a = (out_t.cpu().double().t() - ref).abs().max().item()
+    print("split weights", e_plain, e_split, e_split_a)
+    assert e_split < e_plain / 20 and e_split < 2e-5 and e_split_a < 2e-5, (e_plain, e_split, e_split_a)

@@ -115,16 +115,16 @@ def test_sched_step_golden(ops):
     tab = schedule.Tables(schedule.named_betas("cosine", 50))
     for i in range(50):
         out = ops.sched_step(tab.ddim_coef(i), x_t, x0).cpu().numpy()
-        np.testing.assert_allclose(out, g["ddim50/sample"][i], rtol=0, atol=2e-6, err_msg=f"t={i}")
+        assert np.array_equal(out, g["ddim50/sample"][i]), f"t={i}: not bit-identical to the reference's ddim_sample"
     tab = schedule.Tables(schedule.named_betas("cosine", 250))
     for i in range(0, 250, 7):
         c = tab.ddpm_coef(i)
         c.sigma = 0.0
         out = ops.sched_step(c, x_t, x0).cpu().numpy()
-        np.testing.assert_allclose(out, g["ddpm250/mean"][i], rtol=0, atol=1e-6)
+        assert np.array_equal(out, g["ddpm250/mean"][i]), f"t={i}: posterior mean not bit-identical to the reference"
 
 
-def test_sched_step_bit_exact_vs_oracle(ops):
+def test_sched_step_vs_oracle(ops):
     from dvd_amd import schedule
     from oracle import dvd_oracle as O
     G = 32
@@ -135,7 +135,9 @@ def test_sched_step_bit_exact_vs_oracle(ops):
     sch = O.Schedule(10)
     for i in (9, 5, 1, 0):
         out, grid = ops.sched_step(tab.ddim_coef(i), x_t.cuda(), x0.cuda(), want_grid=True)
-        assert torch.equal(out.cpu(), O.ddim_step(sch, i, x_t, x0)), i
+        # bit-identity is asserted against the reference's golden vectors above; torch-CPU elementwise kernels
+        # differ in the last bit between host ISAs (AVX2 container vs the GPU box), so allow 1-2 ulp here
+        np.testing.assert_allclose(out.cpu().numpy(), O.ddim_step(sch, i, x_t, x0).numpy(), rtol=3e-7, atol=3e-7)
         ref_grid = (x0 + O.base_grid(G, G)) * 2 - 1
         np.testing.assert_allclose(grid.cpu().numpy(), ref_grid.numpy(), rtol=0, atol=2.5e-7)
         out = ops.sched_step(tab.ddpm_coef(i), x_t.cuda(), x0.cuda(), noise=nz.cuda())
