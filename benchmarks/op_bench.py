@@ -64,11 +64,25 @@ def bench_gemm():
     return res
 
 
+def bench_attn():
+    res = {}
+    for (hd, B, T, scale) in [(256, 2, 20736, 0.0625), (64, 8, 20736, 0.125), (256, 2, 1024, 0.0625)]:
+        C = 6 * hd
+        qk = torch.randn(B, T, 2 * C, device="cuda").half()
+        vt = torch.randn(B, C, T, device="cuda").half()
+        out = torch.empty(B, T, C, dtype=torch.float16, device="cuda")
+        t = timeit(lambda: ops.flash_attn(qk[:, :, :C], qk[:, :, C:], vt, out, 6, hd, scale), iters=3, warm=1)
+        res[f"attn_hd{hd}_B{B}_T{T}"] = {"ms": t * 1e3, "TFLOPs": 4.0 * B * T * T * C / t / 1e12}
+    return res
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["unwarp"]
     out = {}
     if "unwarp" in which:
         out.update(bench_unwarp())
+    if "attn" in which:
+        out.update(bench_attn())
     if "gemm" in which:
         out.update(bench_gemm())
     print(json.dumps(out, indent=1))

@@ -259,7 +259,7 @@ extern "C" int dvd_flash_attn(const dvd_attn_desc* d, void* stream) {
     constexpr int LDS = 2 * (64 * (2 * 256 + 16) + 256 * (2 * 64 + 16));
     static bool once = false;
     if (!once) {
-      hipFuncSetAttribute((const void*)flash_attn_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+      (void)hipFuncSetAttribute((const void*)flash_attn_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
       once = true;
     }
     flash_attn_kernel<256><<<(unsigned)nwg, 256, LDS, (hipStream_t)stream>>>(p);

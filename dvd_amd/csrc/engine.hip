@@ -110,6 +110,10 @@ struct Engine {
   std::vector<Buf> bufs;
   bool prepared = false;
   bool split_weights = true;   // use the lo parts (fp32-grade weights, 2x GEMM MFMAs)
+  // optional per-launch timing of the dominant kernel (decoder attention) with HIP events on the launch stream
+  bool prof_on = false;
+  std::vector<hipEvent_t> prof_ev;
+  size_t prof_used = 0;
   int debug_stop = 0;  // parity tests: return from denoise_step after stage k (0 = run everything)
 
   const void* W(const char* name) const {
@@ -262,6 +266,36 @@ extern "C" int dvd_engine_set_tensor(void* handle, const char* name, const void*
     }
   set_error("engine_set_tensor: unknown tensor '%s'", name);
   return DVD_E_ARG;
+}
+
+extern "C" int dvd_engine_profile(void* handle, int enable) {
+  DVD_REQUIRE(handle, "engine_profile: null handle");
+  Engine* e = (Engine*)handle;
+  if (enable && e->prof_ev.empty()) {
+    e->prof_ev.resize(2 * 4096);
+    for (auto& ev : e->prof_ev)
+      if (hipEventCreate(&ev) != hipSuccess) { set_error("engine_profile: hipEventCreate failed"); return DVD_E_LAUNCH; }
+  }
+  e->prof_on = enable != 0;
+  e->prof_used = 0;
+  return DVD_OK;
+}
+
+extern "C" int dvd_engine_profile_read(void* handle, int* launches, double* total_ms) {
+  DVD_REQUIRE(handle && launches && total_ms, "engine_profile_read: null pointer");
+  Engine* e = (Engine*)handle;
+  *launches = 0; *total_ms = 0.0;
+  for (size_t i = 0; i + 1 < e->prof_used; i += 2) {
+    float ms = 0.f;
+    if (hipEventSynchronize(e->prof_ev[i + 1]) != hipSuccess ||
+        hipEventElapsedTime(&ms, e->prof_ev[i], e->prof_ev[i + 1]) != hipSuccess) {
+      set_error("engine_profile_read: event query failed");
+      return DVD_E_LAUNCH;
+    }
+    *total_ms += ms; *launches += 1;
+  }
+  e->prof_used = 0;
+  return DVD_OK;
 }
 
 extern "C" int dvd_engine_set_option(void* handle, const char* name, int value) {
@@ -509,8 +543,11 @@ extern "C" int dvd_engine_denoise_step(void* handle, const float* x_t, float t_e
              nullptr, 0, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0, stream, nullptr, e->Wl(p + "wqk16")));
     TRY(gemm(0, DEC, T, DEC, N, e->Wh(p + "wv16"), DEC, 0, h16, DEC, (long)T * DEC, nullptr, 0, 0, vt16, T,
              (long)DEC * T, nullptr, 0, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0, stream, e->Wl(p + "wv16"), nullptr));
+    const bool timed = e->prof_on && e->prof_used + 2 <= e->prof_ev.size();
+    if (timed) (void)hipEventRecord(e->prof_ev[e->prof_used], st);
     TRY(attn(256, 6, N, T, T, 1, qk16, 2 * DEC, (long)T * 2 * DEC, qk16 + DEC, 2 * DEC, (long)T * 2 * DEC, vt16, T,
              (long)DEC * T, att16, DEC, (long)T * DEC, 0.0625f, stream));
+    if (timed) { (void)hipEventRecord(e->prof_ev[e->prof_used + 1], st); e->prof_used += 2; }
     TRY(gemm(0, (int)NT, DEC, DEC, 1, att16, DEC, 0, e->Wh(p + "wfc16"), DEC, 0, z, DEC, 0, nullptr, 0, 0, nullptr, 0,
              0, nullptr, 0, nullptr, 0, z, DEC, 0, stream, nullptr, e->Wl(p + "wfc16")));
     TRY(dvd_layernorm_rows(z, DEC, 0, h16, DEC, 0, 1, NT, DEC, e->Wf(p + "n2w"), e->Wf(p + "n2b"), nullptr, nullptr, 0,

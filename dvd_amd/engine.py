@@ -104,6 +104,14 @@ class Engine:
     def set_option(self, name: str, value: int):
         lib.call("dvd_engine_set_option", self._h, name.encode(), int(value))
 
+    def profile(self, enable: bool):
+        lib.call("dvd_engine_profile", self._h, int(enable))
+
+    def profile_read(self):
+        n, ms = C.c_int(), C.c_double()
+        lib.call("dvd_engine_profile_read", self._h, C.byref(n), C.byref(ms))
+        return n.value, ms.value
+
     def debug_stop(self, stage: int):
         lib.call("dvd_engine_debug_stop", self._h, stage)
 

@@ -121,6 +121,8 @@ SIGNATURES = {
     "dvd_engine_debug_buffer": [c_void, C.c_char_p, C.POINTER(c_void), C.POINTER(C.c_long)],
     "dvd_engine_debug_stop": [c_void, C.c_int],
     "dvd_engine_set_option": [c_void, C.c_char_p, C.c_int],
+    "dvd_engine_profile": [c_void, C.c_int],
+    "dvd_engine_profile_read": [c_void, C.POINTER(C.c_int), C.POINTER(C.c_double)],
 }
 
 

@@ -231,6 +231,11 @@ int dvd_engine_feat_nchw(void* handle, float* out, void* stream);
  * (idf/cross_model.py:575-580); feat_mode as in dvd_build_r_rows. */
 int dvd_engine_denoise_step(void* handle, const float* x_t, float t_embed, int feat_mode, const float* init_flow,
                             float* x0_out, void* stream);
+/* Per-launch timing of the dominant kernel (the head_dim-256 decoder attention) with HIP events recorded on
+ * the launch stream: profile(1) arms it, profile_read returns the number of timed launches and their summed
+ * duration since the last read (synchronises on the events).  Used by bench.py's roofline leg. */
+int dvd_engine_profile(void* handle, int enable);
+int dvd_engine_profile_read(void* handle, int* launches, double* total_ms);
 /* Internal activation buffers by name (parity tests only); debug_stop makes denoise_step return after
  * stage k: 1 cross-attention streams, 2 DiT block, 3 decoder pos-enc, 4+j decoder layer j (0 = run all). */
 int dvd_engine_debug_buffer(void* handle, const char* name, void** ptr, long* bytes);

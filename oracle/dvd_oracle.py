@@ -193,8 +193,13 @@ def _mha_heads(q, k, v, heads, scale):
     qh = q.reshape(n, tq, heads, hd).transpose(1, 2) * scale
     kh = k.reshape(n, -1, heads, hd).transpose(1, 2)
     vh = v.reshape(n, -1, heads, hd).transpose(1, 2)
-    a = torch.softmax(qh @ kh.transpose(-2, -1), dim=-1)
-    return (a @ vh).transpose(1, 2).reshape(n, tq, c)
+    tk = kh.shape[2]
+    step = tq if n * heads * tq * tk <= (1 << 28) else max(1, (1 << 28) // (n * heads * tk))
+    outs = []
+    for q0 in range(0, tq, step):        # exact: softmax rows are independent (chunking only bounds memory)
+        a = torch.softmax(qh[:, :, q0:q0 + step] @ kh.transpose(-2, -1), dim=-1)
+        outs.append(a @ vh)
+    return torch.cat(outs, dim=2).transpose(1, 2).reshape(n, tq, c)
 
 
 class Oracle:
