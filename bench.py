@@ -190,7 +190,9 @@ def cpu_baseline(grid, hyp, steps):
     when the host can do it in well under a minute, otherwise at G=64 and scaled by the FLOP ratio."""
     from dvd_amd import synth
     from oracle import dvd_oracle as O
-    cores = os.cpu_count() or 1
+    # torch's intra-op pool stops scaling (and then collapses) long before a 256-thread host is full on these
+    # op sizes; 32 threads is at or past the knee on every host tried.  `cores` reports the threads used.
+    cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
 
     def time_one(g):

@@ -23,7 +23,7 @@ extern "C" {
 int dvd_embed_obs_ln(const float*, const float*, const float*, const float*, float*, void*, int, int, void*);
 int dvd_layernorm_rows(const float*, int, long, void*, int, long, int, long, int, const float*, const float*,
                        const float*, const float*, int, int, float, void*);
-int dvd_build_r_rows(const float*, const float*, void*, int, int, int, int, int, void*);
+int dvd_build_r_rows(const float*, const float*, const float*, void*, int, int, int, int, int, void*);
 int dvd_patch_rows(const float*, long, long, long, long, float*, int, int, int, int, void*);
 int dvd_dwconv3x3(const void*, void*, const float*, const float*, int, int, int, void*);
 int dvd_colmean(const float*, float*, float*, int, int, int, int, void*);
@@ -429,12 +429,14 @@ extern "C" int dvd_engine_feat_nchw(void* handle, float* out, void* stream) {
 //   x_t, init_flow, x0_out : [N,2,G,G] f32.   t_embed: the (batch-global) value fed to the timestep
 //   embedder after the reference's override rule (:575-580).   feat_mode: 1 -> init_feat = feat
 //   (t_model > 600, :597-598), 2 -> init_feat = grid_sample(feat, (init_flow + base)*2-1)
-//   (idf/gaussian_diffusion.py:618-624), 0 -> init_feat = 0.
+//   (idf/gaussian_diffusion.py:618-624), 0 -> init_feat = 0, 3 -> init_feat_nchw [N,256,G,G] given explicitly.
 // ------------------------------------------------------------------------------------------------
 extern "C" int dvd_engine_denoise_step(void* handle, const float* x_t, float t_embed, int feat_mode,
-                                       const float* init_flow, float* x0_out, void* stream) {
+                                       const float* init_flow, const float* init_feat_nchw, float* x0_out,
+                                       void* stream) {
   DVD_REQUIRE(handle && x_t && init_flow && x0_out, "engine_denoise_step: null pointer");
-  DVD_REQUIRE(feat_mode >= 0 && feat_mode <= 2, "engine_denoise_step: feat_mode");
+  DVD_REQUIRE(feat_mode >= 0 && feat_mode <= 3 && (feat_mode != 3 || init_feat_nchw),
+              "engine_denoise_step: feat_mode %d (3 needs init_feat)", feat_mode);
   Engine* e = (Engine*)handle;
   TRY(require_ready(e, true));
   hipStream_t st = (hipStream_t)stream;
@@ -474,7 +476,8 @@ extern "C" int dvd_engine_denoise_step(void* handle, const float* x_t, float t_e
 
   // --- tokens ---
   TRY(dvd_embed_obs_ln(x_t, e->Wf("obs_w"), e->Wf("obs_b"), e->Wf("pos"), xtok32, xq16, N, G, stream));
-  TRY(dvd_build_r_rows((const float*)e->B("feat"), init_flow, arows16, RK, N, G, hyp, feat_mode, stream));
+  TRY(dvd_build_r_rows((const float*)e->B("feat"), init_feat_nchw, init_flow, arows16, RK, N, G, hyp, feat_mode,
+                       stream));
   TRY(gemm(0, (int)NT, HID, RK, 1, arows16, RK, 0, e->Wh("r_w16"), RK, 0, nullptr, 0, 0, rtok16, HID, 0, e->Wf("r_b"), 0,
            0, e->Wf("pos"), T, nullptr, 0, nullptr, 0, 0, stream, nullptr, e->Wl("r_w16")));
 

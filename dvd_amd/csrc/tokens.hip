@@ -133,10 +133,11 @@ __global__ void __launch_bounds__(256) layernorm_rows_kernel(const float* __rest
 // feat is channels-last [docs, G, G, 256] f32; flow [N,2,G,G] (x0_prev = init_flow);
 // the warp grid is (x0_prev + base)*2-1 (idf/gaussian_diffusion.py:618-624), zeros padding.
 // Output f16 [N*T, ldo] with ldo >= 1032 (pad columns zeroed).   One wave per (token, pq).
-// mode: 0 = init_feat is zero (first step with tv: never used since t>600 overrides) , 1 = feat
-// itself (t > 600, idf/cross_model.py:597-598), 2 = warped feat.
+// mode: 0 = init_feat is zero, 1 = feat itself (t > 600, idf/cross_model.py:597-598), 2 = warped feat,
+// 3 = an explicit init_feat tensor [N,256,G,G] (NCHW) supplied by the caller (direct model() calls).
 // ----------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) build_r_rows_kernel(const float* __restrict__ feat,
+                                                           const float* __restrict__ init_feat_nchw,
                                                            const float* __restrict__ flow,
                                                            _Float16* __restrict__ out, int ldo, int g, int n_hyp,
                                                            int mode, long items) {
@@ -157,6 +158,9 @@ __global__ void __launch_bounds__(256) build_r_rows_kernel(const float* __restri
   if (mode == 1) {
     const floatx4 f = *(const floatx4*)(fd + ((size_t)y * g + x) * 256 + 4 * lane);
     v[0] = f[0]; v[1] = f[1]; v[2] = f[2]; v[3] = f[3];
+  } else if (mode == 3) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = init_feat_nchw[((size_t)n * 256 + 4 * lane + e) * gg + (size_t)y * g + x];
   } else if (mode == 2) {
     const float inv = 1.f / (float)(g - 1);
     const float gx = sub_rn(mul_rn(add_rn(fx, (float)x * inv), 2.f), 1.f);
@@ -480,13 +484,15 @@ extern "C" int dvd_layernorm_rows(const float* in, int ldin, long stride_in, voi
   return check_launch("layernorm_rows");
 }
 
-extern "C" int dvd_build_r_rows(const float* feat_nhwc, const float* flow, void* out16, int ldo, int n, int g,
-                                int n_hyp, int mode, void* stream) {
+extern "C" int dvd_build_r_rows(const float* feat_nhwc, const float* init_feat_nchw, const float* flow, void* out16,
+                                int ldo, int n, int g, int n_hyp, int mode, void* stream) {
   DVD_REQUIRE(feat_nhwc && flow && out16, "build_r_rows: null pointer");
-  DVD_REQUIRE(ldo >= 1032 && n > 0 && g >= 2 && g % 2 == 0 && n_hyp > 0 && mode >= 0 && mode <= 2,
+  DVD_REQUIRE(ldo >= 1032 && n > 0 && g >= 2 && g % 2 == 0 && n_hyp > 0 && mode >= 0 && mode <= 3,
               "build_r_rows: bad arguments");
+  DVD_REQUIRE(mode != 3 || init_feat_nchw, "build_r_rows: mode 3 needs init_feat");
   const long items = (long)n * (g / 2) * (g / 2) * 4;
-  build_r_rows_kernel<<<LAUNCH_ROWS(items)>>>(feat_nhwc, flow, (_Float16*)out16, ldo, g, n_hyp, mode, items);
+  build_r_rows_kernel<<<LAUNCH_ROWS(items)>>>(feat_nhwc, init_feat_nchw, flow, (_Float16*)out16, ldo, g, n_hyp, mode,
+                                              items);
   return check_launch("build_r_rows");
 }
 

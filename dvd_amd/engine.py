@@ -90,15 +90,20 @@ class Engine:
         lib.call("dvd_engine_feat_nchw", self._h, ptr(out), stream_ptr())
         return out
 
-    def denoise(self, x_t, t_embed: float, feat_mode: int, init_flow, out=None):
+    def denoise(self, x_t, t_embed: float, feat_mode: int, init_flow, out=None, init_feat=None):
         shp = (self.n, 2, self.grid, self.grid)
         for t in (x_t, init_flow):
             if tuple(t.shape) != shp or t.dtype != torch.float32 or not t.is_cuda or not t.is_contiguous():
                 raise lib.DvdError(f"denoise: expected contiguous f32 device tensor of shape {shp}")
         if out is None:
             out = torch.empty(shp, dtype=torch.float32, device=self.device)
-        lib.call("dvd_engine_denoise_step", self._h, ptr(x_t), C.c_float(t_embed), feat_mode, ptr(init_flow), ptr(out),
-                 stream_ptr())
+        if feat_mode == 3:
+            fs = (self.n, 256, self.grid, self.grid)
+            if init_feat is None or tuple(init_feat.shape) != fs or init_feat.dtype != torch.float32 \
+                    or not init_feat.is_cuda or not init_feat.is_contiguous():
+                raise lib.DvdError(f"denoise: feat_mode 3 needs a contiguous f32 device init_feat of shape {fs}")
+        lib.call("dvd_engine_denoise_step", self._h, ptr(x_t), C.c_float(t_embed), feat_mode, ptr(init_flow),
+                 ptr(init_feat if feat_mode == 3 else None), ptr(out), stream_ptr())
         return out
 
     def set_option(self, name: str, value: int):

@@ -95,7 +95,7 @@ SIGNATURES = {
     "dvd_embed_obs_ln": [c_void, c_void, c_void, c_void, c_void, c_void, C.c_int, C.c_int, c_void],
     "dvd_layernorm_rows": [c_void, C.c_int, C.c_long, c_void, C.c_int, C.c_long, C.c_int, C.c_long, C.c_int, c_void,
                            c_void, c_void, c_void, C.c_int, C.c_int, C.c_float, c_void],
-    "dvd_build_r_rows": [c_void, c_void, c_void, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_void],
+    "dvd_build_r_rows": [c_void, c_void, c_void, c_void, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_void],
     "dvd_patch_rows": [c_void, C.c_long, C.c_long, C.c_long, C.c_long, c_void, C.c_int, C.c_int, C.c_int, C.c_int,
                        c_void],
     "dvd_dwconv3x3": [c_void, c_void, c_void, c_void, C.c_int, C.c_int, C.c_int, c_void],
@@ -117,7 +117,7 @@ SIGNATURES = {
     "dvd_engine_set_tensor": [c_void, C.c_char_p, c_void, C.c_long],
     "dvd_engine_prepare_docs": [c_void, c_void, c_void, c_void, c_void, c_void],
     "dvd_engine_feat_nchw": [c_void, c_void, c_void],
-    "dvd_engine_denoise_step": [c_void, c_void, C.c_float, C.c_int, c_void, c_void, c_void],
+    "dvd_engine_denoise_step": [c_void, c_void, C.c_float, C.c_int, c_void, c_void, c_void, c_void],
     "dvd_engine_debug_buffer": [c_void, C.c_char_p, C.POINTER(c_void), C.POINTER(C.c_long)],
     "dvd_engine_debug_stop": [c_void, C.c_int],
     "dvd_engine_set_option": [c_void, C.c_char_p, C.c_int],

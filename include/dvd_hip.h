@@ -167,9 +167,10 @@ int dvd_layernorm_rows(const float* in, int ldin, long stride_in, void* out16, i
 /* Rows of the r_embedder GEMM: per token and 2x2 patch position the 258 channels
  * cat([init_flow, init_feat]) (idf/cross_model.py:596-603) where init_feat is, by `mode`,
  * 0: zeros, 1: feat itself (t > 600), 2: bilinear warp of feat by (init_flow + base)*2-1
- * (idf/gaussian_diffusion.py:618-624).  feat is channels-last [docs,G,G,256]; out f16 [N*T, ldo>=1032]. */
-int dvd_build_r_rows(const float* feat_nhwc, const float* flow, void* out16, int ldo, int n, int g, int n_hyp,
-                     int mode, void* stream);
+ * (idf/gaussian_diffusion.py:618-624), 3: the explicit tensor init_feat_nchw [N,256,G,G].
+ * feat is channels-last [docs,G,G,256]; out f16 [N*T, ldo>=1032]. */
+int dvd_build_r_rows(const float* feat_nhwc, const float* init_feat_nchw, const float* flow, void* out16, int ldo,
+                     int n, int g, int n_hyp, int mode, void* stream);
 
 /* 2x2 patch rows of a map with arbitrary element strides (PatchEmbed operand, idf/cross_model.py:585,594,605):
  * out[(n*T+t)*ldo + (p*2+q)*c + ch] = in[n*sn + ch*sc + (2ty+p)*sy + (2tx+q)*sx]. */
@@ -230,7 +231,7 @@ int dvd_engine_feat_nchw(void* handle, float* out, void* stream);
 /* x_t, init_flow, x0_out [N,2,G,G].  t_embed = value fed to the timestep embedder after the override rule
  * (idf/cross_model.py:575-580); feat_mode as in dvd_build_r_rows. */
 int dvd_engine_denoise_step(void* handle, const float* x_t, float t_embed, int feat_mode, const float* init_flow,
-                            float* x0_out, void* stream);
+                            const float* init_feat_nchw /* feat_mode 3 only, else NULL */, float* x0_out, void* stream);
 /* Per-launch timing of the dominant kernel (the head_dim-256 decoder attention) with HIP events recorded on
  * the launch stream: profile(1) arms it, profile_read returns the number of timed launches and their summed
  * duration since the last read (synchronises on the events).  Used by bench.py's roofline leg. */
