@@ -55,6 +55,7 @@ __global__ void __launch_bounds__(256, (D == 256 ? 1 : 2)) flash_attn_kernel(Att
   constexpr int NV = D * 8 / 256;        // V^T chunks per thread (8 / 2)
   constexpr int KS = D / 16;             // k-steps of the first product
   constexpr int DT = D / 32;             // 32-row tiles of O^T
+  constexpr float RESCALE_THR = 10.f;
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][KBYTES + VBYTES]
 
   const int nwg = gridDim.x;
@@ -118,11 +119,16 @@ __global__ void __launch_bounds__(256, (D == 256 ? 1 : 2)) flash_attn_kernel(Att
       const int kr = min(key0 + k_row[i], p.tk - 1);                                        \
       kreg[i] = *(const u32x4*)(Kg + (size_t)kr * p.ldk + k_col[i]);                        \
     }                                                                                       \
-    _Pragma("unroll") for (int i = 0; i < NV; ++i) {                                        \
-      const int kc = key0 + v_col[i];                                                       \
-      u32x4 v = {0u, 0u, 0u, 0u};                                                           \
-      if (kc < p.tk) v = *(const u32x4*)(Vg + (size_t)v_row[i] * p.ldvt + kc);              \
-      vreg[i] = v;                                                                          \
+    if (key0 + KB <= p.tk) { /* wave-uniform fast path: no per-chunk predication */         \
+      _Pragma("unroll") for (int i = 0; i < NV; ++i)                                        \
+        vreg[i] = *(const u32x4*)(Vg + (size_t)v_row[i] * p.ldvt + key0 + v_col[i]);        \
+    } else {                                                                                \
+      _Pragma("unroll") for (int i = 0; i < NV; ++i) {                                      \
+        const int kc = key0 + v_col[i];                                                     \
+        u32x4 v = {0u, 0u, 0u, 0u};                                                         \
+        if (kc < p.tk) v = *(const u32x4*)(Vg + (size_t)v_row[i] * p.ldvt + kc);            \
+        vreg[i] = v;                                                                        \
+      }                                                                                     \
     }                                                                                       \
   }
 #define DVD_ATTN_LSTORE(buf_)                                                               \
@@ -173,23 +179,30 @@ __global__ void __launch_bounds__(256, (D == 256 ? 1 : 2)) flash_attn_kernel(Att
       for (int i = 0; i < 16; ++i) mx = fmaxf(mx, s[kb][i]);
     mx *= p.c;                                  // c > 0
     mx = fmaxf(mx, __shfl_xor(mx, 32));
-    const float m_new = fmaxf(m_run, mx);
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-    m_run = m_new;
+    // Deferred rescale (guide T13): keep the running max stale while this tile's max exceeds it by less than
+    // RESCALE_THR (log2 units).  P then lies in (0, 2^THR] instead of (0, 1]: f16 keeps the same RELATIVE
+    // precision there, and the fp32 accumulators O^T / l have ample range.  The decision is wave-uniform and
+    // taken BEFORE this tile's P is formed, so O^T, l and P always share one reference max.
+    if (__any(mx - m_run > RESCALE_THR)) {
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      m_run = m_new;
+      l_run *= alpha;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o[dt][i] *= alpha;
+    }
     float rs = 0.f;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        const float pv = __builtin_amdgcn_exp2f(fmaf(s[kb][i], p.c, -m_new));
+        const float pv = __builtin_amdgcn_exp2f(fmaf(s[kb][i], p.c, -m_run));
         s[kb][i] = pv;
         rs += pv;
       }
-    l_run = l_run * alpha + rs;                 // per-lane partial (this half's keys)
-#pragma unroll
-    for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) o[dt][i] *= alpha;
+    l_run += rs;                                // per-lane partial (this half's keys)
 
     // ---- O^T += V^T . P^T
     half8 pf[2][2];
