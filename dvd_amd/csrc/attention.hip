@@ -24,6 +24,7 @@
 //     (batch, head), so its K/V stream is served from that XCD's L2.
 #include "common.h"
 #include "mfma.h"
+#include <stdlib.h>
 
 namespace dvd {
 
@@ -244,6 +245,245 @@ __global__ void __launch_bounds__(256, (D == 256 ? 1 : 2)) flash_attn_kernel(Att
   }
 }
 
+
+// Direct global->LDS loads issued from inline asm (guide 5.7): hipcc then does not know an LDS-DMA is in
+// flight - with the builtin form its waitcnt pass degrades EVERY LDS wait in the loop to lgkmcnt(0), which
+// serialises the fragment-read pipeline - and the SGPR-base + 32-bit-VGPR-offset address form costs no VALU.
+// N loads of 1 KiB each to LDS addresses lds, lds+1024, ...; completion is tracked by the caller's vmcnt(0).
+template <int N>
+__device__ __forceinline__ void glds_group(const char* gbase, const unsigned (&voff)[N], unsigned lds) {
+  static_assert(N == 2 || N == 8, "unsupported group size");
+  unsigned keep;
+  if constexpr (N == 8) {
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %1\n\t"
+        "s_add_u32 m0, %2, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %1\n\t"
+        "s_add_u32 m0, %2, 0x800\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %5, %1\n\t"
+        "s_add_u32 m0, %2, 0xc00\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %6, %1\n\t"
+        "s_add_u32 m0, %2, 0x1000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %7, %1\n\t"
+        "s_add_u32 m0, %2, 0x1400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %8, %1\n\t"
+        "s_add_u32 m0, %2, 0x1800\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %9, %1\n\t"
+        "s_add_u32 m0, %2, 0x1c00\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %10, %1\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "s"(gbase), "s"(lds), "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "v"(voff[3]), "v"(voff[4]), "v"(voff[5]),
+          "v"(voff[6]), "v"(voff[7])
+        : "memory", "scc");
+  } else {
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %1\n\t"
+        "s_add_u32 m0, %2, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %1\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "s"(gbase), "s"(lds), "v"(voff[0]), "v"(voff[1])
+        : "memory", "scc");
+  }
+}
+
+// ================================================================================================
+// Fast path (tk % 64 == 0: every shape the engine produces): K / V^T tiles go global -> LDS DIRECTLY
+// (global_load_lds_dwordx4, 1 KiB per wave-instruction, no staging registers, no ds_write).  The LDS
+// image of such a load is lane-linear, so bank conflicts are avoided by an XOR swizzle applied to the
+// per-lane SOURCE address and, identically, to the fragment reads (guide rule 21):
+//   512-byte rows (K, head_dim 256): 16-byte chunk c of row r lives at chunk  c ^ (r & 15)
+//   128-byte rows (K at head_dim 64, V^T always):                  at chunk  c ^ ((r >> 1) & 7)
+// which makes the 16 rows of every ds_read_b128 lane group hit 16 distinct 16-byte bank slots.
+// The swizzled read offsets are per-lane constants precomputed once (KS + 4 VGPRs).
+// Without staging registers the wave's working set (Q 64 + S^T 32 + P 16 + fragments) fits the 256
+// architectural VGPRs and the 128 O^T accumulators stay in AGPRs untouched by the VALU: the v1
+// structure spent ~400 v_accvgpr moves per tile shuffling spilled state.
+// ================================================================================================
+template <int D>
+__global__ void __launch_bounds__(256, (D == 256 ? 1 : 2)) flash_attn_glds_kernel(AttnArgs p) {
+  constexpr int KB = 64;
+  constexpr int KROWB = 2 * D;             // K row bytes (512 / 128)
+  constexpr int KCPR = KROWB / 16;         // chunks per K row (32 / 8)
+  constexpr int KBYTES = KB * KROWB;       // 32768 / 8192
+  constexpr int VBYTES = D * 128;          // V^T tile: D rows x 64 keys x 2 B
+  constexpr int BUF = KBYTES + VBYTES;
+  constexpr int KINST = KBYTES / 4096;     // 1-KiB loads per wave per tile (8 / 2)
+  constexpr int VINST = VBYTES / 4096;
+  constexpr int KS = D / 16;
+  constexpr int DT = D / 32;
+  constexpr float RESCALE_THR = 10.f;
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][BUF]
+  typedef const __attribute__((address_space(1))) void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+
+  const int nwg = gridDim.x;
+  int id = blockIdx.x;
+  {
+    const int q = nwg / 8, rr = nwg % 8, xcd = id % 8, k = id / 8;
+    id = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + k;
+  }
+  const int qb = id % p.nqb;
+  const int bh = id / p.nqb;
+  const int head = bh % p.heads, b = bh / p.heads;
+  const int kvb = b / p.kv_div;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+
+  const _Float16* Qg = p.Q + b * p.sQ + (size_t)head * D;
+  const char* Kg = (const char*)(p.K + kvb * p.sK + (size_t)head * D);
+  const char* Vg = (const char*)(p.Vt + kvb * p.sVt + (size_t)head * D * p.ldvt);
+
+  const int qrow = min(qb * 128 + wave * 32 + r, p.tq - 1);
+  half8 qf[KS];
+  {
+    const _Float16* qp = Qg + (size_t)qrow * p.ldq + 8 * h;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const half8*)(qp + 16 * ks);
+  }
+
+  // ---- per-lane SOURCE offsets (bytes) of the direct-to-LDS loads, swizzled
+  unsigned koff[KINST], voff[VINST];
+#pragma unroll
+  for (int i = 0; i < KINST; ++i) {
+    const int q = (KINST * wave + i) * 64 + lane;
+    const int row = q / KCPR, pos = q % KCPR;
+    const int f = (KCPR == 32) ? (row & 15) : ((row >> 1) & 7);
+    koff[i] = (unsigned)row * (unsigned)(p.ldk * 2) + (unsigned)((pos ^ f) * 16);
+  }
+#pragma unroll
+  for (int i = 0; i < VINST; ++i) {
+    const int q = (VINST * wave + i) * 64 + lane;
+    const int row = q / 8, pos = q % 8;
+    voff[i] = (unsigned)row * (unsigned)(p.ldvt * 2) + (unsigned)((pos ^ ((row >> 1) & 7)) * 16);
+  }
+  // ---- per-lane fragment READ offsets, same swizzle
+  const int kr = kappa(r);
+  const int fk = (KCPR == 32) ? (kr & 15) : ((kr >> 1) & 7);
+  int kfrag[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) kfrag[ks] = kr * KROWB + (((2 * ks + h) ^ fk) * 16);
+  const int fv = (r >> 1) & 7;
+  int vfrag[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) vfrag[c] = KBYTES + r * 128 + (((2 * c + h) ^ fv) * 16);   // c = 2 kb + s2
+
+  floatx16 o[DT];
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) o[dt][i] = 0.f;
+  float m_run = -1e30f, l_run = 0.f;
+  const int nt = p.tk / KB;
+  const size_t ktile = (size_t)KB * p.ldk * 2;   // bytes between K tiles
+
+  const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t)smem;   // LDS byte address of the dynamic region
+#define DVD_GLDS_ISSUE(t_, buf_)                                                                           \
+  {                                                                                                        \
+    glds_group<KINST>(Kg + (size_t)(t_) * ktile, koff, lds0 + (buf_) * BUF + (KINST * wave) * 1024);        \
+    glds_group<VINST>(Vg + (size_t)(t_) * (KB * 2), voff, lds0 + (buf_) * BUF + KBYTES + (VINST * wave) * 1024); \
+  }
+
+  DVD_GLDS_ISSUE(0, 0)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  // ---- main loop.  The instruction stream is pinned with sched_barrier(0) into groups of
+  //      { 1 MFMA, 1 LDS fragment read for the MFMA four groups later, a few VALU } so that
+  //      (a) four ds_read_b128 are always in flight ahead of their consumer (hipcc otherwise emits
+  //          read -> lgkmcnt(0) -> MFMA pairs and the matrix pipe idles on LDS latency), the compiler
+  //          still places the counted s_waitcnt and every MFMA hazard itself;
+  //      (b) the exp2 / sum / f16-pack of P chunk c+1 issues in the gaps of the 8 MFMAs of chunk c.
+#define SB() __builtin_amdgcn_sched_barrier(0)
+#define KLOAD(i_) fr[(i_) & 7] = *(const half8*)(base + kfrag[(i_) % KS] + ((i_) / KS) * 32 * KROWB)
+#define VLOAD(j_) fr[(j_) & 7] = *(const half8*)(base + vfrag[(j_) / DT] + ((j_) % DT) * 32 * 128)
+  constexpr int NS = 2 * KS;     // MFMAs of the first product per tile
+  constexpr int NP = 4 * DT;     // MFMAs of the second product per tile
+  int cur = 0;
+  for (int t = 0; t < nt; ++t) {
+    if (t + 1 < nt) DVD_GLDS_ISSUE(t + 1, cur ^ 1)
+    const char* base = smem + cur * BUF;
+    half8 fr[8];
+    floatx16 s[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) s[kb][i] = 0.f;
+    KLOAD(0); KLOAD(1); KLOAD(2); KLOAD(3);
+    SB();
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+      s[i / KS] = mfma32_f16(fr[i & 7], qf[i % KS], s[i / KS]);
+      if (i + 4 < NS) { KLOAD(i + 4); } else { VLOAD(i + 4 - NS); }
+      SB();
+    }
+
+    float mx = -1e30f;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) mx = fmaxf(mx, s[kb][i]);
+    mx *= p.c;
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    if (__any(mx - m_run > RESCALE_THR)) {     // deferred rescale, see flash_attn_kernel
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      m_run = m_new;
+      l_run *= alpha;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o[dt][i] *= alpha;
+    }
+    float rs = 0.f;
+    half8 pf[4];
+    // chunk c of P = registers 8 (c & 1) .. +7 of s[c >> 1]
+#define PEXP(c_, e_)                                                                             \
+  {                                                                                              \
+    const float pv_ = __builtin_amdgcn_exp2f(fmaf(s[(c_) >> 1][8 * ((c_) & 1) + (e_)], p.c, -m_run)); \
+    rs += pv_;                                                                                   \
+    pf[c_][e_] = (_Float16)pv_;                                                                  \
+  }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) PEXP(0, e)
+    SB();
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+      const int c = j / DT, dt = j % DT;
+      o[dt] = mfma32_f16(fr[j & 7], pf[c], o[dt]);
+      if (j + 4 < NP) VLOAD(j + 4);
+      if (c < 3) {                          // P chunk c+1: DT MFMA gaps for 8 elements
+        constexpr int per = (8 + DT - 1) / DT;
+#pragma unroll
+        for (int e = dt * per; e < (dt + 1) * per && e < 8; ++e) PEXP(c + 1, e)
+      }
+      SB();
+    }
+    l_run += rs;
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next tile has landed (this wave's loads) ...
+    __syncthreads();                                   // ... and everyone's; also: all reads of `cur` are done
+    cur ^= 1;
+  }
+#undef SB
+#undef KLOAD
+#undef VLOAD
+#undef PEXP
+
+  const float l_tot = l_run + __shfl_xor(l_run, 32);
+  const float inv = 1.f / l_tot;
+  const int qglob = qb * 128 + wave * 32 + r;
+  if (qglob < p.tq) {
+    _Float16* op = p.O + b * p.sO + (size_t)qglob * p.ldo + (size_t)head * D;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        half4 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = (_Float16)(o[dt][4 * g4 + j] * inv);
+        *(half4*)(op + 32 * dt + 8 * g4 + 4 * h) = v;
+      }
+  }
+}
+
 }  // namespace dvd
 
 using namespace dvd;
@@ -268,7 +508,19 @@ extern "C" int dvd_flash_attn(const dvd_attn_desc* d, void* stream) {
   p.c = d->scale * 1.4426950408889634f;
   const long nwg = (long)p.nqb * d->heads * d->batch;
   DVD_REQUIRE(nwg < (1l << 31), "flash_attn: grid too large");
-  if (d->head_dim == 256) {
+  const bool fast = (d->tk % 64 == 0) && !getenv("DVD_ATTN_V1");
+  if (fast && d->head_dim == 256) {
+    constexpr int LDS = 2 * (64 * 512 + 256 * 128);
+    static bool once2 = false;
+    if (!once2) {
+      (void)hipFuncSetAttribute((const void*)flash_attn_glds_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+      once2 = true;
+    }
+    flash_attn_glds_kernel<256><<<(unsigned)nwg, 256, LDS, (hipStream_t)stream>>>(p);
+  } else if (fast) {
+    constexpr int LDS = 2 * (64 * 128 + 64 * 128);
+    flash_attn_glds_kernel<64><<<(unsigned)nwg, 256, LDS, (hipStream_t)stream>>>(p);
+  } else if (d->head_dim == 256) {
     constexpr int LDS = 2 * (64 * (2 * 256 + 16) + 256 * (2 * 64 + 16));
     static bool once = false;
     if (!once) {

@@ -1,0 +1,91 @@
+"""Per-document driver of the sampling path - mirror of train_settings/dvd/evaluation.py
+(`run_sample_lr_dewarping` :80-138, the tail of `run_evaluation_docunet` :245-306) on the HIP engine.
+
+The pre-stage conditioning nets (evaluation.py:162-216) are outside this path: documents arrive
+as dicts of conditioning tensors (synthetic or loaded from .npz), i.e. exactly the tensors those nets produce."""
+from __future__ import annotations
+
+import os
+import time
+
+import numpy as np
+import torch as th
+
+from . import ops, synth
+
+
+def run_sample_lr_dewarping(settings, logger, diffusion, model, source, feature_size, init_flow, doc_mask,
+                            seg_map_all=None, textline_map=None, init_feat=None):
+    """One batch of documents through the sampler (evaluation.py:80-138): returns the clamped flow [B,2,G,G]."""
+    kw = {"init_flow": init_flow, "src_feat": None, "src_64": None, "y512": source, "tmode": settings.env.train_mode,
+          "mask_cat": doc_mask, "init_feat": init_feat, "iter": settings.env.iter}
+    if not settings.env.use_gt_mask:
+        kw["mask_y512"] = seg_map_all
+    if settings.env.use_line_mask:
+        kw["line_msk"] = textline_map
+    logger.info("\nStarting sampling")
+    B = source.shape[0]
+    sample, _ = diffusion.ddim_sample_loop(
+        model, (B, 2, feature_size, feature_size), noise=None, clip_denoised=settings.env.clip_denoised,
+        model_kwargs=kw, eta=0.0, progress=True, denoised_fn=None, sampling_kwargs={"src_img": source}, logger=logger,
+        n_batch=settings.env.n_batch, time_variant=settings.env.time_variant, pyramid=None,
+        sampler_kind=getattr(settings.env, "sampler", "ddim"))
+    return th.clamp(sample, min=-1, max=1)
+
+
+def synthetic_documents(settings, indices):
+    G = settings.env.grid_size
+    for i in indices:
+        d = synth.synth_document(i, G, seed=1234, full_res=tuple(settings.env.full_res))
+        d["path"] = f"synthetic_{i:05d}"
+        yield d
+
+
+def npz_documents(settings, indices, files):
+    for i in indices:
+        z = np.load(files[i])
+        d = {k: z[k] for k in ("y512", "mask_cat", "mask_y512", "line_msk", "src_u8")}
+        d["path"] = os.path.splitext(os.path.basename(files[i]))[0]
+        yield d
+
+
+def run_evaluation_docunet(settings, logger, documents, diffusion, model, device):
+    """Document loop (evaluation.py:142-327): batches `batch_docs` documents, samples, unwarps the full-resolution
+    u8 source with the fused HIP kernel and (if env.visualize) writes PNGs where the reference writes them."""
+    env = settings.env
+    out_dir = f"vis_hp/{env.eval_dataset_name}/{settings.name}/dewarped_pred"
+    if env.visualize:
+        os.makedirs(out_dir, exist_ok=True)
+    G, B = env.grid_size, env.batch_docs
+    times, results, batch = [], [], []
+
+    def flush():
+        if not batch:
+            return
+        nb = len(batch)
+        stack = lambda k: th.from_numpy(np.stack([d[k] for d in batch])).to(device)  # noqa: E731
+        t0 = time.time()
+        model_docs = nb
+        src, msk, seg, line = stack("y512"), stack("mask_cat"), stack("mask_y512"), stack("line_msk")
+        flow = run_sample_lr_dewarping(settings, logger, diffusion, model, src, G,
+                                       th.zeros(nb, 2, G, G, device=device), msk, seg, line,
+                                       th.zeros(nb, 256, G, G, device=device))
+        th.cuda.synchronize()
+        times.append((time.time() - t0) / model_docs)
+        for j, d in enumerate(batch):
+            out = ops.unwarp_u8(flow[j:j + 1].contiguous(), th.from_numpy(d["src_u8"]).to(device))   # :301-306 + viz :75-77
+            results.append((d["path"], out))
+            if env.visualize:
+                from PIL import Image
+                Image.fromarray(out.cpu().numpy()).save(os.path.join(out_dir, f"warped_{d['path']}.png"))
+        batch.clear()
+
+    for d in documents:
+        batch.append(d)
+        if len(batch) == B:
+            flush()
+    flush()
+    if times:
+        print(len(times))
+        print("Elapsed time:{:.2f} avg_second ".format(sum(times) / len(times)))
+    return results
