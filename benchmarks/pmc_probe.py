@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Runs one launch-heavy op a few times so rocprofv3 --pmc can attribute counters to it.
+usage: pmc_probe.py gemm|attn256|attn64|unwarp"""
+import os
+import sys
+
+sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
+import torch  # noqa: E402
+
+from dvd_amd import ops, synth  # noqa: E402
+
+which = sys.argv[1]
+if which == "gemm":
+    M, N, K = 331776, 1536, 1536
+    a = torch.randn(M, K, device="cuda").half()
+    b = torch.randn(N, K, device="cuda").half()
+    out = torch.empty(M, N, dtype=torch.float16, device="cuda")
+    for _ in range(3):
+        ops.gemm_nt(a, b, out16=out)
+elif which in ("attn256", "attn64"):
+    hd = 256 if which == "attn256" else 64
+    B, T = (2, 20736) if hd == 256 else (8, 20736)
+    C = 6 * hd
+    qk = torch.randn(B, T, 2 * C, device="cuda").half()
+    vt = torch.randn(B, C, T, device="cuda").half()
+    out = torch.empty(B, T, C, dtype=torch.float16, device="cuda")
+    for _ in range(3):
+        ops.flash_attn(qk[:, :, :C], qk[:, :, C:], vt, out, 6, hd, 1.0 / (hd ** 0.5))
+elif which == "unwarp":
+    H, W, G = 3508, 2480, 288
+    ctrl = torch.from_numpy(synth.uniform("b/flow", (1, 2, 6, 6), -0.05, 0.05, 1))
+    flow = torch.nn.functional.interpolate(ctrl, size=(G, G), mode="bicubic", align_corners=True).contiguous().cuda()
+    src8 = torch.randint(0, 256, (H, W, 3), device="cuda", dtype=torch.uint8)
+    srcf = src8.permute(2, 0, 1)[None].float().contiguous()
+    grid = ops.unwarp_grid(flow, H, W)
+    for _ in range(3):
+        ops.unwarp_f32(flow, srcf)
+        ops.unwarp_u8(flow, src8)
+        ops.grid_sample(srcf, grid)
+torch.cuda.synchronize()

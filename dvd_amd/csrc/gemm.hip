@@ -94,7 +94,70 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(GemmArgs p) {
     gal[i] = Alo ? Alo + (size_t)ra * p.lda + ch * EPC : ga[i];
     lofs[i] = row * LROW + ch * 16;
   }
-  u32x4 ra_[NLD], rb_[NLD];
+  // Split weights: the low parts are accumulated FIRST, the accumulator is scaled by lo_scale (a power of
+  // two: exact), then the high parts are added -> one accumulator, fp32-grade weights at 2x the MFMAs.
+  const int nkk = p.K / BK;
+  const int nlo = (Blo || Alo) ? nkk : 0;
+  const int nk = nkk + nlo;
+
+  // Register-staged prefetch, TWO K-tiles deep: tile j waits in register set (j & 1) for two full iterations
+  // before it is written to LDS, so a global load has ~2 x (16 MFMA x 2 waves) of matrix time to land.  With
+  // one-tile-deep staging every iteration stalled on L2/HBM latency (2 workgroups per CU cannot hide it).
+  u32x4 ra0[NLD], rb0[NLD], ra1[NLD], rb1[NLD];
+#define DVD_GLOAD(RA, RB, t_)                                                    \
+  {                                                                              \
+    const int tt_ = (t_);                                                        \
+    const bool lo_ = tt_ < nlo;                                                  \
+    const size_t kofs_ = (size_t)(lo_ ? tt_ : tt_ - nlo) * BK;                   \
+    _Pragma("unroll") for (int i = 0; i < NLD; ++i) {                            \
+      RA[i] = *(const u32x4*)((lo_ ? gal[i] : ga[i]) + kofs_);                   \
+      RB[i] = *(const u32x4*)((lo_ ? gbl[i] : gb[i]) + kofs_);                   \
+    }                                                                            \
+  }
+#define DVD_LSTORE(RA, RB, buf_)                                                 \
+  _Pragma("unroll") for (int i = 0; i < NLD; ++i) {                              \
+    *(u32x4*)(&smem[buf_][0][lofs[i]]) = RA[i];                                  \
+    *(u32x4*)(&smem[buf_][1][lofs[i]]) = RB[i];                                  \
+  }
+#define DVD_COMPUTE(buf_)                                                                          \
+  {                                                                                                \
+    const char* sa = &smem[buf_][0][(64 * wr + r) * LROW];                                         \
+    const char* sb = &smem[buf_][1][(64 * wc + r) * LROW];                                         \
+    if constexpr (!F32) {                                                                          \
+      _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                              \
+        half8 a[2], b[2];                                                                          \
+        _Pragma("unroll") for (int m = 0; m < 2; ++m)                                              \
+          a[m] = *(const half8*)(sa + m * 32 * LROW + (16 * s + 8 * h) * 2);                       \
+        _Pragma("unroll") for (int n = 0; n < 2; ++n)                                              \
+          b[n] = *(const half8*)(sb + n * 32 * LROW + (16 * s + 8 * h) * 2);                       \
+        _Pragma("unroll") for (int m = 0; m < 2; ++m)                                              \
+          _Pragma("unroll") for (int n = 0; n < 2; ++n) acc[m][n] = mfma32_f16(a[m], b[n], acc[m][n]); \
+      }                                                                                            \
+    } else {                                                                                       \
+      /* lane-half h owns k = 8h .. 8h+7 of the 16-deep step (any k assignment is valid if A and B agree) */ \
+      float a[2][8], b[2][8];                                                                      \
+      _Pragma("unroll") for (int m = 0; m < 2; ++m) {                                              \
+        const floatx4 lo = *(const floatx4*)(sa + m * 32 * LROW + 32 * h);                         \
+        const floatx4 hi = *(const floatx4*)(sa + m * 32 * LROW + 32 * h + 16);                    \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e) { a[m][e] = lo[e]; a[m][4 + e] = hi[e]; }     \
+      }                                                                                            \
+      _Pragma("unroll") for (int n = 0; n < 2; ++n) {                                              \
+        const floatx4 lo = *(const floatx4*)(sb + n * 32 * LROW + 32 * h);                         \
+        const floatx4 hi = *(const floatx4*)(sb + n * 32 * LROW + 32 * h + 16);                    \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e) { b[n][e] = lo[e]; b[n][4 + e] = hi[e]; }     \
+      }                                                                                            \
+      _Pragma("unroll") for (int s = 0; s < 8; ++s)                                                \
+        _Pragma("unroll") for (int m = 0; m < 2; ++m)                                              \
+          _Pragma("unroll") for (int n = 0; n < 2; ++n) acc[m][n] = mfma32_f32(a[m][s], b[n][s], acc[m][n]); \
+    }                                                                                              \
+  }
+#define DVD_LOSCALE(kt_)                                                                           \
+  if (nlo && (kt_) == nlo - 1) {                                                                   \
+    _Pragma("unroll") for (int m = 0; m < 2; ++m)                                                  \
+      _Pragma("unroll") for (int n = 0; n < 2; ++n)                                                \
+        _Pragma("unroll") for (int i = 0; i < 16; ++i) acc[m][n][i] *= p.lo_scale;                 \
+  }
+
   floatx16 acc[2][2];
 #pragma unroll
   for (int m = 0; m < 2; ++m)
@@ -103,92 +166,39 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(GemmArgs p) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[m][n][i] = 0.f;
 
-  // Split weights: the low parts are accumulated FIRST, the accumulator is scaled by lo_scale (a power of
-  // two: exact), then the high parts are added -> one accumulator, fp32-grade weights at 2x the MFMAs.
-  const int nkk = p.K / BK;
-  const int nlo = (Blo || Alo) ? nkk : 0;
-  const int nk = nkk + nlo;
-#pragma unroll
-  for (int i = 0; i < NLD; ++i) {
-    ra_[i] = *(const u32x4*)(nlo ? gal[i] : ga[i]);
-    rb_[i] = *(const u32x4*)(nlo ? gbl[i] : gb[i]);
-  }
-#pragma unroll
-  for (int i = 0; i < NLD; ++i) {
-    *(u32x4*)(&smem[0][0][lofs[i]]) = ra_[i];
-    *(u32x4*)(&smem[0][1][lofs[i]]) = rb_[i];
-  }
+  // Loads and LDS stores are issued UNCONDITIONALLY (tile index clamped to the last tile: a couple of
+  // redundant tile loads per workgroup) so that the number of loads in flight is the same on every path and
+  // hipcc can emit the counted vmcnt(8) that lets the younger register set stay in flight across the store.
+  const int last = nk - 1;
+  DVD_GLOAD(ra0, rb0, 0)
+  DVD_GLOAD(ra1, rb1, min(1, last))
+  DVD_LSTORE(ra0, rb0, 0)
   __syncthreads();
-  int cur = 0;
-  for (int kt = 0; kt < nk; ++kt) {
-    const bool more = kt + 1 < nk;
-    if (more) {
-      const int tn = kt + 1;
-      const bool lo = tn < nlo;
-      const size_t kofs = (size_t)(lo ? tn : tn - nlo) * BK;
-#pragma unroll
-      for (int i = 0; i < NLD; ++i) {
-        ra_[i] = *(const u32x4*)((lo ? gal[i] : ga[i]) + kofs);
-        rb_[i] = *(const u32x4*)((lo ? gbl[i] : gb[i]) + kofs);
-      }
-    }
-    const char* sa = &smem[cur][0][(64 * wr + r) * LROW];
-    const char* sb = &smem[cur][1][(64 * wc + r) * LROW];
-    if constexpr (!F32) {
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        half8 a[2], b[2];
-#pragma unroll
-        for (int m = 0; m < 2; ++m) a[m] = *(const half8*)(sa + m * 32 * LROW + (16 * s + 8 * h) * 2);
-#pragma unroll
-        for (int n = 0; n < 2; ++n) b[n] = *(const half8*)(sb + n * 32 * LROW + (16 * s + 8 * h) * 2);
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-          for (int n = 0; n < 2; ++n) acc[m][n] = mfma32_f16(a[m], b[n], acc[m][n]);
-      }
-    } else {
-      // lane-half h owns k = 8h .. 8h+7 of the 16-deep step (any k assignment is valid as long as A and B agree)
-      float a[2][8], b[2][8];
-#pragma unroll
-      for (int m = 0; m < 2; ++m) {
-        const float4 lo = *(const float4*)(sa + m * 32 * LROW + 32 * h);
-        const float4 hi = *(const float4*)(sa + m * 32 * LROW + 32 * h + 16);
-        a[m][0] = lo.x; a[m][1] = lo.y; a[m][2] = lo.z; a[m][3] = lo.w;
-        a[m][4] = hi.x; a[m][5] = hi.y; a[m][6] = hi.z; a[m][7] = hi.w;
-      }
-#pragma unroll
-      for (int n = 0; n < 2; ++n) {
-        const float4 lo = *(const float4*)(sb + n * 32 * LROW + 32 * h);
-        const float4 hi = *(const float4*)(sb + n * 32 * LROW + 32 * h + 16);
-        b[n][0] = lo.x; b[n][1] = lo.y; b[n][2] = lo.z; b[n][3] = lo.w;
-        b[n][4] = hi.x; b[n][5] = hi.y; b[n][6] = hi.z; b[n][7] = hi.w;
-      }
-#pragma unroll
-      for (int s = 0; s < 8; ++s)
-#pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-          for (int n = 0; n < 2; ++n) acc[m][n] = mfma32_f32(a[m][s], b[n][s], acc[m][n]);
-    }
-    if (nlo && kt == nlo - 1) {
-#pragma unroll
-      for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int n = 0; n < 2; ++n)
-#pragma unroll
-          for (int i = 0; i < 16; ++i) acc[m][n][i] *= p.lo_scale;
-    }
-    if (more) {
-#pragma unroll
-      for (int i = 0; i < NLD; ++i) {
-        *(u32x4*)(&smem[cur ^ 1][0][lofs[i]]) = ra_[i];
-        *(u32x4*)(&smem[cur ^ 1][1][lofs[i]]) = rb_[i];
-      }
-    }
+  DVD_GLOAD(ra0, rb0, min(2, last))
+  const int pairs = nk >> 1;
+  for (int pp = 0; pp < pairs; ++pp) {
+    const int kt = 2 * pp;
+    // even step: tile kt is in LDS[0]; tile kt+1 waits in set 1, tile kt+2 in set 0
+    DVD_COMPUTE(0)
+    DVD_LOSCALE(kt)
+    DVD_LSTORE(ra1, rb1, 1)
     __syncthreads();
-    cur ^= 1;
+    DVD_GLOAD(ra1, rb1, min(kt + 3, last))
+    // odd step: tile kt+1 is in LDS[1]
+    DVD_COMPUTE(1)
+    DVD_LOSCALE(kt + 1)
+    DVD_LSTORE(ra0, rb0, 0)
+    __syncthreads();
+    DVD_GLOAD(ra0, rb0, min(kt + 4, last))
   }
+  if (nk & 1) {   // odd tile count (no split weights): the last tile is already in LDS[0]
+    DVD_COMPUTE(0)
+    DVD_LOSCALE(nk - 1)
+  }
+#undef DVD_GLOAD
+#undef DVD_LSTORE
+#undef DVD_COMPUTE
+#undef DVD_LOSCALE
 
   // ---------------- epilogue ----------------
   float* C32 = p.C32 ? p.C32 + z * p.sC32 : nullptr;

@@ -5,70 +5,86 @@
 // All of these are HBM/L2-bound gathers: one lane per output pixel along x so that the grid
 // reads, the taps of a smooth warp and the stores of a wave are contiguous runs.
 #include "common.h"
+#include "mfma.h"
 
 namespace dvd {
 
 // Unnormalise with align_corners=True: ((g + 1) / 2) * (size - 1)
 __device__ __forceinline__ float unnorm(float g, int size) { return ((g + 1.f) * 0.5f) * (float)(size - 1); }
 
+// Branch-free bilinear taps (zeros padding): out-of-range taps get weight 0 and a clamped (always valid)
+// address, so all four loads of a pixel issue unconditionally and back-to-back.
 struct Taps {
-  int x0, y0;
-  float wnw, wne, wsw, wse;
-  bool x0ok, x1ok, y0ok, y1ok;
+  int o00, o01, o10, o11;      // element offsets (row * pitch + col) of the four taps, clamped in range
+  float w00, w01, w10, w11;
 };
 
-__device__ __forceinline__ Taps make_taps(float gx, float gy, int hin, int win) {
+__device__ __forceinline__ Taps make_taps(float gx, float gy, int hin, int win, int pitch) {
   Taps t;
-  float ix = unnorm(gx, win), iy = unnorm(gy, hin);
+  const float ix = unnorm(gx, win), iy = unnorm(gy, hin);
   float fx = floorf(ix), fy = floorf(iy);
-  float ex = fx + 1.f, ey = fy + 1.f;
-  t.wnw = (ex - ix) * (ey - iy);
-  t.wne = (ix - fx) * (ey - iy);
-  t.wsw = (ex - ix) * (iy - fy);
-  t.wse = (ix - fx) * (iy - fy);
+  const float ex = fx + 1.f, ey = fy + 1.f;
+  float w00 = (ex - ix) * (ey - iy), w01 = (ix - fx) * (ey - iy);
+  float w10 = (ex - ix) * (iy - fy), w11 = (ix - fx) * (iy - fy);
   // keep the int conversion safe for wild / non-finite coordinates
   fx = fminf(fmaxf(fx, -2.f), (float)win);
   fy = fminf(fmaxf(fy, -2.f), (float)hin);
   if (!(ix == ix)) fx = -2.f;
   if (!(iy == iy)) fy = -2.f;
-  t.x0 = (int)fx;
-  t.y0 = (int)fy;
-  t.x0ok = t.x0 >= 0 && t.x0 < win;
-  t.x1ok = t.x0 + 1 >= 0 && t.x0 + 1 < win;
-  t.y0ok = t.y0 >= 0 && t.y0 < hin;
-  t.y1ok = t.y0 + 1 >= 0 && t.y0 + 1 < hin;
+  const int x0 = (int)fx, y0 = (int)fy;
+  const bool x0ok = x0 >= 0 && x0 < win, x1ok = x0 + 1 >= 0 && x0 + 1 < win;
+  const bool y0ok = y0 >= 0 && y0 < hin, y1ok = y0 + 1 >= 0 && y0 + 1 < hin;
+  t.w00 = (x0ok && y0ok) ? w00 : 0.f;
+  t.w01 = (x1ok && y0ok) ? w01 : 0.f;
+  t.w10 = (x0ok && y1ok) ? w10 : 0.f;
+  t.w11 = (x1ok && y1ok) ? w11 : 0.f;
+  const int xc0 = min(max(x0, 0), win - 1), xc1 = min(max(x0 + 1, 0), win - 1);
+  const int yc0 = min(max(y0, 0), hin - 1), yc1 = min(max(y0 + 1, 0), hin - 1);
+  t.o00 = yc0 * pitch + xc0;
+  t.o01 = yc0 * pitch + xc1;
+  t.o10 = yc1 * pitch + xc0;
+  t.o11 = yc1 * pitch + xc1;
   return t;
 }
 
+constexpr int PX = 4;   // output pixels per thread: PX consecutive ROWS at one x.  A wave-instruction then still
+                        // reads/writes one contiguous run (1 px per lane) while 4x as many loads are in flight,
+                        // and vertically adjacent pixels share their tap rows in L1.
+
 // ---------------------------------------------------------------------------------------
-// Drop-in grid_sample, NCHW f32.  One thread per (n, y, x); loops channels (planes are
-// hin*win apart, so each tap instruction of a wave reads one contiguous-ish run per plane).
+// Drop-in grid_sample, NCHW f32.  One thread per (n, 4 y's, x).
 // ---------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) grid_sample_nchw_kernel(const float* __restrict__ src,
                                                                const float* __restrict__ grid,
                                                                float* __restrict__ out, int c, int hin, int win,
                                                                int h, int w, int src_batch_div) {
   const int n = blockIdx.z;
-  const int y = blockIdx.y;
+  const int y0 = blockIdx.y * PX;
   const int x = blockIdx.x * blockDim.x + threadIdx.x;
   if (x >= w) return;
   const size_t hw = (size_t)h * w;
-  const float* g = grid + (size_t)n * 2 * hw + (size_t)y * w + x;
-  Taps t = make_taps(g[0], g[hw], hin, win);
+  const float* g = grid + (size_t)n * 2 * hw + x;
+  Taps t[PX];
+#pragma unroll
+  for (int k = 0; k < PX; ++k) {
+    const int yy = min(y0 + k, h - 1);
+    t[k] = make_taps(g[(size_t)yy * w], g[hw + (size_t)yy * w], hin, win, win);
+  }
   const size_t plane = (size_t)hin * win;
   const float* s = src + (size_t)(n / src_batch_div) * c * plane;
-  float* o = out + (size_t)n * c * hw + (size_t)y * w + x;
-  const long r0 = (long)t.y0 * win + t.x0;
-  const bool nw = t.x0ok && t.y0ok, ne = t.x1ok && t.y0ok, sw = t.x0ok && t.y1ok, se = t.x1ok && t.y1ok;
-#pragma unroll 4
+  float* o = out + (size_t)n * c * hw + x;
   for (int ch = 0; ch < c; ++ch) {
-    const float* p = s + (size_t)ch * plane + r0;
-    float acc = 0.f;
-    if (nw) acc += p[0] * t.wnw;
-    if (ne) acc += p[1] * t.wne;
-    if (sw) acc += p[win] * t.wsw;
-    if (se) acc += p[win + 1] * t.wse;
-    o[(size_t)ch * hw] = acc;
+    const float* p = s + (size_t)ch * plane;
+    float v[PX][4];
+#pragma unroll
+    for (int k = 0; k < PX; ++k) {
+      v[k][0] = p[t[k].o00]; v[k][1] = p[t[k].o01]; v[k][2] = p[t[k].o10]; v[k][3] = p[t[k].o11];
+    }
+#pragma unroll
+    for (int k = 0; k < PX; ++k)
+      if (y0 + k < h)
+        o[(size_t)ch * hw + (size_t)(y0 + k) * w] =
+            ((v[k][0] * t[k].w00 + v[k][1] * t[k].w01) + v[k][2] * t[k].w10) + v[k][3] * t[k].w11;
   }
 }
 
@@ -120,54 +136,69 @@ __global__ void __launch_bounds__(256) unwarp_grid_kernel(const float* __restric
 __global__ void __launch_bounds__(256) unwarp_f32_kernel(const float* __restrict__ flow,
                                                          const float* __restrict__ src, float* __restrict__ out,
                                                          UpParams p) {
-  const int i = blockIdx.y;
+  const int i0 = blockIdx.y * PX;
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= p.w) return;
-  float gx, gy;
-  flow_grid_at(flow, p, i, j, gx, gy);
-  Taps t = make_taps(gx, gy, p.h, p.w);
+  Taps t[PX];
+#pragma unroll
+  for (int k = 0; k < PX; ++k) {
+    float gx, gy;
+    flow_grid_at(flow, p, min(i0 + k, p.h - 1), j, gx, gy);
+    t[k] = make_taps(gx, gy, p.h, p.w, p.w);
+  }
   const size_t plane = (size_t)p.h * p.w;
-  const long r0 = (long)t.y0 * p.w + t.x0;
-  const bool nw = t.x0ok && t.y0ok, ne = t.x1ok && t.y0ok, sw = t.x0ok && t.y1ok, se = t.x1ok && t.y1ok;
-  float acc[3];
+  float v[3][PX][4];
 #pragma unroll
   for (int ch = 0; ch < 3; ++ch) {
-    const float* q = src + (size_t)ch * plane + r0;
-    float a = 0.f;
-    if (nw) a += q[0] * t.wnw;
-    if (ne) a += q[1] * t.wne;
-    if (sw) a += q[p.w] * t.wsw;
-    if (se) a += q[p.w + 1] * t.wse;
-    acc[ch] = a;
+    const float* q = src + (size_t)ch * plane;
+#pragma unroll
+    for (int k = 0; k < PX; ++k) {
+      v[ch][k][0] = q[t[k].o00]; v[ch][k][1] = q[t[k].o01]; v[ch][k][2] = q[t[k].o10]; v[ch][k][3] = q[t[k].o11];
+    }
   }
-  float* o = out + ((size_t)i * p.w + j) * 3;
-  o[0] = acc[0];
-  o[1] = acc[1];
-  o[2] = acc[2];
+#pragma unroll
+  for (int k = 0; k < PX; ++k) {
+    if (i0 + k >= p.h) break;
+    float* o = out + ((size_t)(i0 + k) * p.w + j) * 3;
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch)
+      o[ch] = ((v[ch][k][0] * t[k].w00 + v[ch][k][1] * t[k].w01) + v[ch][k][2] * t[k].w10) + v[ch][k][3] * t[k].w11;
+  }
 }
 
 __global__ void __launch_bounds__(256) unwarp_u8_kernel(const float* __restrict__ flow,
                                                         const uint8_t* __restrict__ src, uint8_t* __restrict__ out,
                                                         UpParams p) {
-  const int i = blockIdx.y;
+  const int i0 = blockIdx.y * PX;
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= p.w) return;
-  float gx, gy;
-  flow_grid_at(flow, p, i, j, gx, gy);
-  Taps t = make_taps(gx, gy, p.h, p.w);
-  const long r0 = ((long)t.y0 * p.w + t.x0) * 3;
-  const long rs = (long)p.w * 3;
-  const bool nw = t.x0ok && t.y0ok, ne = t.x1ok && t.y0ok, sw = t.x0ok && t.y1ok, se = t.x1ok && t.y1ok;
-  uint8_t* o = out + ((size_t)i * p.w + j) * 3;
+  Taps t[PX];
 #pragma unroll
-  for (int ch = 0; ch < 3; ++ch) {
-    const uint8_t* q = src + r0 + ch;
-    float a = 0.f;
-    if (nw) a += (float)q[0] * t.wnw;
-    if (ne) a += (float)q[3] * t.wne;
-    if (sw) a += (float)q[rs] * t.wsw;
-    if (se) a += (float)q[rs + 3] * t.wse;
-    o[ch] = (uint8_t)(int)a;   // truncation, as numpy .astype(uint8) for 0 <= a < 256
+  for (int k = 0; k < PX; ++k) {
+    float gx, gy;
+    flow_grid_at(flow, p, min(i0 + k, p.h - 1), j, gx, gy);
+    t[k] = make_taps(gx, gy, p.h, p.w, p.w);
+  }
+  uint8_t v[PX][4][3];
+#pragma unroll
+  for (int k = 0; k < PX; ++k) {
+    const int offs[4] = {t[k].o00, t[k].o01, t[k].o10, t[k].o11};
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const uint8_t* q = src + (size_t)offs[a] * 3;
+      v[k][a][0] = q[0]; v[k][a][1] = q[1]; v[k][a][2] = q[2];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < PX; ++k) {
+    if (i0 + k >= p.h) break;
+    uint8_t* o = out + ((size_t)(i0 + k) * p.w + j) * 3;
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+      const float a = (((float)v[k][0][ch] * t[k].w00 + (float)v[k][1][ch] * t[k].w01) +
+                       (float)v[k][2][ch] * t[k].w10) + (float)v[k][3][ch] * t[k].w11;
+      o[ch] = (uint8_t)(int)a;   // truncation, as numpy .astype(uint8) for 0 <= a < 256
+    }
   }
 }
 
@@ -195,8 +226,9 @@ extern "C" int dvd_grid_sample_bilinear_zeros_ac(const float* src, const float* 
               "grid_sample: bad shape n=%d c=%d in=%dx%d out=%dx%d", n, c, hin, win, h, w);
   if (n == 0) return DVD_OK;
   DVD_REQUIRE(h <= 65535 && n <= 65535, "grid_sample: h or n exceeds the 65535 grid limit");
+  DVD_REQUIRE(cdiv(h, 4) <= 65535, "grid_sample: h too large");
   const int bx = w >= 256 ? 256 : (w > 64 ? 128 : 64);
-  dim3 grd(cdiv(w, bx), h, n);
+  dim3 grd(cdiv(w, bx), cdiv(h, 4), n);
   grid_sample_nchw_kernel<<<grd, bx, 0, (hipStream_t)stream>>>(src, grid, out, c, hin, win, h, w, src_batch_div);
   return check_launch("grid_sample");
 }
@@ -218,7 +250,7 @@ extern "C" int dvd_unwarp_grid(const float* flow, int g, float* grid_out, int h,
 extern "C" int dvd_unwarp_f32(const float* flow, int g, const float* src_chw, float* out_hwc, int h, int w,
                               float scale, void* stream) {
   if (int e = unwarp_args(flow, src_chw, out_hwc, g, h, w)) return e;
-  dim3 grd(cdiv(w, 256), h);
+  dim3 grd(cdiv(w, 256), cdiv(h, 4));
   unwarp_f32_kernel<<<grd, 256, 0, (hipStream_t)stream>>>(flow, src_chw, out_hwc, make_up(g, h, w, scale));
   return check_launch("unwarp_f32");
 }
@@ -226,7 +258,7 @@ extern "C" int dvd_unwarp_f32(const float* flow, int g, const float* src_chw, fl
 extern "C" int dvd_unwarp_u8(const float* flow, int g, const uint8_t* src_hwc, uint8_t* out_hwc, int h, int w,
                              float scale, void* stream) {
   if (int e = unwarp_args(flow, src_hwc, out_hwc, g, h, w)) return e;
-  dim3 grd(cdiv(w, 256), h);
+  dim3 grd(cdiv(w, 256), cdiv(h, 4));
   unwarp_u8_kernel<<<grd, 256, 0, (hipStream_t)stream>>>(flow, src_hwc, out_hwc, make_up(g, h, w, scale));
   return check_launch("unwarp_u8");
 }
