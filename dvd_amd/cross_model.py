@@ -40,8 +40,8 @@ class DvdDenoiser(nn.Module):
     # ---- checkpoint-compatible state dict (keys with dots, as in model1852000.pt) --------------------
     def state_dict(self, *args, **kwargs):
         sd = super().state_dict(*args, **kwargs)
-        inv = {v: k for k, v in self._names.items()}
-        return type(sd)((inv.get(k, k), v) for k, v in sd.items())
+        # checkpoint key names, in the reference module's own order (parameters and buffers interleaved)
+        return type(sd)((key, sd[flat]) for key, flat in self._names.items() if flat in sd)
 
     def load_state_dict(self, state_dict, strict=True, **kw):
         mapped = {self._names[k]: v for k, v in state_dict.items() if k in self._names}

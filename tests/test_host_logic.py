@@ -1,0 +1,179 @@
+"""CPU tests of the host-side logic: schedule tables vs the reference's golden tables, the timestep rules,
+the weight packer <-> engine tensor contract (the engine's tensor table is host code and needs no GPU),
+BatchNorm folding, f16 hi/lo weight splitting, the checkpoint-compatible module, and the plug-in surface."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from dvd_amd import lib, schedule, synth, weights
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+@pytest.mark.parametrize("S", [3, 10, 50, 250])
+def test_tables_bit_identical_to_reference(S):
+    g = np.load(os.path.join(GOLD, "schedule.npz"))
+    t = schedule.Tables(schedule.named_betas("cosine", S))
+    for name in ("betas", "alphas_cumprod", "alphas_cumprod_prev", "sqrt_recip_alphas_cumprod",
+                 "sqrt_recipm1_alphas_cumprod", "posterior_variance", "posterior_log_variance_clipped",
+                 "posterior_mean_coef1", "posterior_mean_coef2"):
+        assert np.array_equal(getattr(t, name), g[f"s{S}/{name}"]), name
+    assert list(t.timestep_map) == list(g[f"s{S}/timestep_map"])
+    assert np.array_equal(np.float32([t.model_time(i) for i in range(S)]), g[f"s{S}/t_model_raw"])
+    assert np.array_equal(t.fixed_large_log_variance.astype(np.float32), g[f"s{S}/fixed_large_logvar_f32"])
+
+
+def test_timestep_rules():
+    assert schedule.embedded_time(666.7) == 2.0 and schedule.embedded_time(600.0) == 600.0
+    assert schedule.embedded_time(400.0) == 1.0 and schedule.embedded_time(300.0) == 300.0
+    assert schedule.embedded_time(0.0) == 0.0
+    from dvd_amd.sampler import feat_mode_for
+    assert feat_mode_for(666.7, 2, True) == 1 and feat_mode_for(333.3, 2, False) == 2
+    assert feat_mode_for(500.0, 2, True) == 0 and feat_mode_for(2.0, 2, False) == 1 and feat_mode_for(2.0, 1, False) == 2
+    t = schedule.Tables(schedule.named_betas("cosine", 10))
+    assert [schedule.embedded_time(t.model_time(i)) for i in range(9, -1, -1)] == \
+        [2.0, 2.0, 2.0, 600.0, 1.0, 1.0, 300.0, 200.0, 100.0, 0.0]
+
+
+def test_space_timesteps_contract():
+    assert schedule.space_timesteps(10, [10]) == set(range(10))
+    assert schedule.space_timesteps(300, "10,15,20") == schedule.space_timesteps(300, [10, 15, 20])
+    assert len(schedule.space_timesteps(1000, "ddim50")) == 50
+    with pytest.raises(ValueError):
+        schedule.space_timesteps(10, [11])
+    t = schedule.Tables(schedule.named_betas("linear", 100), schedule.space_timesteps(100, [10]))
+    assert t.num_timesteps == 10 and t.original_num_steps == 100 and t.model_time(9) == 990.0
+
+
+def test_ddim_coefficients_match_torch_reference_math():
+    t = schedule.Tables(schedule.named_betas("cosine", 50))
+    for i in (0, 1, 17, 49):
+        c = t.ddim_coef(i)
+        abp = np.float32(t.alphas_cumprod_prev[i])
+        assert c.sqrt_abar_prev == np.sqrt(abp) and c.dir_coef == np.sqrt(np.float32(1) - abp)
+        assert c.sigma == 0.0 and c.kind == 0
+    assert t.ddpm_coef(0).sigma == 0.0 and t.ddpm_coef(5).sigma > 0
+
+
+def engine_specs(grid):
+    h = C.c_void_p()
+    lib.call("dvd_engine_create", grid, 1, 2, C.byref(h))
+    out = []
+    name, dt, ne = C.c_char_p(), C.c_int(), C.c_long()
+    for i in range(lib.raw().dvd_engine_tensor_count(h)):
+        lib.call("dvd_engine_tensor_info", h, i, C.byref(name), C.byref(dt), C.byref(ne))
+        out.append((name.value.decode(), dt.value, ne.value))
+    ws = lib.raw().dvd_engine_workspace_bytes(h)
+    lib.raw().dvd_engine_destroy(h)
+    return out, ws
+
+
+@pytest.mark.parametrize("grid", [16, 32])
+def test_packer_matches_engine_tensor_table(grid):
+    specs, ws = engine_specs(grid)
+    assert ws > 0
+    packed = weights.pack(synth.synth_state_dict(grid, 7, blocks=[11]), grid)
+    assert set(packed) == {n for n, _, _ in specs}
+    for name, dt, ne in specs:
+        t = packed[name]
+        assert t.dtype == (torch.float16 if dt == 1 else torch.float32), name
+        assert t.numel() == ne and t.is_contiguous(), (name, t.numel(), ne)
+
+
+def test_engine_state_errors_without_gpu():
+    h = C.c_void_p()
+    lib.call("dvd_engine_create", 16, 1, 2, C.byref(h))
+    with pytest.raises(lib.DvdError, match="no workspace"):
+        lib.call("dvd_engine_denoise_step", h, C.c_void_p(8), C.c_float(2.0), 1, C.c_void_p(8), None, C.c_void_p(8), None)
+    with pytest.raises(lib.DvdError, match="unknown tensor"):
+        lib.call("dvd_engine_set_tensor", h, b"nope", C.c_void_p(16), 4)
+    with pytest.raises(lib.DvdError, match="expects"):
+        lib.call("dvd_engine_set_tensor", h, b"obs_b", C.c_void_p(16), 5)
+    with pytest.raises(lib.DvdError):
+        lib.call("dvd_engine_create", 15, 1, 2, C.byref(C.c_void_p()))
+    lib.raw().dvd_engine_destroy(h)
+
+
+def test_bn_fold_and_split_weights():
+    grid = 16
+    sd = synth.synth_state_dict(grid, 7, blocks=[11])
+    p = weights.pack(sd, grid)
+    pre = "decoder.layer_stack.2.feed_forward.conv1."
+    x = torch.from_numpy(synth.uniform("bn/x", (2, 1536, 4, 4), -1, 1, 3))
+    conv = torch.nn.functional.conv2d(x, torch.from_numpy(sd[pre + "conv.weight"]))
+    ref = torch.nn.functional.batch_norm(conv, torch.from_numpy(sd[pre + "bn.running_mean"]),
+                                         torch.from_numpy(sd[pre + "bn.running_var"]),
+                                         torch.from_numpy(sd[pre + "bn.weight"]), torch.from_numpy(sd[pre + "bn.bias"]),
+                                         False, 0.0, 1e-5)
+    w = p["d2_c1w16"].float() + p["d2_c1w16_lo"].float() / 2048.0
+    got = torch.einsum("oc,nchw->nohw", w, x) + p["d2_c1b"][None, :, None, None]
+    assert (got - ref).abs().max() < 2e-5
+    # the split reconstructs the fp32 weight ~2^11 times better than a single f16
+    hi_only = torch.einsum("oc,nchw->nohw", p["d2_c1w16"].float(), x) + p["d2_c1b"][None, :, None, None]
+    assert (hi_only - ref).abs().max() > 20 * (got - ref).abs().max()
+
+
+def test_patch_weight_layout():
+    """K order of the patch-embed GEMM operand is (p*2+q)*C + c."""
+    grid = 16
+    sd = synth.synth_state_dict(grid, 7, blocks=[11])
+    p = weights.pack(sd, grid)
+    w = torch.from_numpy(sd["c_embedder.proj.weight"])       # [384,256,2,2]
+    x = torch.from_numpy(synth.uniform("pw/x", (1, 256, 2, 2), -1, 1, 3))
+    ref = torch.nn.functional.conv2d(x, w, stride=2).reshape(384)
+    row = x[0].permute(1, 2, 0).reshape(-1)                   # (p, q, c)
+    assert (p["c_w"] @ row - ref).abs().max() < 1e-5
+    assert p["r_w16"].shape == (384, 1088) and float(p["r_w16"][:, 1032:].abs().max()) == 0.0
+
+
+def test_denoiser_module_is_checkpoint_compatible():
+    from dvd_amd.script_util import args_to_dict, create_model_and_diffusion, model_and_diffusion_defaults
+    import admin.settings as ws
+    s = ws.Settings()
+    s.env.grid_size = 16
+    model, diffusion = create_model_and_diffusion(device="cpu", train_mode=s.env.train_mode, tv=s.env.time_variant,
+                                                  grid_size=16, **args_to_dict(s, model_and_diffusion_defaults().keys()))
+    sd = model.state_dict()
+    spec = synth.state_dict_spec(16)
+    assert list(sd.keys()) == list(spec.keys()) and len(sd) == 369
+    synth_sd = {k: torch.from_numpy(np.asarray(v)) for k, v in synth.synth_state_dict(16, 7).items()}
+    model.load_state_dict(synth_sd, strict=True)
+    assert torch.equal(model.state_dict()["blocks.11.mlp.fc1.weight"], synth_sd["blocks.11.mlp.fc1.weight"])
+    missing = dict(synth_sd)
+    missing.pop("final_layer2.linear.bias")
+    with pytest.raises(RuntimeError):
+        model.load_state_dict(missing, strict=True)
+    model.load_state_dict(missing, strict=False)             # what val_TDiff.run does
+    assert diffusion.num_timesteps == 3 and diffusion.rescale_timesteps
+    with pytest.raises(RuntimeError, match="HIP engine"):     # no CPU fallback
+        model.engine(16, 1, 2)
+    with pytest.raises(ValueError):
+        create_model_and_diffusion(device="cpu", train_mode="stage_1", tv=True,
+                                   **args_to_dict(s, model_and_diffusion_defaults().keys()))
+
+
+def test_plugin_surface_importable():
+    import importlib
+    mod = importlib.import_module("train_settings.dvd.val_TDiff")
+    assert callable(mod.run)
+    from train_settings.dvd.improved_diffusion import dist_util, logger, script_util  # noqa: F401
+    from train_settings.dvd.improved_diffusion.script_util import create_model_and_diffusion  # noqa: F401
+    assert dist_util.shard_documents(10, 1, 4) == [1, 5, 9]
+    assert sorted(sum((dist_util.shard_documents(10, r, 4) for r in range(4)), [])) == list(range(10))
+
+
+def test_product_never_imports_oracle():
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    bad = []
+    for d in ("dvd_amd", "admin", "train_settings"):
+        for base, _, files in os.walk(os.path.join(root, d)):
+            for f in files:
+                if f.endswith(".py"):
+                    txt = open(os.path.join(base, f)).read()
+                    if "import oracle" in txt or "from oracle" in txt:
+                        bad.append(os.path.join(base, f))
+    assert not bad, bad
+    assert "oracle" not in open(os.path.join(root, "run_sampling.py")).read()
