@@ -15,6 +15,7 @@
 // bias, GELU(tanh) / ReLU, positional-embedding add, adaLN gate, residual add, f16/f32 stores.
 #include "common.h"
 #include "mfma.h"
+#include <stdlib.h>
 #include <type_traits>
 
 namespace dvd {
@@ -44,6 +45,29 @@ __device__ __forceinline__ float gelu_tanh(float x) {
   const float k0 = 0.7978845608028654f, k1 = 0.044715f;
   float u = k0 * (x + k1 * x * x * x);
   return 0.5f * x * (1.f + tanhf(u));
+}
+
+// Epilogue of one 32x32 accumulator tile (rows row0 + cd_row(i,h), column col).  Kept as a function so the
+// callers' tile loops stay small enough to be fully unrolled (a partially unrolled epilogue indexes the
+// accumulator array dynamically, which homes ALL accumulators in scratch memory).
+__device__ __forceinline__ void epilogue_tile(const GemmArgs& p, const floatx16& t, int row0, int col, int h,
+                                              float bcol, float* C32, _Float16* C16, const float* bias,
+                                              const float* res, const float* gate) {
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int row = row0 + cd_row(i, h);
+    if (row < p.M) {
+      float v = t[i] + bcol;
+      if (bias && p.bias_row) v += bias[row];
+      if (p.act == 1) v = gelu_tanh(v);
+      else if (p.act == 2) v = fmaxf(v, 0.f);
+      if (p.pos) v += p.pos[(size_t)(row % p.pos_rows) * p.ldpos + col];
+      if (gate) v *= gate[(size_t)(row / p.gate_rows) * p.ldgate + col];
+      if (res) v += res[(size_t)row * p.ldres + col];
+      if (C32) C32[(size_t)row * p.ldc + col] = v;
+      if (C16) C16[(size_t)row * p.ldc16 + col] = (_Float16)v;
+    }
+  }
 }
 
 template <bool F32>
@@ -231,6 +255,174 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(GemmArgs p) {
   }
 }
 
+
+// ================================================================================================
+// Large-tile f16 kernel for the decoder GEMMs (92 % of the per-step GEMM FLOPs: M = all tokens, N and K in
+// {1536, 2048, 3072}): 256 x 256 tile per 512-thread workgroup (8 waves as 2 x 4, each 128 x 64 = 4 x 2 MFMA
+// 32x32 tiles, 128 accumulator registers), K-step 64.
+//   * operand tiles go global -> LDS directly (global_load_lds_dwordx4 from inline asm, SGPR base + 32-bit
+//     VGPR offset, no staging registers / ds_write), two 64 KiB stages;
+//   * LDS rows are 128 B and unpadded (an LDS-DMA image is lane-linear); bank conflicts are removed by the XOR
+//     swizzle chunk ^= (row >> 1) & 7 applied to the per-lane SOURCE address and to the fragment reads;
+//   * per 16-deep k-step a wave reads 6 fragments for 8 MFMAs (0.75 ds_read_b128 per MFMA instead of 1.0) and
+//     the reads of step s+1 are pinned between the MFMAs of step s (sched_barrier) so LDS latency is covered;
+//   * one barrier per K-step with 32 MFMAs per wave (2 waves per SIMD) between barriers: 4x the matrix work per
+//     synchronisation of the 128 x 128 kernel, whose waves spent > 50 % of their cycles parked (SQ_WAIT_ANY).
+// Same split-weight accumulation order and the same epilogue as gemm_nt_kernel.
+// ================================================================================================
+template <int N>
+__device__ __forceinline__ void glds_group4(const char* gbase, const unsigned (&voff)[N], unsigned lds) {
+  static_assert(N == 4, "unsupported group size");
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %1\n\t"
+      "s_add_u32 m0, %2, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %1\n\t"
+      "s_add_u32 m0, %2, 0x800\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %5, %1\n\t"
+      "s_add_u32 m0, %2, 0xc00\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %6, %1\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "s"(gbase), "s"(lds), "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "v"(voff[3])
+      : "memory", "scc");
+}
+
+__global__ void __launch_bounds__(512, 2) gemm_nt_big_kernel(GemmArgs p) {
+  constexpr int BK = 64, TILE = 256 * 128;   // bytes of one operand tile (256 rows x 64 halfs)
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 stages][A | B]
+  typedef __attribute__((address_space(3))) void* lptr_t;
+
+  const int nwg = p.ntm * p.ntn;
+  int id = blockIdx.x;
+  {
+    const int q = nwg / 8, rr = nwg % 8, xcd = id % 8, k = id / 8;
+    id = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + k;
+  }
+  const int tm = id / p.ntn, tn = id % p.ntn;
+  const int bm0 = tm * 256, bn0 = tn * 256;
+  const int z = blockIdx.y;
+  const _Float16* A = (const _Float16*)p.A + z * p.sA;
+  const _Float16* B = (const _Float16*)p.B + z * p.sB;
+  const _Float16* Alo = p.Alo ? (const _Float16*)p.Alo + z * p.sA : nullptr;
+  const _Float16* Blo = p.Blo ? (const _Float16*)p.Blo + z * p.sB : nullptr;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const int wr = wave >> 2, wc = wave & 3;
+
+  // per-lane source offsets (bytes, relative to the tile's first row at k = 0) of this wave's 4 + 4 loads
+  unsigned aoff[4], boff[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = 8 * (4 * wave + i) + (lane >> 3), pos = lane & 7;
+    const int logical = pos ^ ((row >> 1) & 7);
+    const int ra = min(bm0 + row, p.M - 1) - bm0, rb = min(bn0 + row, p.N - 1) - bn0;
+    aoff[i] = (unsigned)ra * (unsigned)(p.lda * 2) + logical * 16;
+    boff[i] = (unsigned)rb * (unsigned)(p.ldb * 2) + logical * 16;
+  }
+  const char* Atile = (const char*)(A + (size_t)bm0 * p.lda);
+  const char* Btile = (const char*)(B + (size_t)bn0 * p.ldb);
+  const char* Alotile = Alo ? (const char*)(Alo + (size_t)bm0 * p.lda) : Atile;
+  const char* Blotile = Blo ? (const char*)(Blo + (size_t)bn0 * p.ldb) : Btile;
+  const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t)smem;
+
+  // per-lane fragment read offsets: row r of a 32-row block, k-step s -> chunk (2s + h) ^ ((r >> 1) & 7)
+  int frag[4];
+#pragma unroll
+  for (int s4 = 0; s4 < 4; ++s4) frag[s4] = r * 128 + (((2 * s4 + h) ^ ((r >> 1) & 7)) * 16);
+  const int a_base = wr * 128 * 128;            // this wave's first A row, bytes
+  const int b_base = TILE + wc * 64 * 128;      // this wave's first B row
+
+  floatx16 acc[4][2];
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[m][n][i] = 0.f;
+
+  const int nkk = p.K / BK;
+  const int nlo = (Blo || Alo) ? nkk : 0;
+  const int nk = nkk + nlo;
+
+#define BIG_ISSUE(t_, stage_)                                                                      \
+  {                                                                                                \
+    const int tt_ = (t_);                                                                          \
+    const bool lo_ = tt_ < nlo;                                                                    \
+    const size_t kb_ = (size_t)(lo_ ? tt_ : tt_ - nlo) * (BK * 2);                                 \
+    glds_group4<4>((lo_ ? Alotile : Atile) + kb_, aoff, lds0 + (stage_) * 2 * TILE + (4 * wave) * 1024);        \
+    glds_group4<4>((lo_ ? Blotile : Btile) + kb_, boff, lds0 + (stage_) * 2 * TILE + TILE + (4 * wave) * 1024); \
+  }
+#define SB() __builtin_amdgcn_sched_barrier(0)
+#define LDFRAG(set_, s4_)                                                                          \
+  {                                                                                                \
+    _Pragma("unroll") for (int m = 0; m < 4; ++m)                                                  \
+      fa[set_][m] = *(const half8*)(base + a_base + m * 32 * 128 + frag[s4_]);                     \
+    _Pragma("unroll") for (int n = 0; n < 2; ++n)                                                  \
+      fb[set_][n] = *(const half8*)(base + b_base + n * 32 * 128 + frag[s4_]);                     \
+  }
+
+  BIG_ISSUE(0, 0)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int cur = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) BIG_ISSUE(kt + 1, cur ^ 1)
+    const char* base = smem + cur * 2 * TILE;
+    half8 fa[2][4], fb[2][2];
+    LDFRAG(0, 0)
+    SB();
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      const int cs = s4 & 1;
+      // 8 MFMAs of k-step s4; the 6 fragment reads of step s4+1 are spread between them
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+#pragma unroll
+        for (int n = 0; n < 2; ++n) acc[m][n] = mfma32_f16(fa[cs][m], fb[cs][n], acc[m][n]);
+        if (s4 < 3) {
+          fa[cs ^ 1][m] = *(const half8*)(base + a_base + m * 32 * 128 + frag[s4 + 1]);
+          if (m < 2) fb[cs ^ 1][m] = *(const half8*)(base + b_base + m * 32 * 128 + frag[s4 + 1]);
+        }
+        SB();
+      }
+    }
+    if (nlo && kt == nlo - 1) {
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) acc[m][n][i] *= p.lo_scale;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    cur ^= 1;
+  }
+#undef BIG_ISSUE
+#undef SB
+#undef LDFRAG
+
+  // ---------------- epilogue (same semantics as gemm_nt_kernel) ----------------
+  float* C32 = p.C32 ? p.C32 + z * p.sC32 : nullptr;
+  _Float16* C16 = p.C16 ? p.C16 + z * p.sC16 : nullptr;
+  const float* bias = p.bias ? p.bias + z * p.sBias : nullptr;
+  const float* res = p.res ? p.res + z * p.sRes : nullptr;
+  const float* gate = p.gate ? p.gate + z * p.sGate : nullptr;
+  // written out (not a loop): hipcc refuses to fully unroll an 8 x 16-element epilogue loop and would then
+  // index acc[][] dynamically
+#define BIG_EP(m_, n_)                                                                                    \
+  {                                                                                                       \
+    const int col = bn0 + 64 * wc + 32 * (n_) + r;                                                        \
+    if (col < p.N) {                                                                                      \
+      const float bcol = (bias && !p.bias_row) ? bias[col] : 0.f;                                         \
+      epilogue_tile(p, acc[m_][n_], bm0 + 128 * wr + 32 * (m_), col, h, bcol, C32, C16, bias, res, gate); \
+    }                                                                                                     \
+  }
+  BIG_EP(0, 0) BIG_EP(0, 1) BIG_EP(1, 0) BIG_EP(1, 1) BIG_EP(2, 0) BIG_EP(2, 1) BIG_EP(3, 0) BIG_EP(3, 1)
+#undef BIG_EP
+}
+
 }  // namespace dvd
 
 using namespace dvd;
@@ -263,6 +455,20 @@ extern "C" int dvd_gemm_nt(const dvd_gemm_desc* d, void* stream) {
   p.ldgate = d->ldgate; p.ldpos = d->ldpos;
   p.gate_rows = d->gate_rows; p.pos_rows = d->pos_rows;
   p.act = d->act; p.bias_row = d->bias_row;
+  // large-tile kernel for the big f16 GEMMs (decoder): N a multiple of 256, at least a few row tiles
+  const bool big = d->dtype == 0 && d->N % 256 == 0 && d->M >= 1024 && !getenv("DVD_GEMM_V1");
+  if (big) {
+    p.ntm = cdiv(d->M, 256); p.ntn = d->N / 256;
+    constexpr int LDS = 2 * 2 * 256 * 128;
+    static bool once = false;
+    if (!once) {
+      (void)hipFuncSetAttribute((const void*)gemm_nt_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+      once = true;
+    }
+    dim3 gridb(p.ntm * p.ntn, d->batch);
+    gemm_nt_big_kernel<<<gridb, 512, LDS, (hipStream_t)stream>>>(p);
+    return check_launch("gemm_nt(big)");
+  }
   p.ntm = cdiv(d->M, 128); p.ntn = cdiv(d->N, 128);
   dim3 grid(p.ntm * p.ntn, d->batch);
   if (d->dtype == 1)

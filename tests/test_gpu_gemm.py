@@ -107,3 +107,49 @@ def test_gemm_split_weights(ops):
     e_split_a = (out_t.cpu().double().t() - ref).abs().max().item()
     print("split weights", e_plain, e_split, e_split_a)
     assert e_split < e_plain / 20 and e_split < 2e-5 and e_split_a < 2e-5, (e_plain, e_split, e_split_a)
+
+
+@pytest.mark.parametrize("M,N,K", [(1024, 1536, 1536), (1100, 512, 256), (2048, 3072, 1536), (4096, 256, 64)])
+def test_gemm_large_tile_kernel(ops, M, N, K):
+    """Shapes routed to the 256x256 LDS-DMA kernel (N % 256 == 0, M >= 1024), incl. a ragged M."""
+    a, b = rnd(f"la{M}{K}", (M, K)).half(), rnd(f"lb{N}{K}", (N, K)).half()
+    ref = a.double() @ b.double().t()
+    out = torch.zeros(M, N, device="cuda")
+    ops.gemm_nt(a.cuda(), b.cuda(), out32=out)
+    err = (out.cpu().double() - ref).abs().max().item()
+    assert err < 1e-4 * K ** 0.5, err
+
+
+def test_gemm_large_tile_exact_and_epilogue(ops):
+    rng = np.random.RandomState(5)
+    M, N, K, T = 1536, 512, 192, 512
+    a = torch.from_numpy(rng.randint(-4, 5, (M, K)).astype(np.float32)).half()
+    b = torch.from_numpy(rng.randint(-4, 5, (N, K)).astype(np.float32)).half()
+    ref = a.float() @ b.float().t()
+    out = torch.zeros(M, N, device="cuda")
+    ops.gemm_nt(a.cuda(), b.cuda(), out32=out)
+    assert torch.equal(out.cpu(), ref)
+    bias, gate, res = rnd("lbias", (N,)), rnd("lgate", (M // T, N)), rnd("lres", (M, N))
+    out2 = res.clone().cuda()
+    ops.gemm_nt(a.cuda(), b.cuda(), out32=out2, bias=bias.cuda(), gate=gate.cuda(), gate_rows=T, res=out2)
+    ref2 = gate.double().repeat_interleave(T, 0) * (ref.double() + bias.double()) + res.double()
+    assert (out2.cpu().double() - ref2).abs().max() < 1e-3
+    out16 = torch.zeros(M, N, dtype=torch.float16, device="cuda")
+    ops.gemm_nt(a.cuda(), b.cuda(), out16=out16, bias=bias.cuda(), act=2)
+    assert (out16.cpu().double() - torch.relu(ref.double() + bias.double())).abs().max() < 0.3   # f16 store of |v| <= 400
+
+
+def test_gemm_large_tile_split_weights(ops):
+    M, N, K = 2048, 1536, 1536
+    a = rnd("lsa", (M, K)).half()
+    w = rnd("lsw", (N, K)) * 0.05
+    hi = w.half()
+    lo = ((w - hi.float()) * 2048.0).half()
+    ref = a.double() @ w.double().t()
+    out = torch.zeros(M, N, device="cuda")
+    ops.gemm_nt(a.cuda(), hi.cuda(), out32=out, b_lo=lo.cuda())
+    e_b = (out.cpu().double() - ref).abs().max().item()
+    out_t = torch.zeros(N, M, device="cuda")
+    ops.gemm_nt(hi.cuda(), a.cuda(), out32=out_t, a_lo=lo.cuda())       # weight on the A side, N = M % 256 == 0
+    e_a = (out_t.cpu().double().t() - ref).abs().max().item()
+    assert e_b < 2e-5 and e_a < 2e-5, (e_b, e_a)
