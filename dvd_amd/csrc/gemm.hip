@@ -39,6 +39,11 @@ struct GemmArgs {
   int act;       // 0 none, 1 GELU(tanh), 2 ReLU
   int bias_row;  // bias indexed by row instead of column
   int ntm, ntn;  // tile counts
+  int stagger;       // large-tile kernel: start-up delay quantum (x4096 cycles) of the first round of workgroups
+  int vec_epilogue;  // 1: LDS-staged row-contiguous stores (needs N % 8 == 0 and 16-byte aligned rows)
+  int debug;     // timing ablations only (DVD_GEMM_DEBUG): 1 = no operand loads in the K loop, 2 = no MFMAs,
+                 // 3 = per-wave s_memtime stamps (start, first tile landed, K loop done, epilogue done) -> stamps
+  unsigned long long* stamps;
 };
 
 __device__ __forceinline__ float gelu_tanh(float x) {
@@ -70,6 +75,89 @@ __device__ __forceinline__ void epilogue_tile(const GemmArgs& p, const floatx16&
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Epilogue of one wave's 64 x 64 block (2 x 2 accumulator tiles), staged through a private 16 KiB LDS region so
+// that global traffic is row-contiguous 16-byte (f32) / 8-byte (f16) accesses per lane: 4 rows x 256 B (resp.
+// 128 B) per wave-instruction.  The MFMA C layout has one COLUMN per lane; storing it directly costs one 2-byte
+// (f16) store per element and took as long as the whole K loop (measured with s_memtime stamps: 50.6 % of a
+// wave's lifetime in the 256 x 256 kernel).  All epilogue math (bias, activation, pos, gate, residual) runs on
+// the read-back side, 4 consecutive columns per lane.
+//   stage : this wave's LDS region, 64 rows x 64 floats (256-B pitch: conflict-free for both access patterns)
+//   t00.. : accumulator tiles (rows 0-31 | 32-63) x (cols 0-31 | 32-63) of the block at (row0, col0)
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void epilogue_block64(const GemmArgs& p, float* stage, const floatx16& t00,
+                                                 const floatx16& t01, const floatx16& t10, const floatx16& t11,
+                                                 int row0, int col0, int lane, float* C32, _Float16* C16,
+                                                 const float* bias, const float* res, const float* gate) {
+  const int r = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int rr = cd_row(i, h);
+    stage[rr * 64 + r] = t00[i];
+    stage[rr * 64 + 32 + r] = t01[i];
+    stage[(32 + rr) * 64 + r] = t10[i];
+    stage[(32 + rr) * 64 + 32 + r] = t11[i];
+  }
+  // same-wave LDS accesses execute in order; the compiler inserts the lgkmcnt wait for the reads below.
+  // Read back 8 consecutive columns per lane: 8 rows x 256 B (f32, two 16-B stores) / 128 B (f16, one 16-B store)
+  // per wave-instruction - the store tail is store-ISSUE-bound, so fewer, wider stores matter (guide T21).
+  const int c8 = (lane & 7) * 8;
+  const int col = col0 + c8;
+  float bc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (bias && !p.bias_row && col < p.N) {
+    const floatx4 b0 = *(const floatx4*)(bias + col), b1 = *(const floatx4*)(bias + col + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { bc[e] = b0[e]; bc[4 + e] = b1[e]; }
+  }
+#pragma unroll 2
+  for (int it = 0; it < 8; ++it) {
+    const int lr = it * 8 + (lane >> 3);
+    const int row = row0 + lr;
+    const floatx4 s0 = *(const floatx4*)(stage + lr * 64 + c8), s1 = *(const floatx4*)(stage + lr * 64 + c8 + 4);
+    if (row < p.M && col < p.N) {
+      float v[8];
+      const float br = (bias && p.bias_row) ? bias[row] : 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float x = (e < 4 ? s0[e] : s1[e - 4]) + bc[e] + br;
+        if (p.act == 1) x = gelu_tanh(x);
+        else if (p.act == 2) x = fmaxf(x, 0.f);
+        v[e] = x;
+      }
+      if (p.pos) {
+        const float* pp = p.pos + (size_t)(row % p.pos_rows) * p.ldpos + col;
+        const floatx4 p0 = *(const floatx4*)pp, p1 = *(const floatx4*)(pp + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] += p0[e]; v[4 + e] += p1[e]; }
+      }
+      if (gate) {
+        const float* gp = gate + (size_t)(row / p.gate_rows) * p.ldgate + col;
+        const floatx4 g0 = *(const floatx4*)gp, g1 = *(const floatx4*)(gp + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] *= g0[e]; v[4 + e] *= g1[e]; }
+      }
+      if (res) {
+        const float* rp = res + (size_t)row * p.ldres + col;
+        const floatx4 r0 = *(const floatx4*)rp, r1 = *(const floatx4*)(rp + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[4 + e] += r1[e]; }
+      }
+      if (C32) {
+        float* cp = C32 + (size_t)row * p.ldc + col;
+        const floatx4 o0 = {v[0], v[1], v[2], v[3]}, o1 = {v[4], v[5], v[6], v[7]};
+        *(floatx4*)cp = o0;
+        *(floatx4*)(cp + 4) = o1;
+      }
+      if (C16) {
+        half8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (_Float16)v[e];
+        *(half8*)(C16 + (size_t)row * p.ldc16 + col) = o;
+      }
+    }
+  }
+}
+
 template <bool F32>
 __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(GemmArgs p) {
   using T = typename std::conditional<F32, float, _Float16>::type;
@@ -79,7 +167,10 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(GemmArgs p) {
   constexpr int CH = ROWB / 16;                      // 16-B chunks per row
   constexpr int NLD = 128 * CH / 256;                // chunks per thread per operand
   constexpr int EPC = 16 / (int)sizeof(T);           // elements per chunk
-  __shared__ __attribute__((aligned(16))) char smem[2][2][128 * LROW];
+  // each [stage][operand] slab is at least 16 KiB so that the four slabs double as the epilogue's 4 x 16 KiB
+  // per-wave staging regions (f32 operands alone would only need 10 KiB per slab)
+  constexpr int SLAB = 128 * LROW > 16384 ? 128 * LROW : 16384;
+  __shared__ __attribute__((aligned(16))) char smem[2][2][SLAB];
 
   // XCD-aware tile order: consecutive ids inside one XCD walk the N tiles of one M panel.
   const int nwg = p.ntm * p.ntn;
@@ -230,31 +321,24 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(GemmArgs p) {
   const float* bias = p.bias ? p.bias + z * p.sBias : nullptr;
   const float* res = p.res ? p.res + z * p.sRes : nullptr;
   const float* gate = p.gate ? p.gate + z * p.sGate : nullptr;
+  if (p.vec_epilogue) {
+    // the K loop ended with a barrier (or the tail compute): make sure every wave is done reading operands
+    __syncthreads();
+    float* stage = (float*)(&smem[0][0][0]) + wave * (64 * 64);     // 4 x 16 KiB of the 72 KiB operand buffers
+    epilogue_block64(p, stage, acc[0][0], acc[0][1], acc[1][0], acc[1][1], bm0 + 64 * wr, bn0 + 64 * wc, lane, C32,
+                     C16, bias, res, gate);
+  } else {
 #pragma unroll
-  for (int n = 0; n < 2; ++n) {
-    const int col = bn0 + 64 * wc + 32 * n + r;
-    if (col >= p.N) continue;
-    const float bcol = (bias && !p.bias_row) ? bias[col] : 0.f;
+    for (int n = 0; n < 2; ++n) {
+      const int col = bn0 + 64 * wc + 32 * n + r;
+      if (col >= p.N) continue;
+      const float bcol = (bias && !p.bias_row) ? bias[col] : 0.f;
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int row = bm0 + 64 * wr + 32 * m + cd_row(i, h);
-        if (row >= p.M) continue;
-        float v = acc[m][n][i] + bcol;
-        if (bias && p.bias_row) v += bias[row];
-        if (p.act == 1) v = gelu_tanh(v);
-        else if (p.act == 2) v = fmaxf(v, 0.f);
-        if (p.pos) v += p.pos[(size_t)(row % p.pos_rows) * p.ldpos + col];
-        if (gate) v *= gate[(size_t)(row / p.gate_rows) * p.ldgate + col];
-        if (res) v += res[(size_t)row * p.ldres + col];
-        if (C32) C32[(size_t)row * p.ldc + col] = v;
-        if (C16) C16[(size_t)row * p.ldc16 + col] = (_Float16)v;
-      }
+      for (int m = 0; m < 2; ++m)
+        epilogue_tile(p, acc[m][n], bm0 + 64 * wr + 32 * m, col, h, bcol, C32, C16, bias, res, gate);
     }
   }
 }
-
 
 // ================================================================================================
 // Large-tile f16 kernel for the decoder GEMMs (92 % of the per-step GEMM FLOPs: M = all tokens, N and K in
@@ -286,6 +370,7 @@ __device__ __forceinline__ void glds_group4(const char* gbase, const unsigned (&
       : "memory", "scc");
 }
 
+template <int DBG>   // DBG: timing ablations (DVD_GEMM_DEBUG) 1 = no operand loads in the K loop, 2 = no MFMAs
 __global__ void __launch_bounds__(512, 2) gemm_nt_big_kernel(GemmArgs p) {
   constexpr int BK = 64, TILE = 256 * 128;   // bytes of one operand tile (256 rows x 64 halfs)
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 stages][A | B]
@@ -344,6 +429,8 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_big_kernel(GemmArgs p) {
   const int nkk = p.K / BK;
   const int nlo = (Blo || Alo) ? nkk : 0;
   const int nk = nkk + nlo;
+  // (a per-workgroup K rotation was tried against suspected L2-channel hot-spotting: no gain, and it makes the
+  //  fp32 summation order depend on the tile id, so it is not used)
 
 #define BIG_ISSUE(t_, stage_)                                                                      \
   {                                                                                                \
@@ -362,13 +449,29 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_big_kernel(GemmArgs p) {
       fb[set_][n] = *(const half8*)(base + b_base + n * 32 * 128 + frag[s4_]);                     \
   }
 
+  // De-synchronise the chip: with one workgroup per CU every CU would otherwise run its K loop and then its
+  // (HBM-write-bound) epilogue in lockstep, so the output bursts of all 256 CUs collide while HBM idles during
+  // the K loops.  The first round of workgroups starts with a different delay per CU; later rounds stay spread.
+  if (p.stagger && blockIdx.x < 256) {
+    const int slots = (blockIdx.x * 5) & 15;
+    for (int i = 0; i < slots * p.stagger; ++i) __builtin_amdgcn_s_sleep(64);   // 64 * 64 cycles each
+  }
+  unsigned long long t0 = 0, t1 = 0, t2 = 0;
+  if constexpr (DBG == 3) t0 = __builtin_amdgcn_s_memtime();
   BIG_ISSUE(0, 0)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  if constexpr (DBG == 3) t1 = __builtin_amdgcn_s_memtime();
   int cur = 0;
   for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) BIG_ISSUE(kt + 1, cur ^ 1)
+    if (DBG != 1 && kt + 1 < nk) BIG_ISSUE(kt + 1, cur ^ 1)
     const char* base = smem + cur * 2 * TILE;
+    if constexpr (DBG == 2) {   // ablation: loads + barrier only
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      cur ^= 1;
+      continue;
+    }
     half8 fa[2][4], fb[2][2];
     LDFRAG(0, 0)
     SB();
@@ -403,12 +506,20 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_big_kernel(GemmArgs p) {
 #undef SB
 #undef LDFRAG
 
+  if constexpr (DBG == 3) t2 = __builtin_amdgcn_s_memtime();
   // ---------------- epilogue (same semantics as gemm_nt_kernel) ----------------
   float* C32 = p.C32 ? p.C32 + z * p.sC32 : nullptr;
   _Float16* C16 = p.C16 ? p.C16 + z * p.sC16 : nullptr;
   const float* bias = p.bias ? p.bias + z * p.sBias : nullptr;
   const float* res = p.res ? p.res + z * p.sRes : nullptr;
   const float* gate = p.gate ? p.gate + z * p.sGate : nullptr;
+  if (p.vec_epilogue) {
+    float* stage = (float*)smem + wave * (64 * 64);                  // 8 x 16 KiB = the whole 128 KiB
+    const int row0 = bm0 + 128 * wr, col0 = bn0 + 64 * wc;
+    epilogue_block64(p, stage, acc[0][0], acc[0][1], acc[1][0], acc[1][1], row0, col0, lane, C32, C16, bias, res, gate);
+    epilogue_block64(p, stage, acc[2][0], acc[2][1], acc[3][0], acc[3][1], row0 + 64, col0, lane, C32, C16, bias, res,
+                     gate);
+  } else {
   // written out (not a loop): hipcc refuses to fully unroll an 8 x 16-element epilogue loop and would then
   // index acc[][] dynamically
 #define BIG_EP(m_, n_)                                                                                    \
@@ -421,11 +532,24 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_big_kernel(GemmArgs p) {
   }
   BIG_EP(0, 0) BIG_EP(0, 1) BIG_EP(1, 0) BIG_EP(1, 1) BIG_EP(2, 0) BIG_EP(2, 1) BIG_EP(3, 0) BIG_EP(3, 1)
 #undef BIG_EP
+  }
+  if constexpr (DBG == 3) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long t3 = __builtin_amdgcn_s_memtime();
+    if (lane == 0 && p.stamps) {
+      unsigned long long* o = p.stamps + ((size_t)blockIdx.x * 8 + wave) * 4;
+      o[0] = t0; o[1] = t1; o[2] = t2; o[3] = t3;
+    }
+  }
 }
 
 }  // namespace dvd
 
 using namespace dvd;
+
+static unsigned long long* g_gemm_stamps = nullptr;
+// diagnostic builds only (DVD_GEMM_DEBUG=3): where the per-wave s_memtime stamps of the large-tile kernel go
+extern "C" int dvd_gemm_debug_stamps(void* dev_u64) { g_gemm_stamps = (unsigned long long*)dev_u64; return DVD_OK; }
 
 extern "C" int dvd_gemm_nt(const dvd_gemm_desc* d, void* stream) {
   DVD_REQUIRE(d && d->A && d->B && (d->C32 || d->C16), "gemm: null pointer");
@@ -455,6 +579,21 @@ extern "C" int dvd_gemm_nt(const dvd_gemm_desc* d, void* stream) {
   p.ldgate = d->ldgate; p.ldpos = d->ldpos;
   p.gate_rows = d->gate_rows; p.pos_rows = d->pos_rows;
   p.act = d->act; p.bias_row = d->bias_row;
+
+  { const char* dbg = getenv("DVD_GEMM_DEBUG"); p.debug = dbg ? atoi(dbg) : 0; }
+  {
+    auto al = [](const void* q, size_t a) { return ((uintptr_t)q % a) == 0; };
+    bool ok = d->N % 8 == 0 && !getenv("DVD_GEMM_SCALAR_EPILOGUE");
+    if (d->C32) ok = ok && d->ldc % 4 == 0 && d->strideC32 % 4 == 0 && al(d->C32, 16);
+    if (d->C16) ok = ok && d->ldc16 % 8 == 0 && d->strideC16 % 8 == 0 && al(d->C16, 16);
+    if (d->bias && !d->bias_row) ok = ok && al(d->bias, 16) && d->strideBias % 4 == 0;
+    if (d->pos) ok = ok && d->ldpos % 4 == 0 && al(d->pos, 16);
+    if (d->gate) ok = ok && d->ldgate % 4 == 0 && d->strideGate % 4 == 0 && al(d->gate, 16);
+    if (d->res) ok = ok && d->ldres % 4 == 0 && d->strideRes % 4 == 0 && al(d->res, 16);
+    p.vec_epilogue = ok ? 1 : 0;
+  }
+  p.stamps = g_gemm_stamps;
+  { const char* sg = getenv("DVD_GEMM_STAGGER"); p.stagger = sg ? atoi(sg) : 0; }   // measured: no effect
   // large-tile kernel for the big f16 GEMMs (decoder): N a multiple of 256, at least a few row tiles
   const bool big = d->dtype == 0 && d->N % 256 == 0 && d->M >= 1024 && !getenv("DVD_GEMM_V1");
   if (big) {
@@ -462,11 +601,17 @@ extern "C" int dvd_gemm_nt(const dvd_gemm_desc* d, void* stream) {
     constexpr int LDS = 2 * 2 * 256 * 128;
     static bool once = false;
     if (!once) {
-      (void)hipFuncSetAttribute((const void*)gemm_nt_big_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+      (void)hipFuncSetAttribute((const void*)gemm_nt_big_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+      (void)hipFuncSetAttribute((const void*)gemm_nt_big_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+      (void)hipFuncSetAttribute((const void*)gemm_nt_big_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+      (void)hipFuncSetAttribute((const void*)gemm_nt_big_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
       once = true;
     }
     dim3 gridb(p.ntm * p.ntn, d->batch);
-    gemm_nt_big_kernel<<<gridb, 512, LDS, (hipStream_t)stream>>>(p);
+    if (p.debug == 1) gemm_nt_big_kernel<1><<<gridb, 512, LDS, (hipStream_t)stream>>>(p);
+    else if (p.debug == 2) gemm_nt_big_kernel<2><<<gridb, 512, LDS, (hipStream_t)stream>>>(p);
+    else if (p.debug == 3) gemm_nt_big_kernel<3><<<gridb, 512, LDS, (hipStream_t)stream>>>(p);
+    else gemm_nt_big_kernel<0><<<gridb, 512, LDS, (hipStream_t)stream>>>(p);
     return check_launch("gemm_nt(big)");
   }
   p.ntm = cdiv(d->M, 128); p.ntn = cdiv(d->N, 128);

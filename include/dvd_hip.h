@@ -123,6 +123,8 @@ typedef struct {
 } dvd_gemm_desc;
 
 int dvd_gemm_nt(const dvd_gemm_desc* desc, void* stream);
+/* diagnostics (env DVD_GEMM_DEBUG=3): device buffer [workgroups*8*4] u64 receiving per-wave s_memtime stamps */
+int dvd_gemm_debug_stamps(void* dev_u64);
 
 /* ------------------------------------------------------------------------------------------
  * Flash attention core  O = softmax(scale * Q K^T) V  per (batch, head); f16 in/out, fp32 softmax.
