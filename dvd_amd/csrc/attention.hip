@@ -39,6 +39,7 @@ struct AttnArgs {
   int kv_div;            // kv batch = b / kv_div
   int nqb;               // query blocks per (b, h)
   float c;               // scale * log2(e)
+  unsigned long long* stamps;   // diagnostic builds only
 };
 
 __device__ __forceinline__ int kappa(int r) {  // swap bits 2 and 3
@@ -282,6 +283,20 @@ __device__ __forceinline__ void glds_group(const char* gbase, const unsigned (&v
   }
 }
 
+// One 1-KiB LDS-DMA load (see glds_group).  Issued one at a time between MFMAs: sixteen of them back to back at
+// the top of a tile cost ~120 cycles EACH with the matrix pipe idle (36 % of the tile, s_memtime stamps);
+// spread over the tile the memory pipeline drains between them and most of the issue time hides under an MFMA.
+__device__ __forceinline__ void glds_one(const char* gbase, unsigned voff, unsigned lds) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %1\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "s"(gbase), "s"(lds), "v"(voff)
+      : "memory");
+}
+
 // ================================================================================================
 // Fast path (tk % 64 == 0: every shape the engine produces): K / V^T tiles go global -> LDS DIRECTLY
 // (global_load_lds_dwordx4, 1 KiB per wave-instruction, no staging registers, no ds_write).  The LDS
@@ -295,7 +310,7 @@ __device__ __forceinline__ void glds_group(const char* gbase, const unsigned (&v
 // architectural VGPRs and the 128 O^T accumulators stay in AGPRs untouched by the VALU: the v1
 // structure spent ~400 v_accvgpr moves per tile shuffling spilled state.
 // ================================================================================================
-template <int D>
+template <int D, int DBG>   // DBG 1: accumulate per-phase s_memtime deltas (diagnostic build, DVD_ATTN_DEBUG=1)
 __global__ void __launch_bounds__(256, (D == 256 ? 1 : 2)) flash_attn_glds_kernel(AttnArgs p) {
   constexpr int KB = 64;
   constexpr int KROWB = 2 * D;             // K row bytes (512 / 128)
@@ -392,13 +407,31 @@ __global__ void __launch_bounds__(256, (D == 256 ? 1 : 2)) flash_attn_glds_kerne
   //          still places the counted s_waitcnt and every MFMA hazard itself;
   //      (b) the exp2 / sum / f16-pack of P chunk c+1 issues in the gaps of the 8 MFMAs of chunk c.
 #define SB() __builtin_amdgcn_sched_barrier(0)
-#define KLOAD(i_) fr[(i_) & 7] = *(const half8*)(base + kfrag[(i_) % KS] + ((i_) / KS) * 32 * KROWB)
+// S^T step i works on key block (i & 1) and k-step (i >> 1): the two 16-deep accumulation chains alternate, so
+// consecutive MFMAs never depend on each other (a single dependent chain ran at ~58 cycles per MFMA, not 32)
+#define KLOAD(i_) fr[(i_) & 7] = *(const half8*)(base + kfrag[(i_) >> 1] + ((i_) & 1) * 32 * KROWB)
 #define VLOAD(j_) fr[(j_) & 7] = *(const half8*)(base + vfrag[(j_) / DT] + ((j_) % DT) * 32 * 128)
   constexpr int NS = 2 * KS;     // MFMAs of the first product per tile
   constexpr int NP = 4 * DT;     // MFMAs of the second product per tile
   int cur = 0;
+  unsigned long long acc_t[5] = {0, 0, 0, 0, 0};
+#define STAMP(k_)                                                              \
+  if constexpr (DBG == 1) {                                                    \
+    __builtin_amdgcn_sched_barrier(0);                                         \
+    const unsigned long long now_ = __builtin_amdgcn_s_memtime();              \
+    __builtin_amdgcn_s_waitcnt(0xC07F);                                        \
+    acc_t[k_] += now_ - tprev;                                                 \
+    tprev = now_;                                                              \
+    __builtin_amdgcn_sched_barrier(0);                                         \
+  }
+  unsigned long long tprev = 0;
+  if constexpr (DBG == 1) tprev = __builtin_amdgcn_s_memtime();
   for (int t = 0; t < nt; ++t) {
+    // all 16 LDS-DMA loads of the next tile are issued here in one burst (~120 cycles each, matrix pipe idle: 36 %
+    // of the tile).  Interleaving them one by one between the MFMAs was measured and is WORSE (each then costs
+    // 60-180 cycles inside the MFMA/ds_read stream: 6442 vs 5335 cycles per tile); see DESIGN.md.
     if (t + 1 < nt) DVD_GLDS_ISSUE(t + 1, cur ^ 1)
+    STAMP(0)
     const char* base = smem + cur * BUF;
     half8 fr[8];
     floatx16 s[2];
@@ -410,11 +443,12 @@ __global__ void __launch_bounds__(256, (D == 256 ? 1 : 2)) flash_attn_glds_kerne
     SB();
 #pragma unroll
     for (int i = 0; i < NS; ++i) {
-      s[i / KS] = mfma32_f16(fr[i & 7], qf[i % KS], s[i / KS]);
+      s[i & 1] = mfma32_f16(fr[i & 7], qf[i >> 1], s[i & 1]);
       if (i + 4 < NS) { KLOAD(i + 4); } else { VLOAD(i + 4 - NS); }
       SB();
     }
 
+    STAMP(1)
     float mx = -1e30f;
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
@@ -443,6 +477,7 @@ __global__ void __launch_bounds__(256, (D == 256 ? 1 : 2)) flash_attn_glds_kerne
   }
 #pragma unroll
     for (int e = 0; e < 8; ++e) PEXP(0, e)
+    STAMP(2)
     SB();
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
@@ -457,11 +492,20 @@ __global__ void __launch_bounds__(256, (D == 256 ? 1 : 2)) flash_attn_glds_kerne
       SB();
     }
     l_run += rs;
+    STAMP(3)
 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next tile has landed (this wave's loads) ...
     __syncthreads();                                   // ... and everyone's; also: all reads of `cur` are done
+    STAMP(4)
     cur ^= 1;
   }
+  if constexpr (DBG == 1) {
+    if (lane == 0 && p.stamps) {
+      unsigned long long* o_ = p.stamps + ((size_t)blockIdx.x * 4 + wave) * 5;
+      for (int k = 0; k < 5; ++k) o_[k] = acc_t[k];
+    }
+  }
+#undef STAMP
 #undef SB
 #undef KLOAD
 #undef VLOAD
@@ -488,6 +532,10 @@ __global__ void __launch_bounds__(256, (D == 256 ? 1 : 2)) flash_attn_glds_kerne
 
 using namespace dvd;
 
+static unsigned long long* g_attn_stamps = nullptr;
+// diagnostic builds only (DVD_ATTN_DEBUG=1): per-wave accumulated s_memtime deltas of the 5 phases of a KV tile
+extern "C" int dvd_attn_debug_stamps(void* dev_u64) { g_attn_stamps = (unsigned long long*)dev_u64; return DVD_OK; }
+
 extern "C" int dvd_flash_attn(const dvd_attn_desc* d, void* stream) {
   DVD_REQUIRE(d && d->Q && d->K && d->Vt && d->O, "flash_attn: null pointer");
   DVD_REQUIRE(d->head_dim == 64 || d->head_dim == 256, "flash_attn: head_dim %d not in {64,256}", d->head_dim);
@@ -506,6 +554,7 @@ extern "C" int dvd_flash_attn(const dvd_attn_desc* d, void* stream) {
   p.kv_div = d->kv_batch_div;
   p.nqb = cdiv(d->tq, 128);
   p.c = d->scale * 1.4426950408889634f;
+  p.stamps = g_attn_stamps;
   const long nwg = (long)p.nqb * d->heads * d->batch;
   DVD_REQUIRE(nwg < (1l << 31), "flash_attn: grid too large");
   const bool fast = (d->tk % 64 == 0) && !getenv("DVD_ATTN_V1");
@@ -513,13 +562,15 @@ extern "C" int dvd_flash_attn(const dvd_attn_desc* d, void* stream) {
     constexpr int LDS = 2 * (64 * 512 + 256 * 128);
     static bool once2 = false;
     if (!once2) {
-      (void)hipFuncSetAttribute((const void*)flash_attn_glds_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+      (void)hipFuncSetAttribute((const void*)flash_attn_glds_kernel<256, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+      (void)hipFuncSetAttribute((const void*)flash_attn_glds_kernel<256, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
       once2 = true;
     }
-    flash_attn_glds_kernel<256><<<(unsigned)nwg, 256, LDS, (hipStream_t)stream>>>(p);
+    if (getenv("DVD_ATTN_DEBUG")) flash_attn_glds_kernel<256, 1><<<(unsigned)nwg, 256, LDS, (hipStream_t)stream>>>(p);
+    else flash_attn_glds_kernel<256, 0><<<(unsigned)nwg, 256, LDS, (hipStream_t)stream>>>(p);
   } else if (fast) {
     constexpr int LDS = 2 * (64 * 128 + 64 * 128);
-    flash_attn_glds_kernel<64><<<(unsigned)nwg, 256, LDS, (hipStream_t)stream>>>(p);
+    flash_attn_glds_kernel<64, 0><<<(unsigned)nwg, 256, LDS, (hipStream_t)stream>>>(p);
   } else if (d->head_dim == 256) {
     constexpr int LDS = 2 * (64 * (2 * 256 + 16) + 256 * (2 * 64 + 16));
     static bool once = false;

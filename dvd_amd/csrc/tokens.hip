@@ -93,13 +93,16 @@ __global__ void __launch_bounds__(256) layernorm_rows_kernel(const float* __rest
   const float* ip = in + blockIdx.y * sIn + row * ldin;
   float v[PER];
   float s = 0.f;
+  typedef float fvec __attribute__((ext_vector_type(V)));
+  typedef _Float16 hvec __attribute__((ext_vector_type(V)));
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
     const int c0 = (k * 64 + lane) * V;
+    const fvec x = *(const fvec*)(ip + c0);          // 8-/16-byte loads: rows are 16-byte aligned (host check)
 #pragma unroll
     for (int e = 0; e < V; ++e) {
-      v[k * V + e] = ip[c0 + e];
-      s += v[k * V + e];
+      v[k * V + e] = x[e];
+      s += x[e];
     }
   }
   const float mean = wave_sum(s) * (1.f / C);
@@ -116,13 +119,18 @@ __global__ void __launch_bounds__(256) layernorm_rows_kernel(const float* __rest
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
     const int c0 = (k * 64 + lane) * V;
+    fvec g = {}, bt = {}, scv = {}, shv = {};
+    if (gamma) { g = *(const fvec*)(gamma + c0); bt = *(const fvec*)(beta + c0); }
+    if (sc) { scv = *(const fvec*)(sc + c0); shv = *(const fvec*)(sh + c0); }
+    hvec o;
 #pragma unroll
     for (int e = 0; e < V; ++e) {
       float y = (v[k * V + e] - mean) * rstd;
-      if (gamma) y = y * gamma[c0 + e] + beta[c0 + e];
-      if (sc) y = y * (1.f + sc[c0 + e]) + sh[c0 + e];
-      op[c0 + e] = (_Float16)y;
+      if (gamma) y = y * g[e] + bt[e];
+      if (sc) y = y * (1.f + scv[e]) + shv[e];
+      o[e] = (_Float16)y;
     }
+    *(hvec*)(op + c0) = o;
   }
 }
 
@@ -232,8 +240,11 @@ __global__ void __launch_bounds__(256) dwconv3x3_kernel(const _Float16* __restri
   const int t = (int)(tok % T);
   const int ty = t / side, tx = t % side;
   float acc[8];
+  {
+    const floatx4 b0 = *(const floatx4*)(b + ch), b1 = *(const floatx4*)(b + ch + 4);
 #pragma unroll
-  for (int e = 0; e < 8; ++e) acc[e] = b[ch + e];
+    for (int e = 0; e < 4; ++e) { acc[e] = b0[e]; acc[4 + e] = b1[e]; }
+  }
 #pragma unroll
   for (int dy = -1; dy <= 1; ++dy) {
     const int yy = ty + dy;
@@ -244,8 +255,12 @@ __global__ void __launch_bounds__(256) dwconv3x3_kernel(const _Float16* __restri
       if (xx < 0 || xx >= side) continue;
       const half8 v = *(const half8*)(in + (tok + (long)dy * side + dx) * c + ch);
       const float* wp = w + ((dy + 1) * 3 + (dx + 1)) * c + ch;
+      const floatx4 w0 = *(const floatx4*)wp, w1 = *(const floatx4*)(wp + 4);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) acc[e] += (float)v[e] * wp[e];
+      for (int e = 0; e < 4; ++e) {
+        acc[e] += (float)v[e] * w0[e];
+        acc[4 + e] += (float)v[4 + e] * w1[e];
+      }
     }
   }
   half8 o;
@@ -472,6 +487,10 @@ extern "C" int dvd_layernorm_rows(const float* in, int ldin, long stride_in, voi
               "layernorm_rows: affine / modulate pointers must come in pairs");
   DVD_REQUIRE(!shift || mod_rows > 0, "layernorm_rows: mod_rows");
   DVD_REQUIRE(rows > 0 && batch > 0 && batch < 65536, "layernorm_rows: bad rows/batch");
+  DVD_REQUIRE(ldin % 4 == 0 && stride_in % 2 == 0 && ldout % 4 == 0 && stride_out % 2 == 0 && ldmod % 4 == 0 &&
+                  ((uintptr_t)in % 16) == 0 && ((uintptr_t)out16 % 8) == 0 && ((uintptr_t)gamma % 16) == 0 &&
+                  ((uintptr_t)beta % 16) == 0 && ((uintptr_t)shift % 16) == 0 && ((uintptr_t)scale % 16) == 0,
+              "layernorm_rows: rows must be 16-byte aligned (vector loads)");
   dim3 grid(cdiv(rows, 4), batch);
   if (c == 384)
     layernorm_rows_kernel<384><<<grid, 256, 0, (hipStream_t)stream>>>(in, ldin, stride_in, (_Float16*)out16, ldout,

@@ -93,6 +93,7 @@ SIGNATURES = {
     "dvd_gemm_nt": [C.POINTER(GemmDesc), c_void],
     "dvd_gemm_debug_stamps": [c_void],
     "dvd_flash_attn": [C.POINTER(AttnDesc), c_void],
+    "dvd_attn_debug_stamps": [c_void],
     "dvd_embed_obs_ln": [c_void, c_void, c_void, c_void, c_void, c_void, C.c_int, C.c_int, c_void],
     "dvd_layernorm_rows": [c_void, C.c_int, C.c_long, c_void, C.c_int, C.c_long, C.c_int, C.c_long, C.c_int, c_void,
                            c_void, c_void, c_void, C.c_int, C.c_int, C.c_float, c_void],

@@ -142,3 +142,85 @@ def flash_attn(q, k, vt, out, heads, head_dim, scale, kv_batch_div=1):
     d.scale = scale
     lib.call("dvd_flash_attn", C.byref(d), stream_ptr())
     return out
+
+
+# ---- token-side kernels (thin wrappers used by the parity tests; the engine calls them from C++) ----------------
+def layernorm_rows(x, c, gamma=None, beta=None, shift=None, scale=None, mod_rows=1, eps=1e-6):
+    rows = x.shape[0]
+    out = torch.empty(rows, c, dtype=torch.float16, device=x.device)
+    lib.call("dvd_layernorm_rows", ptr(x), x.stride(0), 0, ptr(out), c, 0, 1, rows, c, ptr(gamma), ptr(beta), ptr(shift),
+             ptr(scale), (shift.stride(0) if shift is not None and shift.dim() > 1 else 0), mod_rows, C.c_float(eps),
+             stream_ptr())
+    return out
+
+
+def dwconv3x3(x16, w9c, b, n, side):
+    out = torch.empty_like(x16)
+    lib.call("dvd_dwconv3x3", ptr(x16), ptr(out), ptr(w9c), ptr(b), n, side, x16.shape[-1], stream_ptr())
+    return out
+
+
+def embed_obs_ln(x, w, b, pos):
+    n, _, g, _ = x.shape
+    T = (g // 2) ** 2
+    tok = torch.empty(n * T, 384, dtype=torch.float32, device=x.device)
+    ln = torch.empty(n * T, 384, dtype=torch.float16, device=x.device)
+    lib.call("dvd_embed_obs_ln", ptr(x), ptr(w), ptr(b), ptr(pos), ptr(tok), ptr(ln), n, g, stream_ptr())
+    return tok, ln
+
+
+def small_linear(x, w, b, act_in=0, act_out=0, kmod=None):
+    m = x.shape[0]
+    n, k = w.shape
+    y = torch.empty(m, n, dtype=torch.float32, device=x.device)
+    lib.call("dvd_small_linear", ptr(x), x.stride(0), ptr(w), ptr(b), ptr(y), n, m, k, n, kmod or k, act_in, act_out,
+             stream_ptr())
+    return y
+
+
+def final_tokens(z, gamma, beta, shift, scale, w8, b8, init_flow, n, g):
+    x0 = torch.empty(n, 2, g, g, dtype=torch.float32, device=z.device)
+    tok8 = torch.empty(z.shape[0], 8, dtype=torch.float32, device=z.device)
+    lib.call("dvd_final_tokens", ptr(z), ptr(gamma), ptr(beta), ptr(shift), ptr(scale), 0, z.shape[0], ptr(w8), ptr(b8),
+             ptr(init_flow), ptr(x0), ptr(tok8), n, g, stream_ptr())
+    return x0, tok8
+
+
+def posenc(z, hs, ws, htab, wtab, n, side):
+    c = z.shape[-1]
+    chunks = 8
+    part = torch.empty(n * chunks * c, dtype=torch.float32, device=z.device)
+    pooled = torch.empty(n, c, dtype=torch.float32, device=z.device)
+    lib.call("dvd_colmean", ptr(z), ptr(part), ptr(pooled), n, side * side, c, chunks, stream_ptr())
+    lib.call("dvd_posenc_add", ptr(z), ptr(hs), ptr(ws), ptr(htab), ptr(wtab), n, side, c, stream_ptr())
+    return pooled
+
+
+def build_r_rows(feat_nhwc, flow, n_hyp, mode, init_feat=None):
+    n, _, g, _ = flow.shape
+    T = (g // 2) ** 2
+    out = torch.empty(n * T, 1088, dtype=torch.float16, device=flow.device)
+    lib.call("dvd_build_r_rows", ptr(feat_nhwc), ptr(init_feat), ptr(flow), ptr(out), 1088, n, g, n_hyp, mode, stream_ptr())
+    return out
+
+
+def conv3x3_relu_nhwc(x_nhwc, w_packed, bias, cin, cout, h, w):
+    """One pyramid layer the way the engine runs it: im2col + exact-f32 GEMM (+bias, ReLU)."""
+    kp = w_packed.shape[1]
+    col = torch.empty(h * w, kp, dtype=torch.float32, device=x_nhwc.device)
+    lib.call("dvd_im2col3x3", ptr(x_nhwc), 1, w * cin, cin, ptr(col), kp, cin, h, w, stream_ptr())
+    out = torch.empty(h * w, cout, dtype=torch.float32, device=x_nhwc.device)
+    gemm_nt(col, w_packed, out32=out, bias=bias, act=2)
+    return out
+
+
+def maxpool2_nhwc(x, c, h, w):
+    out = torch.empty((h // 2) * (w // 2), c, dtype=torch.float32, device=x.device)
+    lib.call("dvd_maxpool2_nhwc", ptr(x), ptr(out), c, h, w, stream_ptr())
+    return out
+
+
+def resize_bilinear_nhwc(x, c, hin, win, hout, wout):
+    out = torch.empty(hout * wout, c, dtype=torch.float32, device=x.device)
+    lib.call("dvd_resize_bilinear_nhwc", ptr(x), ptr(out), c, hin, win, hout, wout, stream_ptr())
+    return out

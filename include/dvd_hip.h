@@ -147,6 +147,8 @@ typedef struct {
 } dvd_attn_desc;
 
 int dvd_flash_attn(const dvd_attn_desc* desc, void* stream);
+/* diagnostics (env DVD_ATTN_DEBUG=1): device buffer [workgroups*4*5] u64 receiving per-wave phase times */
+int dvd_attn_debug_stamps(void* dev_u64);
 
 /* ------------------------------------------------------------------------------------------
  * Token-side kernels (each also reachable on its own for parity tests).  "rows" = tokens of all

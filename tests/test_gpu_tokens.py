@@ -1,0 +1,147 @@
+"""GPU parity of the token-side HIP kernels, each against the torch-CPU op(s) it replaces (the same ops the
+oracle / the reference call)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from dvd_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from dvd_amd import ops as _ops
+    return _ops
+
+
+def rnd(tag, shape, lo=-1.0, hi=1.0):
+    return torch.from_numpy(synth.uniform(tag, shape, lo, hi, 21))
+
+
+@pytest.mark.parametrize("c", [384, 1536])
+def test_layernorm_variants(ops, c):
+    x = rnd(f"ln{c}", (300, c), -3, 3)
+    g, b = rnd("lng", (c,), 0.5, 1.5), rnd("lnb", (c,), -0.2, 0.2)
+    sh, sc = rnd("lnsh", (1, c), -0.5, 0.5), rnd("lnsc", (1, c), -0.5, 0.5)
+    plain = ops.layernorm_rows(x.cuda(), c).float().cpu()
+    assert (plain - F.layer_norm(x, (c,), eps=1e-6)).abs().max() < 3e-3
+    aff = ops.layernorm_rows(x.cuda(), c, gamma=g.cuda(), beta=b.cuda(), eps=1e-5).float().cpu()
+    assert (aff - F.layer_norm(x, (c,), g, b, 1e-5)).abs().max() < 4e-3
+    mod = ops.layernorm_rows(x.cuda(), c, shift=sh.cuda(), scale=sc.cuda(), mod_rows=300).float().cpu()
+    assert (mod - (F.layer_norm(x, (c,), eps=1e-6) * (1 + sc) + sh)).abs().max() < 4e-3
+
+
+def test_embed_obs_ln(ops):
+    g, n = 16, 3
+    x = rnd("eo/x", (n, 2, g, g))
+    w, b, pos = rnd("eo/w", (384, 2, 2, 2), -0.3, 0.3), rnd("eo/b", (384,), -0.1, 0.1), rnd("eo/p", (64, 384))
+    tok, ln = ops.embed_obs_ln(x.cuda(), w.reshape(384, 8).contiguous().cuda(), b.cuda(), pos.cuda())
+    ref = F.conv2d(x, w, b, stride=2).flatten(2).transpose(1, 2) + pos[None]
+    assert (tok.cpu().reshape(n, 64, 384) - ref).abs().max() < 1e-5
+    assert (ln.float().cpu().reshape(n, 64, 384) - F.layer_norm(ref, (384,), eps=1e-6)).abs().max() < 3e-3
+
+
+def test_timestep_mlp_and_adaln(ops):
+    """small_linear: sinusoid -> Linear -> SiLU -> Linear (TimestepEmbedder), then SiLU -> Linear (adaLN) with the
+    input tiled x4 (FinalLayer2's t.repeat(1,4))."""
+    w0, b0 = rnd("t/w0", (384, 256), -0.1, 0.1), rnd("t/b0", (384,), -0.1, 0.1)
+    w2, b2 = rnd("t/w2", (384, 384), -0.1, 0.1), rnd("t/b2", (384,), -0.1, 0.1)
+    wa, ba = rnd("t/wa", (3072, 1536), -0.05, 0.05), rnd("t/ba", (3072,), -0.1, 0.1)
+    for t in (2.0, 1.0, 0.0, 600.0, 333.3333):
+        tt = torch.tensor([[t]], dtype=torch.float32)
+        th = ops.small_linear(tt.cuda(), w0.cuda(), b0.cuda(), act_in=2, act_out=1, kmod=256)
+        c = ops.small_linear(th, w2.cuda(), b2.cuda())
+        fin = ops.small_linear(c, wa.cuda(), ba.cuda(), act_in=1, kmod=384)
+        half = 128
+        freqs = torch.exp(-math.log(10000) * torch.arange(half, dtype=torch.float32) / half)
+        e = torch.cat([torch.cos(tt * freqs), torch.sin(tt * freqs)], dim=-1)
+        c_ref = F.linear(F.silu(F.linear(e, w0, b0)), w2, b2)
+        fin_ref = F.linear(F.silu(c_ref.repeat(1, 4)), wa, ba)
+        assert (c.cpu() - c_ref).abs().max() < 2e-5, t
+        assert (fin.cpu() - fin_ref).abs().max() < 5e-5, t
+
+
+def test_dwconv_bn_relu(ops):
+    n, side, c = 2, 8, 2048
+    x = rnd("dw/x", (n, c, side, side), -1, 2)
+    w = rnd("dw/w", (c, 1, 3, 3), -0.5, 0.5)
+    s, b = rnd("dw/s", (c,), 0.5, 1.5), rnd("dw/b", (c,), -0.3, 0.3)
+    ref = F.relu(F.conv2d(x.half().float(), w, None, padding=1, groups=c) * s[None, :, None, None] + b[None, :, None, None])
+    x16 = x.permute(0, 2, 3, 1).reshape(n * side * side, c).half().contiguous()
+    w9c = (w.reshape(c, 9) * s[:, None]).t().contiguous()
+    out = ops.dwconv3x3(x16.cuda(), w9c.cuda(), b.cuda(), n, side).float().cpu()
+    got = out.reshape(n, side, side, c).permute(0, 3, 1, 2)
+    assert (got - ref).abs().max() < 6e-3
+
+
+def test_adaptive_posenc(ops):
+    n, side, c = 2, 4, 1536
+    z = rnd("pe/z", (n * side * side, c))
+    hs, ws = rnd("pe/hs", (n, c), 0, 1), rnd("pe/ws", (n, c), 0, 1)
+    htab, wtab = rnd("pe/ht", (side, c)), rnd("pe/wt", (side, c))
+    zz = z.clone().cuda()
+    pooled = ops.posenc(zz, hs.cuda(), ws.cuda(), htab.cuda(), wtab.cuda(), n, side)
+    assert (pooled.cpu() - z.reshape(n, side * side, c).mean(1)).abs().max() < 1e-6
+    ref = z.reshape(n, side, side, c) + hs[:, None, None, :] * htab[None, :, None, :] + ws[:, None, None, :] * wtab[None, None, :, :]
+    assert (zz.cpu().reshape(n, side, side, c) - ref).abs().max() < 1e-6
+
+
+def test_final_tokens(ops):
+    n, g = 2, 8
+    T = (g // 2) ** 2
+    z = rnd("fi/z", (n * T, 1536), -2, 2)
+    gam, bet = rnd("fi/g", (1536,), 0.8, 1.2), rnd("fi/b", (1536,), -0.1, 0.1)
+    sh, sc = rnd("fi/sh", (1536,), -0.3, 0.3), rnd("fi/sc", (1536,), -0.3, 0.3)
+    w8, b8 = rnd("fi/w8", (8, 1536), -0.05, 0.05), rnd("fi/b8", (8,), -0.1, 0.1)
+    flow = rnd("fi/flow", (n, 2, g, g), -0.3, 0.3)
+    x0, tok8 = ops.final_tokens(z.cuda(), gam.cuda(), bet.cuda(), sh.cuda(), sc.cuda(), w8.cuda(), b8.cuda(), flow.cuda(), n, g)
+    h = F.layer_norm(F.layer_norm(z, (1536,), gam, bet, 1e-5), (1536,), eps=1e-6) * (1 + sc) + sh
+    o = F.linear(h, w8, b8)
+    assert (tok8.cpu() - o).abs().max() < 2e-5
+    side = g // 2
+    ref = torch.einsum("nhwpqc->nchpwq", o.reshape(n, side, side, 2, 2, 2)).reshape(n, 2, g, g) + flow
+    assert (x0.cpu() - ref).abs().max() < 2e-5
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
+def test_build_r_rows(ops, mode):
+    from oracle import dvd_oracle as O
+    g, docs, hyp = 8, 2, 2
+    n = docs * hyp
+    feat = rnd("rr/feat", (docs, 256, g, g), 0, 2)
+    flow = rnd("rr/flow", (n, 2, g, g), -0.4, 0.4)
+    explicit = rnd("rr/if", (n, 256, g, g), 0, 1)
+    feat_n = feat.repeat_interleave(hyp, 0)
+    init_feat = {0: torch.zeros(n, 256, g, g), 1: feat_n,
+                 2: O.grid_sample_ref(feat_n, (flow + O.base_grid(g, g)) * 2 - 1), 3: explicit}[mode]
+    rows = ops.build_r_rows(feat.permute(0, 2, 3, 1).contiguous().cuda(), flow.cuda(), hyp, mode,
+                            init_feat=explicit.cuda() if mode == 3 else None).float().cpu()
+    x = torch.cat([flow, init_feat], dim=1)                                       # [n,258,g,g]
+    side = g // 2
+    ref = x.reshape(n, 258, side, 2, side, 2).permute(0, 2, 4, 3, 5, 1).reshape(n * side * side, 4 * 258)   # (p,q,c)
+    assert (rows[:, :1032] - ref).abs().max() < 2e-3
+    assert float(rows[:, 1032:].abs().max()) == 0.0
+
+
+def test_pyramid_pieces(ops):
+    h = w = 16
+    cin, cout = 8, 64
+    x = rnd("py/x", (1, cin, h, w))
+    wt, b = rnd("py/w", (cout, cin, 3, 3), -0.3, 0.3), rnd("py/b", (cout,), -0.1, 0.1)
+    flat = wt.permute(0, 2, 3, 1).reshape(cout, -1)
+    wp = torch.zeros(cout, 128)
+    wp[:, :flat.shape[1]] = flat
+    out = ops.conv3x3_relu_nhwc(x[0].permute(1, 2, 0).contiguous().cuda(), wp.cuda(), b.cuda(), cin, cout, h, w)
+    ref = F.relu(F.conv2d(x, wt, b, padding=1))[0].permute(1, 2, 0).reshape(h * w, cout)
+    assert (out.cpu() - ref).abs().max() < 2e-5
+    pooled = ops.maxpool2_nhwc(out, cout, h, w).cpu()
+    ref_p = F.max_pool2d(out.cpu().reshape(h, w, cout).permute(2, 0, 1)[None], 2)[0].permute(1, 2, 0).reshape(-1, cout)
+    assert torch.equal(pooled, ref_p)          # max-pool of the kernel's own conv output is exact
+    up = ops.resize_bilinear_nhwc(pooled.cuda(), cout, h // 2, w // 2, 18, 18).cpu()
+    ref_u = F.interpolate(ref_p.reshape(h // 2, w // 2, cout).permute(2, 0, 1)[None], size=(18, 18), mode="bilinear",
+                          align_corners=True)[0].permute(1, 2, 0).reshape(-1, cout)
+    assert (up - ref_u).abs().max() < 1e-5
