@@ -528,6 +528,198 @@ __global__ void __launch_bounds__(256, (D == 256 ? 1 : 2)) flash_attn_glds_kerne
   }
 }
 
+
+// ================================================================================================
+// head_dim 256, TWO waves per SIMD ("d-split"): a workgroup is 8 waves = 4 query blocks x 2 halves of the
+// head dimension.  The two waves of a pair own the same 32 query rows; BOTH compute the full S^T = K.Q^T and the
+// softmax (no communication), each accumulates only its 128 of the 256 output columns (O^T: 64 registers
+// instead of 128).  EXPERIMENT, NOT THE DEFAULT: correct (parity tests pass with DVD_ATTN_DSPLIT=1) but 10 % slower
+// than the one-wave-per-SIMD kernel - the CU's L2->LDS load path (~34 B/clk, 64 KiB per tile) is the common
+// limit and the duplicated QK^T product is not paid back.  That wastes MFMA work (48 instead of 32 useful-equivalent MFMAs per wave and tile: the QK^T
+// product is done twice) but brings the wave under 256 registers, so two waves share every SIMD and one wave's
+// LDS-DMA issue (8 x ~120 cycles per tile), softmax VALU and LDS latency overlap the other's MFMAs - at one wave
+// per SIMD those were 64 % of a tile (s_memtime stamps: 5335 cycles per 2048 cycles of MFMA).
+// ================================================================================================
+template <int N>
+__device__ __forceinline__ void glds_group4(const char* gbase, const unsigned (&voff)[N], unsigned lds) {
+  static_assert(N == 4, "unsupported group size");
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %1\n\t"
+      "s_add_u32 m0, %2, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %1\n\t"
+      "s_add_u32 m0, %2, 0x800\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %5, %1\n\t"
+      "s_add_u32 m0, %2, 0xc00\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %6, %1\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "s"(gbase), "s"(lds), "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "v"(voff[3])
+      : "memory", "scc");
+}
+
+__global__ void __launch_bounds__(512, 2) flash_attn_dsplit_kernel(AttnArgs p) {
+  constexpr int D = 256, KB = 64, KROWB = 512, KBYTES = KB * KROWB, VBYTES = D * 128, BUF = KBYTES + VBYTES;
+  constexpr int KS = 16, NS = 32, NP = 16;
+  constexpr float RESCALE_THR = 10.f;
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][BUF]
+  typedef __attribute__((address_space(3))) void* lptr_t;
+
+  const int nwg = gridDim.x;
+  int id = blockIdx.x;
+  {
+    const int q = nwg / 8, rr = nwg % 8, xcd = id % 8, k = id / 8;
+    id = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + k;
+  }
+  const int qb = id % p.nqb;
+  const int bh = id / p.nqb;
+  const int head = bh % p.heads, b = bh / p.heads;
+  const int kvb = b / p.kv_div;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int qw = wave >> 1, dh = wave & 1;
+  const int r = lane & 31, h = lane >> 5;
+
+  const _Float16* Qg = p.Q + b * p.sQ + (size_t)head * D;
+  const char* Kg = (const char*)(p.K + kvb * p.sK + (size_t)head * D);
+  const char* Vg = (const char*)(p.Vt + kvb * p.sVt + (size_t)head * D * p.ldvt);
+
+  const int qrow = min(qb * 128 + qw * 32 + r, p.tq - 1);
+  half8 qf[KS];
+  {
+    const _Float16* qp = Qg + (size_t)qrow * p.ldq + 8 * h;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const half8*)(qp + 16 * ks);
+  }
+
+  unsigned koff[4], voff[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int q = (4 * wave + i) * 64 + lane;
+    const int krow = q / 32, kpos = q % 32;
+    koff[i] = (unsigned)krow * (unsigned)(p.ldk * 2) + (unsigned)((kpos ^ (krow & 15)) * 16);
+    const int vrow = q / 8, vpos = q % 8;
+    voff[i] = (unsigned)vrow * (unsigned)(p.ldvt * 2) + (unsigned)((vpos ^ ((vrow >> 1) & 7)) * 16);
+  }
+  // fragment read offsets: K chunk (2 ks + h) ^ fk = 2 (ks ^ (fk >> 1)) + (h ^ (fk & 1)); ks ^ xs = 8 (ks >> 3) + ((ks & 7) ^ xs)
+  const int kr = kappa(r), fk = kr & 15, xs = fk >> 1;
+  int kfrag8[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) kfrag8[k] = kr * KROWB + 16 * (h ^ (fk & 1)) + 32 * (k ^ xs);
+  const int fv = (r >> 1) & 7;
+  int vfrag[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) vfrag[c] = KBYTES + (dh * 128 + r) * 128 + (((2 * c + h) ^ fv) * 16);   // (128 dh + r) >> 1 & 7 == fv
+
+  floatx16 o[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) o[dt][i] = 0.f;
+  float m_run = -1e30f, l_run = 0.f;
+  const int nt = p.tk / KB;
+  const size_t ktile = (size_t)KB * p.ldk * 2;
+  const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t)smem;
+
+#define DS_ISSUE(t_, buf_)                                                                                   \
+  {                                                                                                          \
+    glds_group4<4>(Kg + (size_t)(t_) * ktile, koff, lds0 + (buf_) * BUF + (4 * wave) * 1024);                 \
+    glds_group4<4>(Vg + (size_t)(t_) * (KB * 2), voff, lds0 + (buf_) * BUF + KBYTES + (4 * wave) * 1024);     \
+  }
+#define SB() __builtin_amdgcn_sched_barrier(0)
+#define KLOAD(i_) fr[(i_) & 7] = *(const half8*)(base + kfrag8[((i_) >> 1) & 7] + ((i_) >> 4) * 256 + ((i_) & 1) * 32 * KROWB)
+#define VLOAD(j_) fr[(j_) & 7] = *(const half8*)(base + vfrag[(j_) >> 2] + ((j_) & 3) * 32 * 128)
+
+  DS_ISSUE(0, 0)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  int cur = 0;
+  for (int t = 0; t < nt; ++t) {
+    if (t + 1 < nt) DS_ISSUE(t + 1, cur ^ 1)
+    const char* base = smem + cur * BUF;
+    half8 fr[8];
+    floatx16 s[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) s[kb][i] = 0.f;
+    KLOAD(0); KLOAD(1); KLOAD(2); KLOAD(3);
+    SB();
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {         // key block i & 1, k-step i >> 1 (alternating accumulation chains)
+      s[i & 1] = mfma32_f16(fr[i & 7], qf[i >> 1], s[i & 1]);
+      if (i + 4 < NS) { KLOAD(i + 4); } else { VLOAD(i + 4 - NS); }
+      SB();
+    }
+
+    float mx = -1e30f;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) mx = fmaxf(mx, s[kb][i]);
+    mx *= p.c;
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    if (__any(mx - m_run > RESCALE_THR)) {
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      m_run = m_new;
+      l_run *= alpha;
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o[dt][i] *= alpha;
+    }
+    float rs = 0.f;
+    half8 pf[4];
+#define PEXP(c_, e_)                                                                             \
+  {                                                                                              \
+    const float pv_ = __builtin_amdgcn_exp2f(fmaf(s[(c_) >> 1][8 * ((c_) & 1) + (e_)], p.c, -m_run)); \
+    rs += pv_;                                                                                   \
+    pf[c_][e_] = (_Float16)pv_;                                                                  \
+  }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) PEXP(0, e)
+    SB();
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {         // key chunk c = j >> 2 outer, this wave's 4 d-tiles inner
+      const int c = j >> 2, dt = j & 3;
+      o[dt] = mfma32_f16(fr[j & 7], pf[c], o[dt]);
+      if (j + 4 < NP) VLOAD(j + 4);
+      if (c < 3) {
+        PEXP(c + 1, 2 * dt)
+        PEXP(c + 1, 2 * dt + 1)
+      }
+      SB();
+    }
+    l_run += rs;
+
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    cur ^= 1;
+  }
+#undef DS_ISSUE
+#undef SB
+#undef KLOAD
+#undef VLOAD
+#undef PEXP
+
+  const float l_tot = l_run + __shfl_xor(l_run, 32);
+  const float inv = 1.f / l_tot;
+  const int qglob = qb * 128 + qw * 32 + r;
+  if (qglob < p.tq) {
+    _Float16* op = p.O + b * p.sO + (size_t)qglob * p.ldo + (size_t)head * D + 128 * dh;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        half4 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = (_Float16)(o[dt][4 * g4 + j] * inv);
+        *(half4*)(op + 32 * dt + 8 * g4 + 4 * h) = v;
+      }
+  }
+}
+
 }  // namespace dvd
 
 using namespace dvd;
@@ -558,7 +750,15 @@ extern "C" int dvd_flash_attn(const dvd_attn_desc* d, void* stream) {
   const long nwg = (long)p.nqb * d->heads * d->batch;
   DVD_REQUIRE(nwg < (1l << 31), "flash_attn: grid too large");
   const bool fast = (d->tk % 64 == 0) && !getenv("DVD_ATTN_V1");
-  if (fast && d->head_dim == 256) {
+  if (fast && d->head_dim == 256 && getenv("DVD_ATTN_DSPLIT")) {   // measured slower (732 vs 812 TF/s): opt-in only
+    constexpr int LDS = 2 * (64 * 512 + 256 * 128);
+    static bool once3 = false;
+    if (!once3) {
+      (void)hipFuncSetAttribute((const void*)flash_attn_dsplit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+      once3 = true;
+    }
+    flash_attn_dsplit_kernel<<<(unsigned)nwg, 512, LDS, (hipStream_t)stream>>>(p);
+  } else if (fast && d->head_dim == 256) {
     constexpr int LDS = 2 * (64 * 512 + 256 * 128);
     static bool once2 = false;
     if (!once2) {
