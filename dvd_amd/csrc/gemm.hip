@@ -376,24 +376,28 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_big_kernel(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 stages][A | B]
   typedef __attribute__((address_space(3))) void* lptr_t;
 
+  // PERSISTENT: gridDim.x <= 256 workgroups (one per CU, a multiple of 8 so a workgroup stays on "its" XCD
+  // group) walk the tile list.  The epilogue's global stores are fire-and-forget, so they drain while the same
+  // workgroup is already loading / multiplying its next tile; with one workgroup per tile every CU ran K loop and
+  // (HBM-write-bound, 25 % of its time) epilogue in lockstep and the two phases never overlapped.
   const int nwg = p.ntm * p.ntn;
-  int id = blockIdx.x;
+  const int z = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const int wr = wave >> 2, wc = wave & 3;
+  for (int vid = blockIdx.x; vid < nwg; vid += gridDim.x) {
+  int id = vid;
   {
     const int q = nwg / 8, rr = nwg % 8, xcd = id % 8, k = id / 8;
     id = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + k;
   }
   const int tm = id / p.ntn, tn = id % p.ntn;
   const int bm0 = tm * 256, bn0 = tn * 256;
-  const int z = blockIdx.y;
   const _Float16* A = (const _Float16*)p.A + z * p.sA;
   const _Float16* B = (const _Float16*)p.B + z * p.sB;
   const _Float16* Alo = p.Alo ? (const _Float16*)p.Alo + z * p.sA : nullptr;
   const _Float16* Blo = p.Blo ? (const _Float16*)p.Blo + z * p.sB : nullptr;
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int r = lane & 31, h = lane >> 5;
-  const int wr = wave >> 2, wc = wave & 3;
 
   // per-lane source offsets (bytes, relative to the tile's first row at k = 0) of this wave's 4 + 4 loads
   unsigned aoff[4], boff[4];
@@ -534,13 +538,16 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_big_kernel(GemmArgs p) {
 #undef BIG_EP
   }
   if constexpr (DBG == 3) {
+    const unsigned long long t3 = __builtin_amdgcn_s_memtime();      // stores issued, not yet drained
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const unsigned long long t3 = __builtin_amdgcn_s_memtime();
-    if (lane == 0 && p.stamps) {
-      unsigned long long* o = p.stamps + ((size_t)blockIdx.x * 8 + wave) * 4;
-      o[0] = t0; o[1] = t1; o[2] = t2; o[3] = t3;
+    const unsigned long long t4 = __builtin_amdgcn_s_memtime();      // stores drained
+    if (lane == 0 && p.stamps && vid < 256 * 64) {
+      unsigned long long* o = p.stamps + ((size_t)vid * 8 + wave) * 5;
+      o[0] = t0; o[1] = t1; o[2] = t2; o[3] = t3; o[4] = t4;
     }
   }
+  __syncthreads();   // every wave has read its staging region back: the next tile's LDS-DMA may overwrite it
+  }  // persistent tile loop
 }
 
 }  // namespace dvd
@@ -607,7 +614,9 @@ extern "C" int dvd_gemm_nt(const dvd_gemm_desc* d, void* stream) {
       (void)hipFuncSetAttribute((const void*)gemm_nt_big_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
       once = true;
     }
-    dim3 gridb(p.ntm * p.ntn, d->batch);
+    int nblk = p.ntm * p.ntn;
+    if (nblk > 256 && !getenv("DVD_GEMM_NONPERSISTENT")) nblk = 256;
+    dim3 gridb(nblk, d->batch);
     if (p.debug == 1) gemm_nt_big_kernel<1><<<gridb, 512, LDS, (hipStream_t)stream>>>(p);
     else if (p.debug == 2) gemm_nt_big_kernel<2><<<gridb, 512, LDS, (hipStream_t)stream>>>(p);
     else if (p.debug == 3) gemm_nt_big_kernel<3><<<gridb, 512, LDS, (hipStream_t)stream>>>(p);
