@@ -1,0 +1,82 @@
+"""GPU tests of the drop-in surface: the reference's call sequence (create_model_and_diffusion -> load_state_dict
+-> .to(dev) -> ddim_sample_loop / model(x, t, **kw)) reproduces the CPU oracle, and val_TDiff.run(settings) runs
+end to end on synthetic documents."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from dvd_amd import synth
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def build(grid, steps):
+    import admin.settings as ws
+    from dvd_amd.script_util import args_to_dict, create_model_and_diffusion, model_and_diffusion_defaults
+    s = ws.Settings()
+    s.env.grid_size, s.env.diffusion_steps = grid, steps
+    s.name = "pytest"
+    model, diffusion = create_model_and_diffusion(device="cuda", train_mode=s.env.train_mode, tv=s.env.time_variant,
+                                                  grid_size=grid, **args_to_dict(s, model_and_diffusion_defaults().keys()))
+    sd = {k: torch.from_numpy(np.asarray(v)) for k, v in synth.synth_state_dict(grid, 7).items()}
+    model.cpu().load_state_dict(sd, strict=False)           # val_TDiff.py:79
+    model.to("cuda")
+    model.eval()
+    return s, model, diffusion
+
+
+def test_ddim_sample_loop_contract_vs_reference_golden():
+    """Same call as evaluation.py:121-135 (explicit noise = the golden x_T) against the real reference's loop."""
+    g = np.load(os.path.join(GOLD, "loop_g64_s3.npz"))
+    s, model, diffusion = build(64, 3)
+    doc = {k: torch.from_numpy(v)[None].cuda() for k, v in synth.synth_document(0, 64, 1234).items()}
+    kw = {"init_flow": torch.zeros(1, 2, 64, 64, device="cuda"), "src_feat": None, "src_64": None, "y512": doc["y512"],
+          "tmode": s.env.train_mode, "mask_cat": doc["mask_cat"], "init_feat": torch.zeros(1, 256, 64, 64, device="cuda"),
+          "iter": True, "mask_y512": doc["mask_y512"], "line_msk": doc["line_msk"]}
+    sample, final = diffusion.ddim_sample_loop(model, (1, 2, 64, 64), noise=torch.from_numpy(g["x_T"]), clip_denoised=False,
+                                               model_kwargs=kw, eta=0.0, progress=True, denoised_fn=None,
+                                               sampling_kwargs={"src_img": doc["y512"]}, logger=None, n_batch=2,
+                                               time_variant=True, pyramid=None)
+    assert tuple(sample.shape) == (1, 2, 64, 64) and set(final) == {"sample", "pred_xstart", "feat_dict"}
+    assert tuple(final["feat_dict"].shape) == (1, 256, 64, 64)
+    err = float(np.sqrt(((sample.cpu().numpy() - g["sample"]) ** 2).mean()))
+    assert err < 1e-3, err
+
+
+@pytest.mark.parametrize("tag", ["t2", "t1", "raw0", "raw600", "raw200"])
+def test_model_call_all_t_classes_vs_reference_golden(tag):
+    """model(x, t, **kwargs) -> (x0, feat) with an ARBITRARY init_feat, for every timestep class of the reference's
+    override rule (cross_model.py:575-580), against golden G2."""
+    grid = 16
+    g = np.load(os.path.join(GOLD, f"forward_g{grid}.npz"))
+    s, model, _ = build(grid, 3)
+    doc = {k: torch.from_numpy(v)[None].repeat(2, 1, 1, 1).cuda() for k, v in synth.synth_document(0, grid, 1234).items()}
+    init_feat = torch.from_numpy(synth.uniform("g2/init_feat", (2, 256, grid, grid), 0.0, 1.5, 1234)).cuda()
+    t = torch.full((2,), float(g[f"{tag}/t_in"]), device="cuda")
+    x0, feat = model(torch.from_numpy(g["x"]).cuda(), t, y512=doc["y512"], mask_y512=doc["mask_y512"],
+                     init_flow=torch.from_numpy(g["init_flow"]).cuda(), tv=True, tmode="stage_1_dit_cross",
+                     line_msk=doc["line_msk"], mask_cat=doc["mask_cat"], init_feat=init_feat, iter=True, mode=None)
+    err = float(np.sqrt(((x0.cpu().numpy() - g[f"{tag}/x0"]) ** 2).mean()))
+    assert err < 1e-3, (tag, err)
+    np.testing.assert_allclose(feat[0].cpu().numpy(), g["feat/full"], rtol=0, atol=2e-4)
+
+
+def test_plugin_run_end_to_end(tmp_path, monkeypatch):
+    """val_TDiff.run(settings): model + diffusion from settings, synthetic weights/documents, batched sampling,
+    full-resolution u8 unwarp."""
+    monkeypatch.chdir(tmp_path)
+    import admin.settings as ws
+    from dvd_amd import val_TDiff
+    s = ws.Settings()
+    s.env.grid_size, s.env.diffusion_steps = 16, 3
+    s.env.num_synthetic_docs, s.env.batch_docs, s.env.full_res = 3, 2, (96, 80)
+    s.env.visualize = True
+    s.name, s.seed, s.severity, s.corruption_number = "pytest", 0, 0, 0
+    results = val_TDiff.run(s)
+    assert len(results) == 3
+    for path, img in results:
+        assert img.dtype == torch.uint8 and tuple(img.shape) == (96, 80, 3)
+        assert os.path.exists(f"vis_hp/synthetic/pytest/dewarped_pred/warped_{path}.png")
