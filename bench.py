@@ -150,7 +150,7 @@ def main():
         if launches:
             avg_s = attn_ms / launches * 1e-3
             achieved = attn_launch_per_sample * n / avg_s / 1e12
-            roof = {"kernel": "flash_attn_kernel<256> (decoder self-attention, 6 heads x 256)", "bound": "mfma",
+            roof = {"kernel": "flash_attn_glds_kernel<256,0> (decoder self-attention, 6 heads x 256)", "bound": "mfma",
                     "achieved": round(achieved, 1), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved / PEAK_F16_TFLOPS, 4), "traffic": None,
                     "launches_timed": launches, "avg_launch_ms": round(avg_s * 1e3, 3),
