@@ -31,19 +31,52 @@ def bench_unwarp():
     flow = torch.nn.functional.interpolate(ctrl, size=(G, G), mode="bicubic", align_corners=True).contiguous().cuda()
     if os.environ.get("DVD_BENCH_RANDOM_FLOW"):
         flow = torch.from_numpy(synth.uniform("b/flow", (1, 2, G, G), -0.05, 0.05, 1)).cuda()
-    src8 = torch.from_numpy(synth.synth_document(0, 8, 1, full_res=(H, W))["src_u8"]).cuda()
-    srcf = src8.permute(2, 0, 1)[None].float().contiguous()
+    import ctypes as C
+    from dvd_amd import lib
+    NSET = 3                       # rotate 3 buffer sets (> 256 MiB in total) so the Infinity Cache cannot hold them
+    src8 = [torch.from_numpy(synth.synth_document(k, 8, 1, full_res=(H, W))["src_u8"]).cuda() for k in range(NSET)]
+    srcf = [s8.permute(2, 0, 1)[None].float().contiguous() for s8 in src8]
+    grid = [ops.unwarp_grid(flow, H, W) for _ in range(NSET)]
+    outf = [torch.empty(H, W, 3, device="cuda") for _ in range(NSET)]
+    out8 = [torch.empty(H, W, 3, dtype=torch.uint8, device="cuda") for _ in range(NSET)]
+    outc = [torch.empty(1, 3, H, W, device="cuda") for _ in range(NSET)]
+    st = lib.stream_ptr()
     px = H * W
     res = {}
-    t = timeit(lambda: ops.unwarp_f32(flow, srcf))
-    res["unwarp_f32_fused"] = {"ms": t * 1e3, "GBps_algo(24B/px)": 24 * px / t / 1e9}
-    t = timeit(lambda: ops.unwarp_u8(flow, src8))
-    res["unwarp_u8_fused"] = {"ms": t * 1e3, "GBps_algo(6B/px)": 6 * px / t / 1e9}
-    grid = ops.unwarp_grid(flow, H, W)
-    t = timeit(lambda: ops.unwarp_grid(flow, H, W))
+    it = [0]
+
+    def rot():
+        it[0] = (it[0] + 1) % NSET
+        return it[0]
+
+    def f32():
+        k = rot()
+        lib.call("dvd_unwarp_f32", lib.ptr(flow), G, lib.ptr(srcf[k]), lib.ptr(outf[k]), H, W, C.c_float(0.987), st)
+
+    def u8():
+        k = rot()
+        lib.call("dvd_unwarp_u8", lib.ptr(flow), G, lib.ptr(src8[k]), lib.ptr(out8[k]), H, W, C.c_float(0.987), st)
+
+    def gs():
+        k = rot()
+        lib.call("dvd_grid_sample_bilinear_zeros_ac", lib.ptr(srcf[k]), lib.ptr(grid[k]), lib.ptr(outc[k]), 1, 3, H, W, H, W, 1, st)
+
+    def gg():
+        k = rot()
+        lib.call("dvd_unwarp_grid", lib.ptr(flow), G, lib.ptr(grid[k]), H, W, C.c_float(0.987), st)
+
+    for tag, extra in (("", {}), ("_scalar_fallback", {"DVD_WARP_SCALAR": "1"})):
+        os.environ.update(extra)
+        t = timeit(f32, iters=60)
+        res["unwarp_f32_fused" + tag] = {"ms": t * 1e3, "GBps_algo(24B/px)": 24 * px / t / 1e9}
+        t = timeit(u8, iters=60)
+        res["unwarp_u8_fused" + tag] = {"ms": t * 1e3, "GBps_algo(6B/px)": 6 * px / t / 1e9}
+        t = timeit(gs, iters=60)
+        res["grid_sample_dropin" + tag] = {"ms": t * 1e3, "GBps_algo(32B/px)": 32 * px / t / 1e9}
+        for k in extra:
+            os.environ.pop(k)
+    t = timeit(gg, iters=60)
     res["unwarp_grid"] = {"ms": t * 1e3, "GBps_algo(8B/px)": 8 * px / t / 1e9}
-    t = timeit(lambda: ops.grid_sample(srcf, grid))
-    res["grid_sample_dropin"] = {"ms": t * 1e3, "GBps_algo(32B/px)": 32 * px / t / 1e9}
     a = torch.empty(px * 8, dtype=torch.float32, device="cuda")
     b = torch.empty_like(a)
     t = timeit(lambda: b.copy_(a))

@@ -19,7 +19,7 @@ if which == "gemm":
         ops.gemm_nt(a, b, out16=out)
 elif which in ("attn256", "attn64"):
     hd = 256 if which == "attn256" else 64
-    B, T = (2, 20736) if hd == 256 else (8, 20736)
+    B, T = (int(os.environ.get("PROBE_B", "2")), 20736) if hd == 256 else (int(os.environ.get("PROBE_B", "8")), 20736)
     C = 6 * hd
     qk = torch.randn(B, T, 2 * C, device="cuda").half()
     vt = torch.randn(B, C, T, device="cuda").half()

@@ -2,8 +2,13 @@
 // (datasets/utils/warping.py:50-73) and the fused full-resolution unwarp tail
 // (train_settings/dvd/evaluation.py:301-306 + utils_flow/visualization_utils.py:75-77).
 //
-// All of these are HBM/L2-bound gathers: one lane per output pixel along x so that the grid
-// reads, the taps of a smooth warp and the stores of a wave are contiguous runs.
+// All of these are HBM/L2-bound gathers.  Fast kernels: one WAVE per run of an output row (lane-consecutive pixels,
+// so grid reads, the taps of a smooth warp and the stores of every wave instruction are contiguous runs), the two
+// x-neighbours of a tap row fetched as ONE 8-byte (f32) / 12-byte (u8 RGB pair) load, wave-uniform plane/row bases in
+// SGPRs with 32-bit lane offsets, streaming (nt) grid loads and output stores.  Measured on MI355X at 3508x2480x3 f32
+// (benchmarks/lab/warp_lab.hip): 4.4 TB/s on the 32 B/px drop-in contract against 5.6 TB/s for a plain copy of the same
+// streams; the 1-pixel-per-lane-x-4-rows scalar kernels (kept below for win < 2, unaligned widths and > 4 GiB planes)
+// reach 3.5 TB/s.
 #include "common.h"
 #include "mfma.h"
 
@@ -13,7 +18,8 @@ namespace dvd {
 __device__ __forceinline__ float unnorm(float g, int size) { return ((g + 1.f) * 0.5f) * (float)(size - 1); }
 
 // Branch-free bilinear taps (zeros padding): out-of-range taps get weight 0 and a clamped (always valid)
-// address, so all four loads of a pixel issue unconditionally and back-to-back.
+// address, so all four loads of a pixel issue unconditionally and back-to-back.  A NaN / infinite coordinate gives a
+// NaN output pixel, as F.grid_sample does.
 struct Taps {
   int o00, o01, o10, o11;      // element offsets (row * pitch + col) of the four taps, clamped in range
   float w00, w01, w10, w11;
@@ -38,6 +44,8 @@ __device__ __forceinline__ Taps make_taps(float gx, float gy, int hin, int win, 
   t.w01 = (x1ok && y0ok) ? w01 : 0.f;
   t.w10 = (x0ok && y1ok) ? w10 : 0.f;
   t.w11 = (x1ok && y1ok) ? w11 : 0.f;
+  if (!(fabsf(ix) < __builtin_inff()) || !(fabsf(iy) < __builtin_inff()))
+    t.w00 = t.w01 = t.w10 = t.w11 = __builtin_nanf("");   // non-finite coordinate: NaN out, as ATen (inf - inf weights)
   const int xc0 = min(max(x0, 0), win - 1), xc1 = min(max(x0 + 1, 0), win - 1);
   const int yc0 = min(max(y0, 0), hin - 1), yc1 = min(max(y0 + 1, 0), hin - 1);
   t.o00 = yc0 * pitch + xc0;
@@ -46,6 +54,60 @@ __device__ __forceinline__ Taps make_taps(float gx, float gy, int hin, int win, 
   t.o11 = yc1 * pitch + xc1;
   return t;
 }
+
+
+// Pair taps: the two x-neighbours of a tap row are one load at column bx = clamp(x0, 0, win-2).  The weights are
+// re-targeted onto (bx, bx+1) so an out-of-range tap contributes exactly 0 (zeros padding); in range they are the
+// same products, blended in the same order, as the scalar kernels - results are bit-identical.
+struct PTaps {
+  int r0, r1;                  // element offsets (row * pitch + bx) of the upper / lower tap row, clamped in range
+  float a00, a01, a10, a11;    // weights of (r0, bx), (r0, bx+1), (r1, bx), (r1, bx+1)
+};
+
+__device__ __forceinline__ PTaps make_ptaps(float gx, float gy, int hin, int win, int pitch) {
+  PTaps t;
+  const float ix = unnorm(gx, win), iy = unnorm(gy, hin);
+  float fx = floorf(ix), fy = floorf(iy);
+  const float ex = fx + 1.f, ey = fy + 1.f;
+  const float wx0 = ex - ix, wx1 = ix - fx, wy0 = ey - iy, wy1 = iy - fy;
+  fx = fminf(fmaxf(fx, -2.f), (float)win);
+  fy = fminf(fmaxf(fy, -2.f), (float)hin);
+  if (!(ix == ix)) fx = -2.f;
+  if (!(iy == iy)) fy = -2.f;
+  const int x0 = (int)fx, y0 = (int)fy;
+  const int bx = min(max(x0, 0), win - 2);
+  const float cl = (x0 == bx) ? wx0 : ((x0 + 1 == bx) ? wx1 : 0.f);        // weight landing on column bx
+  const float cr = (x0 == bx) ? wx1 : ((x0 == bx + 1) ? wx0 : 0.f);        // ... on column bx + 1
+  const bool y0ok = y0 >= 0 && y0 < hin, y1ok = y0 + 1 >= 0 && y0 + 1 < hin;
+  t.a00 = y0ok ? cl * wy0 : 0.f;
+  t.a01 = y0ok ? cr * wy0 : 0.f;
+  t.a10 = y1ok ? cl * wy1 : 0.f;
+  t.a11 = y1ok ? cr * wy1 : 0.f;
+  if (!(fabsf(ix) < __builtin_inff()) || !(fabsf(iy) < __builtin_inff()))
+    t.a00 = t.a01 = t.a10 = t.a11 = __builtin_nanf("");   // non-finite coordinate: NaN out, as ATen (inf - inf weights)
+  const int yc0 = min(max(y0, 0), hin - 1), yc1 = min(max(y0 + 1, 0), hin - 1);
+  t.r0 = yc0 * pitch + bx;
+  t.r1 = yc1 * pitch + bx;
+  return t;
+}
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x3 __attribute__((ext_vector_type(3)));
+struct __attribute__((packed, aligned(4))) PackedF2 { float a, b; };
+struct __attribute__((packed, aligned(4))) PackedF3 { float a, b, c; };
+struct __attribute__((packed, aligned(4))) PackedU3 { uint32_t a, b, c; };
+
+// 8-byte load at a 4-byte-aligned address: wave-uniform base + 32-bit lane byte offset (saddr + voffset form)
+__device__ __forceinline__ f32x2 load_pair(const float* base, uint32_t byte_off) {
+  const PackedF2 v = *reinterpret_cast<const PackedF2*>(reinterpret_cast<const char*>(base) + byte_off);
+  return f32x2{v.a, v.b};
+}
+__device__ __forceinline__ float blend(f32x2 u, f32x2 d, const PTaps& t) {
+  return ((u[0] * t.a00 + u[1] * t.a01) + d[0] * t.a10) + d[1] * t.a11;
+}
+
+constexpr int KR = 4;    // rows per wave of the f32 fast kernels (vertically adjacent pixels per lane)
+constexpr int CG = 3;    // channels whose gathers are in flight together in the drop-in kernel
 
 constexpr int PX = 4;   // output pixels per thread: PX consecutive ROWS at one x.  A wave-instruction then still
                         // reads/writes one contiguous run (1 px per lane) while 4x as many loads are in flight,
@@ -85,6 +147,57 @@ __global__ void __launch_bounds__(256) grid_sample_nchw_kernel(const float* __re
       if (y0 + k < h)
         o[(size_t)ch * hw + (size_t)(y0 + k) * w] =
             ((v[k][0] * t[k].w00 + v[k][1] * t[k].w01) + v[k][2] * t[k].w10) + v[k][3] * t[k].w11;
+  }
+}
+
+
+// Fast path (win >= 2, plane < 4 GiB).  Wave = 64 consecutive x  x  KR consecutive rows (a lane owns KR vertically
+// adjacent pixels, whose tap rows overlap in L1); block = 4 waves stacked in y.
+__global__ void __launch_bounds__(256) grid_sample_rows_kernel(const float* __restrict__ src,
+                                                               const float* __restrict__ grid,
+                                                               float* __restrict__ out, int c, int hin, int win,
+                                                               int h, int w, int src_batch_div) {
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int n = blockIdx.z;
+  const int yb = (blockIdx.y * 4 + wv) * KR;            // wave-uniform
+  if (yb >= h) return;
+  const bool live = blockIdx.x * 64u + lane < (uint32_t)w;
+  const uint32_t xb = min(blockIdx.x * 64u + lane, (uint32_t)w - 1u) * 4u;
+  const size_t hw = (size_t)h * w;
+  const size_t plane = (size_t)hin * win;
+  const float* g = grid + (size_t)n * 2 * hw;
+  PTaps t[KR];
+#pragma unroll
+  for (int k = 0; k < KR; ++k) {
+    const float* grow = g + (size_t)min(yb + k, h - 1) * w;
+    const float gx = __builtin_nontemporal_load(reinterpret_cast<const float*>(reinterpret_cast<const char*>(grow) + xb));
+    const float gy = __builtin_nontemporal_load(reinterpret_cast<const float*>(reinterpret_cast<const char*>(grow + hw) + xb));
+    t[k] = make_ptaps(gx, gy, hin, win, win);
+  }
+  const float* s = src + (size_t)(n / src_batch_div) * c * plane;
+  float* o = out + (size_t)n * c * hw;
+  for (int ch0 = 0; ch0 < c; ch0 += CG) {
+    f32x2 u[CG][KR], d[CG][KR];
+#pragma unroll
+    for (int j = 0; j < CG; ++j) {
+      const float* pc = s + (size_t)min(ch0 + j, c - 1) * plane;     // uniform
+#pragma unroll
+      for (int k = 0; k < KR; ++k) {
+        u[j][k] = load_pair(pc, (uint32_t)t[k].r0 * 4u);
+        d[j][k] = load_pair(pc, (uint32_t)t[k].r1 * 4u);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < CG; ++j) {
+      if (ch0 + j >= c) break;
+#pragma unroll
+      for (int k = 0; k < KR; ++k)
+        if (live && yb + k < h)
+          __builtin_nontemporal_store(
+              blend(u[j][k], d[j][k], t[k]),
+              reinterpret_cast<float*>(reinterpret_cast<char*>(o + (size_t)(ch0 + j) * hw + (size_t)(yb + k) * w) + xb));
+    }
   }
 }
 
@@ -202,6 +315,101 @@ __global__ void __launch_bounds__(256) unwarp_u8_kernel(const float* __restrict_
   }
 }
 
+
+// Fast fused f32 tail (w >= 2, plane < 4 GiB): same wave shape; the output is HWC, so a lane's three channels are one
+// 12-byte store and a wave instruction writes 768 contiguous bytes.
+__global__ void __launch_bounds__(256) unwarp_f32_rows_kernel(const float* __restrict__ flow,
+                                                              const float* __restrict__ src,
+                                                              float* __restrict__ out, UpParams p) {
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int ib = (blockIdx.y * 4 + wv) * KR;
+  if (ib >= p.h) return;
+  const bool live = blockIdx.x * 64u + lane < (uint32_t)p.w;
+  const uint32_t j = min(blockIdx.x * 64u + lane, (uint32_t)p.w - 1u);
+  PTaps t[KR];
+#pragma unroll
+  for (int k = 0; k < KR; ++k) {
+    float gx, gy;
+    flow_grid_at(flow, p, min(ib + k, p.h - 1), (int)j, gx, gy);
+    t[k] = make_ptaps(gx, gy, p.h, p.w, p.w);
+  }
+  const size_t plane = (size_t)p.h * p.w;
+  f32x2 u[3][KR], d[3][KR];
+#pragma unroll
+  for (int ch = 0; ch < 3; ++ch)
+#pragma unroll
+    for (int k = 0; k < KR; ++k) {
+      u[ch][k] = load_pair(src + ch * plane, (uint32_t)t[k].r0 * 4u);
+      d[ch][k] = load_pair(src + ch * plane, (uint32_t)t[k].r1 * 4u);
+    }
+#pragma unroll
+  for (int k = 0; k < KR; ++k)
+    if (live && ib + k < p.h) {
+      PackedF3 o{blend(u[0][k], d[0][k], t[k]), blend(u[1][k], d[1][k], t[k]), blend(u[2][k], d[2][k], t[k])};
+      *reinterpret_cast<PackedF3*>(reinterpret_cast<char*>(out + (size_t)(ib + k) * p.w * 3) + j * 12u) = o;
+    }
+}
+
+// Fast fused u8 tail (w % 4 == 0, image < 4 GiB): a lane owns 4 consecutive pixels of a row.  The RGB pair of a tap
+// row is 6 consecutive bytes at byte offset 3*(row*w + bx): one 12-byte load at the 4-byte-aligned address below it
+// (moved back inside the image at its very end) and two v_alignbyte; the lane's 12 output bytes are one 12-byte store.
+__device__ __forceinline__ void load_rgb_pair(const uint8_t* __restrict__ src, uint32_t off, uint32_t last_base,
+                                              uint32_t& lo, uint32_t& hi) {
+  // bytes [off, off + 6): lo = bytes 0..3, hi = bytes 4..5 (upper half unspecified)
+  const uint32_t base = min(off & ~3u, last_base);
+  uint32_t sh = off - base;                                 // 0..6
+  const PackedU3 v = *reinterpret_cast<const PackedU3*>(src + base);
+  uint32_t d0 = v.a, d1 = v.b, d2 = v.c;
+  if (sh >= 4u) { d0 = d1; d1 = d2; d2 = 0u; sh -= 4u; }
+  lo = __builtin_amdgcn_alignbyte(d1, d0, sh);
+  hi = __builtin_amdgcn_alignbyte(d2, d1, sh);
+}
+
+__global__ void __launch_bounds__(256) unwarp_u8_rows_kernel(const float* __restrict__ flow,
+                                                             const uint8_t* __restrict__ src,
+                                                             uint8_t* __restrict__ out, UpParams p) {
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int i = blockIdx.y * 4 + wv;
+  if (i >= p.h) return;
+  const uint32_t j0 = (blockIdx.x * 64 + lane) * 4;
+  if (j0 >= (uint32_t)p.w) return;
+  const uint32_t last_base = (uint32_t)p.h * (uint32_t)p.w * 3u - 12u;
+  PTaps t[4];
+  uint32_t ulo[4], uhi[4], dlo[4], dhi[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    float gx, gy;
+    flow_grid_at(flow, p, i, (int)(j0 + k), gx, gy);
+    t[k] = make_ptaps(gx, gy, p.h, p.w, p.w);
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    load_rgb_pair(src, (uint32_t)t[k].r0 * 3u, last_base, ulo[k], uhi[k]);
+    load_rgb_pair(src, (uint32_t)t[k].r1 * 3u, last_base, dlo[k], dhi[k]);
+  }
+  uint32_t ob[12];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    // left pixel = bytes 0,1,2; right pixel = bytes 3 (lo), 4,5 (hi)
+    const float ul[3] = {(float)(ulo[k] & 255u), (float)((ulo[k] >> 8) & 255u), (float)((ulo[k] >> 16) & 255u)};
+    const float ur[3] = {(float)(ulo[k] >> 24), (float)(uhi[k] & 255u), (float)((uhi[k] >> 8) & 255u)};
+    const float dl[3] = {(float)(dlo[k] & 255u), (float)((dlo[k] >> 8) & 255u), (float)((dlo[k] >> 16) & 255u)};
+    const float dr[3] = {(float)(dlo[k] >> 24), (float)(dhi[k] & 255u), (float)((dhi[k] >> 8) & 255u)};
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+      const float a = ((ul[ch] * t[k].a00 + ur[ch] * t[k].a01) + dl[ch] * t[k].a10) + dr[ch] * t[k].a11;
+      ob[k * 3 + ch] = (uint32_t)(int)a & 255u;             // truncation, as numpy .astype(uint8) for 0 <= a < 256
+    }
+  }
+  PackedU3 o;
+  o.a = ob[0] | (ob[1] << 8) | (ob[2] << 16) | (ob[3] << 24);
+  o.b = ob[4] | (ob[5] << 8) | (ob[6] << 16) | (ob[7] << 24);
+  o.c = ob[8] | (ob[9] << 8) | (ob[10] << 16) | (ob[11] << 24);
+  *reinterpret_cast<PackedU3*>(out + ((size_t)i * p.w + j0) * 3) = o;
+}
+
 static UpParams make_up(int g, int h, int w, float scale) {
   UpParams p;
   p.g = g;
@@ -219,6 +427,12 @@ static UpParams make_up(int g, int h, int w, float scale) {
 
 using namespace dvd;
 
+// DVD_WARP_SCALAR=1 forces the 1-pixel-per-lane fallback kernels (A/B runs and the fallback's own tests)
+static bool scalar_warp() {
+  const char* e = getenv("DVD_WARP_SCALAR");
+  return e && e[0] == '1';
+}
+
 extern "C" int dvd_grid_sample_bilinear_zeros_ac(const float* src, const float* grid, float* out, int n, int c,
                                                  int hin, int win, int h, int w, int src_batch_div, void* stream) {
   DVD_REQUIRE(src && grid && out, "grid_sample: null pointer");
@@ -227,6 +441,11 @@ extern "C" int dvd_grid_sample_bilinear_zeros_ac(const float* src, const float* 
   if (n == 0) return DVD_OK;
   DVD_REQUIRE(h <= 65535 && n <= 65535, "grid_sample: h or n exceeds the 65535 grid limit");
   DVD_REQUIRE(cdiv(h, 4) <= 65535, "grid_sample: h too large");
+  if (win >= 2 && (size_t)hin * win * 4 < (1ull << 32) && (size_t)w * 4 < (1ull << 32) && !scalar_warp()) {
+    dim3 grd(cdiv(w, 64), cdiv(h, 4 * KR), n);
+    grid_sample_rows_kernel<<<grd, 256, 0, (hipStream_t)stream>>>(src, grid, out, c, hin, win, h, w, src_batch_div);
+    return check_launch("grid_sample");
+  }
   const int bx = w >= 256 ? 256 : (w > 64 ? 128 : 64);
   dim3 grd(cdiv(w, bx), cdiv(h, 4), n);
   grid_sample_nchw_kernel<<<grd, bx, 0, (hipStream_t)stream>>>(src, grid, out, c, hin, win, h, w, src_batch_div);
@@ -250,6 +469,11 @@ extern "C" int dvd_unwarp_grid(const float* flow, int g, float* grid_out, int h,
 extern "C" int dvd_unwarp_f32(const float* flow, int g, const float* src_chw, float* out_hwc, int h, int w,
                               float scale, void* stream) {
   if (int e = unwarp_args(flow, src_chw, out_hwc, g, h, w)) return e;
+  if (w >= 2 && (size_t)h * w * 12 < (1ull << 32) && !scalar_warp()) {
+    dim3 grd(cdiv(w, 64), cdiv(h, 4 * KR));
+    unwarp_f32_rows_kernel<<<grd, 256, 0, (hipStream_t)stream>>>(flow, src_chw, out_hwc, make_up(g, h, w, scale));
+    return check_launch("unwarp_f32");
+  }
   dim3 grd(cdiv(w, 256), cdiv(h, 4));
   unwarp_f32_kernel<<<grd, 256, 0, (hipStream_t)stream>>>(flow, src_chw, out_hwc, make_up(g, h, w, scale));
   return check_launch("unwarp_f32");
@@ -258,6 +482,11 @@ extern "C" int dvd_unwarp_f32(const float* flow, int g, const float* src_chw, fl
 extern "C" int dvd_unwarp_u8(const float* flow, int g, const uint8_t* src_hwc, uint8_t* out_hwc, int h, int w,
                              float scale, void* stream) {
   if (int e = unwarp_args(flow, src_hwc, out_hwc, g, h, w)) return e;
+  if (w % 4 == 0 && (size_t)h * w * 3 < (1ull << 32) && (size_t)h * w * 3 >= 12 && !scalar_warp()) {
+    dim3 grd(cdiv(w, 256), cdiv(h, 4));
+    unwarp_u8_rows_kernel<<<grd, 256, 0, (hipStream_t)stream>>>(flow, src_hwc, out_hwc, make_up(g, h, w, scale));
+    return check_launch("unwarp_u8");
+  }
   dim3 grd(cdiv(w, 256), cdiv(h, 4));
   unwarp_u8_kernel<<<grd, 256, 0, (hipStream_t)stream>>>(flow, src_hwc, out_hwc, make_up(g, h, w, scale));
   return check_launch("unwarp_u8");

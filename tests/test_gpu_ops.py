@@ -108,6 +108,74 @@ def test_unwarp_full_size_properties(ops):
     assert float((of2 - 0.5 * of).abs().max()) < 1e-3
 
 
+def _both_paths(fn):
+    """Run fn() with the row-per-wave fast kernels and again with the scalar fallback kernels (DVD_WARP_SCALAR=1)."""
+    os.environ.pop("DVD_WARP_SCALAR", None)
+    fast = fn()
+    os.environ["DVD_WARP_SCALAR"] = "1"
+    try:
+        slow = fn()
+    finally:
+        os.environ.pop("DVD_WARP_SCALAR", None)
+    return fast, slow
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 37, 53, 41, 129), (1, 7, 64, 2, 5, 200), (1, 2, 9, 1, 8, 8), (1, 9, 33, 65, 3, 1)])
+def test_grid_sample_fast_equals_fallback_and_oracle(ops, shape):
+    """Pair-gather kernel == scalar kernel bit for bit (same products, same blend order), incl. wild / non-finite
+    coordinates, borders, win = 2 (every tap pair clamped) and win = 1 (fast path not applicable)."""
+    from oracle import dvd_oracle as O
+    n, c, hin, win, h, w = shape
+    src = torch.from_numpy(synth.uniform("gsf/src", (n, c, hin, win), -1, 1, 5))
+    grid = torch.from_numpy(synth.uniform("gsf/grid", (n, 2, h, w), -1.4, 1.4, 5))
+    flat = grid.view(-1)
+    flat[0], flat[1], flat[2] = 1.0, -1.0, 1e30
+    flat[3], flat[4] = float("inf"), -1e30
+    ref = O.grid_sample_ref(src, grid).numpy()
+    fast, slow = _both_paths(lambda: ops.grid_sample(src.cuda(), grid.cuda()).cpu().numpy())
+    assert np.array_equal(fast, slow, equal_nan=True)
+    assert np.array_equal(np.isnan(fast), np.isnan(ref))           # inf coordinate -> NaN pixel, like ATen
+    np.testing.assert_allclose(fast, ref, rtol=0, atol=2e-6, equal_nan=True)
+    gn = grid.clone()
+    gn.view(-1)[5] = float("nan")
+    ref = O.grid_sample_ref(src, gn).numpy()
+    fast, slow = _both_paths(lambda: ops.grid_sample(src.cuda(), gn.cuda()).cpu().numpy())
+    assert np.array_equal(fast, slow, equal_nan=True)
+    assert np.array_equal(np.isnan(fast), np.isnan(ref))
+
+
+@pytest.mark.parametrize("hw", [(97, 132), (64, 4), (31, 130), (5, 8)])
+def test_unwarp_fast_equals_fallback(ops, hw):
+    """Fused tails: fast kernels == scalar kernels bit for bit, flows that push taps outside the image on all sides;
+    widths that are / are not multiples of 4 (the u8 fast path needs w % 4 == 0)."""
+    H, W = hw
+    G = 16
+    flow = torch.from_numpy(synth.uniform("uwf/flow", (1, 2, G, G), -0.2, 0.2, 9)).cuda()
+    src8 = torch.from_numpy(synth.uniform("uwf/src", (H, W, 3), 0.0, 256.0, 9).astype(np.uint8)).cuda()
+    srcf = src8.permute(2, 0, 1)[None].float().contiguous()
+    f_fast, f_slow = _both_paths(lambda: ops.unwarp_f32(flow, srcf, scale=1.05).cpu().numpy())
+    assert np.array_equal(f_fast, f_slow)
+    u_fast, u_slow = _both_paths(lambda: ops.unwarp_u8(flow, src8, scale=1.05).cpu().numpy())
+    assert np.array_equal(u_fast, u_slow)
+    assert np.array_equal(u_fast, np.clip(f_fast.astype(np.int32), 0, 255).astype(np.uint8))
+    assert (f_fast == 0).any() and (f_fast > 0).any()        # zero padding was exercised
+
+
+def test_unwarp_full_size_fast_equals_fallback(ops):
+    H, W, G = 3508, 2480, 288
+    ctrl = torch.from_numpy(synth.uniform("uwf/ctrl", (1, 2, 6, 6), -0.05, 0.05, 1))
+    flow = torch.nn.functional.interpolate(ctrl, size=(G, G), mode="bicubic", align_corners=True).contiguous().cuda()
+    src8 = torch.from_numpy(synth.synth_document(1, 8, 1234, full_res=(H, W))["src_u8"]).cuda()
+    u_fast, u_slow = _both_paths(lambda: ops.unwarp_u8(flow, src8))
+    assert torch.equal(u_fast, u_slow)
+    srcf = src8.permute(2, 0, 1)[None].float().contiguous()
+    grid = ops.unwarp_grid(flow, H, W)
+    g_fast, g_slow = _both_paths(lambda: ops.grid_sample(srcf, grid))
+    assert torch.equal(g_fast, g_slow)
+    f_fast = ops.unwarp_f32(flow, srcf)
+    assert torch.equal(f_fast.permute(2, 0, 1)[None], g_fast)    # fused tail == materialised grid + drop-in
+
+
 def test_sched_step_golden(ops):
     from dvd_amd import schedule
     g = load("ddim_step.npz")
