@@ -297,6 +297,21 @@ __device__ __forceinline__ void glds_one(const char* gbase, unsigned voff, unsig
       : "memory");
 }
 
+
+// O^T *= alpha with the accumulators LEFT IN AGPRs.  Written as `o[dt][i] *= alpha` the compiler keeps O in AGPRs for
+// the MFMAs but copies all 128 registers to VGPRs at the top of EVERY tile for the (rare) rescale branch
+// (128 v_accvgpr_read per tile, ~10 % of the tile); here the round trip exists only inside the branch.
+__device__ __forceinline__ void scale_acc_in_agpr(floatx16& acc, float alpha) {
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    float x = acc[i], tmp;
+    asm volatile("v_accvgpr_read_b32 %1, %0\n\tv_mul_f32 %1, %1, %2\n\ts_nop 0\n\tv_accvgpr_write_b32 %0, %1"
+                 : "+a"(x), "=&v"(tmp)
+                 : "v"(alpha));
+    acc[i] = x;
+  }
+}
+
 // ================================================================================================
 // Fast path (tk % 64 == 0: every shape the engine produces): K / V^T tiles go global -> LDS DIRECTLY
 // (global_load_lds_dwordx4, 1 KiB per wave-instruction, no staging registers, no ds_write).  The LDS
@@ -353,6 +368,11 @@ __global__ void __launch_bounds__(256, (D == 256 ? 1 : 2)) flash_attn_glds_kerne
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const half8*)(qp + 16 * ks);
   }
+  // The compiler cannot see the inline-asm vmcnt(0) below; left alone it sinks its own waits for these KS loads into
+  // the tile loop as vmcnt(15), vmcnt(14), ... before the MFMAs that first use qf[ks] - which, vmcnt being in-order,
+  // makes every tile's S^T phase wait for the LDS-DMA loads of the NEXT tile issued just before it.  Retire the Q
+  // loads here with a wait the compiler does track (vmcnt(0); expcnt / lgkmcnt untouched).
+  __builtin_amdgcn_s_waitcnt(0x0F70);
 
   // ---- per-lane SOURCE offsets (bytes) of the direct-to-LDS loads, swizzled
   unsigned koff[KINST], voff[VINST];
@@ -461,10 +481,15 @@ __global__ void __launch_bounds__(256, (D == 256 ? 1 : 2)) flash_attn_glds_kerne
       const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
       m_run = m_new;
       l_run *= alpha;
+      if constexpr (D == 256) {
 #pragma unroll
-      for (int dt = 0; dt < DT; ++dt)
+        for (int dt = 0; dt < DT; ++dt) scale_acc_in_agpr(o[dt], alpha);
+      } else {                      // head_dim 64: the 32 accumulators live in VGPRs, plain VALU multiply
 #pragma unroll
-        for (int i = 0; i < 16; ++i) o[dt][i] *= alpha;
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) o[dt][i] *= alpha;
+      }
     }
     float rs = 0.f;
     half8 pf[4];
