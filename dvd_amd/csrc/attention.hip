@@ -325,7 +325,7 @@ __device__ __forceinline__ void scale_acc_in_agpr(floatx16& acc, float alpha) {
 // architectural VGPRs and the 128 O^T accumulators stay in AGPRs untouched by the VALU: the v1
 // structure spent ~400 v_accvgpr moves per tile shuffling spilled state.
 // ================================================================================================
-template <int D, int DBG>   // DBG 1: accumulate per-phase s_memtime deltas (diagnostic build, DVD_ATTN_DEBUG=1)
+template <int D, int DBG>   // DBG bit 0: accumulate per-phase s_memtime deltas (DVD_ATTN_DEBUG=1); bit 1: bulk load issue (DVD_ATTN_BULK=1)
 __global__ void __launch_bounds__(256, (D == 256 ? 1 : 2)) flash_attn_glds_kernel(AttnArgs p) {
   constexpr int KB = 64;
   constexpr int KROWB = 2 * D;             // K row bytes (512 / 128)
@@ -436,7 +436,7 @@ __global__ void __launch_bounds__(256, (D == 256 ? 1 : 2)) flash_attn_glds_kerne
   int cur = 0;
   unsigned long long acc_t[5] = {0, 0, 0, 0, 0};
 #define STAMP(k_)                                                              \
-  if constexpr (DBG == 1) {                                                    \
+  if constexpr (DBG & 1) {                                                    \
     __builtin_amdgcn_sched_barrier(0);                                         \
     const unsigned long long now_ = __builtin_amdgcn_s_memtime();              \
     __builtin_amdgcn_s_waitcnt(0xC07F);                                        \
@@ -445,12 +445,28 @@ __global__ void __launch_bounds__(256, (D == 256 ? 1 : 2)) flash_attn_glds_kerne
     __builtin_amdgcn_sched_barrier(0);                                         \
   }
   unsigned long long tprev = 0;
-  if constexpr (DBG == 1) tprev = __builtin_amdgcn_s_memtime();
+  if constexpr (DBG & 1) tprev = __builtin_amdgcn_s_memtime();
+  // Next-tile loads.  SPREAD (default): one 1-KiB LDS-DMA load after every 3rd MFMA, S^T product first - the CU's
+  // L2->LDS path moves ~33 B/clk, so the 16 loads of a wave issued back to back stall ~120 cycles EACH with the
+  // matrix pipe idle (30 % of the tile); spread over the tile the path is ~60 % busy and an issue rarely stalls.  The
+  // tile index is clamped instead of branching (the last tile is re-loaded into the idle buffer, harmlessly).
+  // BULK (DBG 2/3, DVD_ATTN_BULK=1): the burst at the top of the tile, kept for A/B runs.
+  constexpr bool SPREAD = (DBG < 2);
+  constexpr bool STAMPS = (DBG & 1);
   for (int t = 0; t < nt; ++t) {
-    // all 16 LDS-DMA loads of the next tile are issued here in one burst (~120 cycles each, matrix pipe idle: 36 %
-    // of the tile).  Interleaving them one by one between the MFMAs was measured and is WORSE (each then costs
-    // 60-180 cycles inside the MFMA/ds_read stream: 6442 vs 5335 cycles per tile); see DESIGN.md.
-    if (t + 1 < nt) DVD_GLDS_ISSUE(t + 1, cur ^ 1)
+    if constexpr (!SPREAD) {
+      if (t + 1 < nt) DVD_GLDS_ISSUE(t + 1, cur ^ 1)
+    }
+    const int tn = min(t + 1, nt - 1);
+    const char* kg_next = Kg + (size_t)tn * ktile;
+    const char* vg_next = Vg + (size_t)tn * (KB * 2);
+    const unsigned lds_next = lds0 + (cur ^ 1) * BUF;
+#define GLDS_K(i_) glds_one(kg_next, koff[i_], lds_next + (KINST * wave + (i_)) * 1024)
+#define GLDS_V(i_) glds_one(vg_next, voff[i_], lds_next + KBYTES + (VINST * wave + (i_)) * 1024)
+    // load g of the tile (K loads first) goes after MFMA number GAP*g + GAP-1 of the tile's 64 (S^T then PV): all are
+    // issued in the first ~3/4 of the tile so that the last has landed (L2 latency ~500 cycles) by the tile's barrier
+    constexpr int NG = KINST + VINST, GAP = 3;
+#define GLDS_ANY(g_) if ((g_) < KINST) { GLDS_K((g_) < KINST ? (g_) : 0); } else { GLDS_V((g_) >= KINST ? (g_) - KINST : 0); }
     STAMP(0)
     const char* base = smem + cur * BUF;
     half8 fr[8];
@@ -465,6 +481,9 @@ __global__ void __launch_bounds__(256, (D == 256 ? 1 : 2)) flash_attn_glds_kerne
     for (int i = 0; i < NS; ++i) {
       s[i & 1] = mfma32_f16(fr[i & 7], qf[i >> 1], s[i & 1]);
       if (i + 4 < NS) { KLOAD(i + 4); } else { VLOAD(i + 4 - NS); }
+      if constexpr (SPREAD) {
+        if (i % GAP == GAP - 1 && i / GAP < NG) { GLDS_ANY(i / GAP) }
+      }
       SB();
     }
 
@@ -514,6 +533,9 @@ __global__ void __launch_bounds__(256, (D == 256 ? 1 : 2)) flash_attn_glds_kerne
 #pragma unroll
         for (int e = dt * per; e < (dt + 1) * per && e < 8; ++e) PEXP(c + 1, e)
       }
+      if constexpr (SPREAD) {
+        if ((NS + j) % GAP == GAP - 1 && (NS + j) / GAP < NG) { GLDS_ANY((NS + j) / GAP) }
+      }
       SB();
     }
     l_run += rs;
@@ -524,13 +546,16 @@ __global__ void __launch_bounds__(256, (D == 256 ? 1 : 2)) flash_attn_glds_kerne
     STAMP(4)
     cur ^= 1;
   }
-  if constexpr (DBG == 1) {
+  if constexpr (DBG & 1) {
     if (lane == 0 && p.stamps) {
       unsigned long long* o_ = p.stamps + ((size_t)blockIdx.x * 4 + wave) * 5;
       for (int k = 0; k < 5; ++k) o_[k] = acc_t[k];
     }
   }
 #undef STAMP
+#undef GLDS_K
+#undef GLDS_V
+#undef GLDS_ANY
 #undef SB
 #undef KLOAD
 #undef VLOAD
@@ -789,13 +814,19 @@ extern "C" int dvd_flash_attn(const dvd_attn_desc* d, void* stream) {
     if (!once2) {
       (void)hipFuncSetAttribute((const void*)flash_attn_glds_kernel<256, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
       (void)hipFuncSetAttribute((const void*)flash_attn_glds_kernel<256, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+      (void)hipFuncSetAttribute((const void*)flash_attn_glds_kernel<256, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+      (void)hipFuncSetAttribute((const void*)flash_attn_glds_kernel<256, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
       once2 = true;
     }
-    if (getenv("DVD_ATTN_DEBUG")) flash_attn_glds_kernel<256, 1><<<(unsigned)nwg, 256, LDS, (hipStream_t)stream>>>(p);
+    const int variant = (getenv("DVD_ATTN_DEBUG") ? 1 : 0) | (getenv("DVD_ATTN_BULK") ? 2 : 0);
+    if (variant == 3) flash_attn_glds_kernel<256, 3><<<(unsigned)nwg, 256, LDS, (hipStream_t)stream>>>(p);
+    else if (variant == 2) flash_attn_glds_kernel<256, 2><<<(unsigned)nwg, 256, LDS, (hipStream_t)stream>>>(p);
+    else if (variant == 1) flash_attn_glds_kernel<256, 1><<<(unsigned)nwg, 256, LDS, (hipStream_t)stream>>>(p);
     else flash_attn_glds_kernel<256, 0><<<(unsigned)nwg, 256, LDS, (hipStream_t)stream>>>(p);
   } else if (fast) {
     constexpr int LDS = 2 * (64 * 128 + 64 * 128);
-    flash_attn_glds_kernel<64, 0><<<(unsigned)nwg, 256, LDS, (hipStream_t)stream>>>(p);
+    if (getenv("DVD_ATTN_BULK")) flash_attn_glds_kernel<64, 2><<<(unsigned)nwg, 256, LDS, (hipStream_t)stream>>>(p);
+    else flash_attn_glds_kernel<64, 0><<<(unsigned)nwg, 256, LDS, (hipStream_t)stream>>>(p);
   } else if (d->head_dim == 256) {
     constexpr int LDS = 2 * (64 * (2 * 256 + 16) + 256 * (2 * 64 + 16));
     static bool once = false;
