@@ -26,6 +26,10 @@
 #include "mfma.h"
 #include <stdlib.h>
 
+#ifndef DVD_ATTN_PF
+#define DVD_ATTN_PF 4
+#endif
+
 namespace dvd {
 
 struct AttnArgs {
@@ -429,8 +433,10 @@ __global__ void __launch_bounds__(256, (D == 256 ? 1 : 2)) flash_attn_glds_kerne
 #define SB() __builtin_amdgcn_sched_barrier(0)
 // S^T step i works on key block (i & 1) and k-step (i >> 1): the two 16-deep accumulation chains alternate, so
 // consecutive MFMAs never depend on each other (a single dependent chain ran at ~58 cycles per MFMA, not 32)
-#define KLOAD(i_) fr[(i_) & 7] = *(const half8*)(base + kfrag[(i_) >> 1] + ((i_) & 1) * 32 * KROWB)
-#define VLOAD(j_) fr[(j_) & 7] = *(const half8*)(base + vfrag[(j_) / DT] + ((j_) % DT) * 32 * 128)
+#define KLOAD(i_) fr[(i_) & FM] = *(const half8*)(base + kfrag[(i_) >> 1] + ((i_) & 1) * 32 * KROWB)
+#define VLOAD(j_) fr[(j_) & FM] = *(const half8*)(base + vfrag[(j_) / DT] + ((j_) % DT) * 32 * 128)
+  // fragment reads in flight ahead of their MFMA: LDS latency grows under the concurrent LDS-DMA writes
+  constexpr int PF = (D == 256) ? DVD_ATTN_PF : 4, FM = 2 * PF - 1;
   constexpr int NS = 2 * KS;     // MFMAs of the first product per tile
   constexpr int NP = 4 * DT;     // MFMAs of the second product per tile
   int cur = 0;
@@ -469,18 +475,19 @@ __global__ void __launch_bounds__(256, (D == 256 ? 1 : 2)) flash_attn_glds_kerne
 #define GLDS_ANY(g_) if ((g_) < KINST) { GLDS_K((g_) < KINST ? (g_) : 0); } else { GLDS_V((g_) >= KINST ? (g_) - KINST : 0); }
     STAMP(0)
     const char* base = smem + cur * BUF;
-    half8 fr[8];
+    half8 fr[FM + 1];
     floatx16 s[2];
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int i = 0; i < 16; ++i) s[kb][i] = 0.f;
-    KLOAD(0); KLOAD(1); KLOAD(2); KLOAD(3);
+#pragma unroll
+    for (int i = 0; i < PF; ++i) KLOAD(i);
     SB();
 #pragma unroll
     for (int i = 0; i < NS; ++i) {
-      s[i & 1] = mfma32_f16(fr[i & 7], qf[i >> 1], s[i & 1]);
-      if (i + 4 < NS) { KLOAD(i + 4); } else { VLOAD(i + 4 - NS); }
+      s[i & 1] = mfma32_f16(fr[i & FM], qf[i >> 1], s[i & 1]);
+      if (i + PF < NS) { KLOAD(i + PF); } else { VLOAD(i + PF - NS); }
       if constexpr (SPREAD) {
         if (i % GAP == GAP - 1 && i / GAP < NG) { GLDS_ANY(i / GAP) }
       }
@@ -526,8 +533,8 @@ __global__ void __launch_bounds__(256, (D == 256 ? 1 : 2)) flash_attn_glds_kerne
 #pragma unroll
     for (int j = 0; j < NP; ++j) {
       const int c = j / DT, dt = j % DT;
-      o[dt] = mfma32_f16(fr[j & 7], pf[c], o[dt]);
-      if (j + 4 < NP) VLOAD(j + 4);
+      o[dt] = mfma32_f16(fr[j & FM], pf[c], o[dt]);
+      if (j + PF < NP) VLOAD(j + PF);
       if (c < 3) {                          // P chunk c+1: DT MFMA gaps for 8 elements
         constexpr int per = (8 + DT - 1) / DT;
 #pragma unroll
