@@ -354,6 +354,18 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(GemmArgs p) {
 //     synchronisation of the 128 x 128 kernel, whose waves spent > 50 % of their cycles parked (SQ_WAIT_ANY).
 // Same split-weight accumulation order and the same epilogue as gemm_nt_kernel.
 // ================================================================================================
+// one 1-KiB LDS-DMA load (issued between MFMA groups, see the K loop)
+__device__ __forceinline__ void glds_one4(const char* gbase, unsigned voff, unsigned lds) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %1\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "s"(gbase), "s"(lds), "v"(voff)
+      : "memory", "scc");
+}
+
 template <int N>
 __device__ __forceinline__ void glds_group4(const char* gbase, const unsigned (&voff)[N], unsigned lds) {
   static_assert(N == 4, "unsupported group size");
@@ -467,8 +479,19 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_big_kernel(GemmArgs p) {
   __syncthreads();
   if constexpr (DBG == 3) t1 = __builtin_amdgcn_s_memtime();
   int cur = 0;
+  // Next-slab loads: all 8 of a wave in a burst at the top of the slab (default; with two waves per SIMD the burst of
+  // one wave hides under the MFMAs of the other).  DBG 4 (DVD_GEMM_SPREAD=1) spreads them over the slab instead (one
+  // 1-KiB load after every second group of two MFMAs): measured 3 % SLOWER here (811 vs 840 TF/s at N=K=1536), unlike
+  // the one-wave-per-SIMD attention kernel where spreading gained 10 %.
+  constexpr bool SPREAD = (DBG == 4);
   for (int kt = 0; kt < nk; ++kt) {
-    if (DBG != 1 && kt + 1 < nk) BIG_ISSUE(kt + 1, cur ^ 1)
+    if (!SPREAD && DBG != 1 && kt + 1 < nk) BIG_ISSUE(kt + 1, cur ^ 1)
+    const int tnx = min(kt + 1, nk - 1);
+    const bool lo_nx = tnx < nlo;
+    const size_t kb_nx = (size_t)(lo_nx ? tnx : tnx - nlo) * (BK * 2);
+    const char* a_nx = (lo_nx ? Alotile : Atile) + kb_nx;
+    const char* b_nx = (lo_nx ? Blotile : Btile) + kb_nx;
+    const unsigned lds_nx = lds0 + (cur ^ 1) * 2 * TILE + (4 * wave) * 1024;
     const char* base = smem + cur * 2 * TILE;
     if constexpr (DBG == 2) {   // ablation: loads + barrier only
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -490,6 +513,11 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_big_kernel(GemmArgs p) {
         if (s4 < 3) {
           fa[cs ^ 1][m] = *(const half8*)(base + a_base + m * 32 * 128 + frag[s4 + 1]);
           if (m < 2) fb[cs ^ 1][m] = *(const half8*)(base + b_base + m * 32 * 128 + frag[s4 + 1]);
+        }
+        if constexpr (SPREAD) {
+          const int g = s4 * 4 + m;                       // 16 MFMA groups per slab, a load after every odd one
+          if ((g & 1) && (g >> 1) < 4) glds_one4(a_nx, aoff[(g >> 1) & 3], lds_nx + ((g >> 1) & 3) * 1024);
+          if ((g & 1) && (g >> 1) >= 4) glds_one4(b_nx, boff[(g >> 1) & 3], lds_nx + TILE + ((g >> 1) & 3) * 1024);
         }
         SB();
       }
@@ -612,6 +640,7 @@ extern "C" int dvd_gemm_nt(const dvd_gemm_desc* d, void* stream) {
       (void)hipFuncSetAttribute((const void*)gemm_nt_big_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
       (void)hipFuncSetAttribute((const void*)gemm_nt_big_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
       (void)hipFuncSetAttribute((const void*)gemm_nt_big_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+      (void)hipFuncSetAttribute((const void*)gemm_nt_big_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
       once = true;
     }
     int nblk = p.ntm * p.ntn;
@@ -620,6 +649,7 @@ extern "C" int dvd_gemm_nt(const dvd_gemm_desc* d, void* stream) {
     if (p.debug == 1) gemm_nt_big_kernel<1><<<gridb, 512, LDS, (hipStream_t)stream>>>(p);
     else if (p.debug == 2) gemm_nt_big_kernel<2><<<gridb, 512, LDS, (hipStream_t)stream>>>(p);
     else if (p.debug == 3) gemm_nt_big_kernel<3><<<gridb, 512, LDS, (hipStream_t)stream>>>(p);
+    else if (getenv("DVD_GEMM_SPREAD")) gemm_nt_big_kernel<4><<<gridb, 512, LDS, (hipStream_t)stream>>>(p);
     else gemm_nt_big_kernel<0><<<gridb, 512, LDS, (hipStream_t)stream>>>(p);
     return check_launch("gemm_nt(big)");
   }
