@@ -17,6 +17,9 @@ for _ in range(2):
 torch.cuda.synchronize()
 s = st.view(nwg * 4, 5).cpu().double() / (T // 64)
 names = ["issue LDS-DMA (16 loads)", "S^T phase (32 MFMA)", "max/rescale + P chunk 0", "PV phase (32 MFMA) + softmax", "vmcnt(0) + barrier"]
+if os.environ.get("DVD_ATTN_PIPE"):   # software-pipelined kernel: per 64-key tile = 2 blocks
+    names = ["2 x (K prefetch issue + max tree + rescale test)", "2 x (16 S^T MFMA || 13 exps)", "2 x (16 PV MFMA || 3 exps, sa+sb)",
+             "2 x vmcnt wait", "2 x s_barrier"]
 tot = s.sum(1).mean()
 for k, n in enumerate(names):
     print(f"{n:34s} {s[:, k].mean():8.0f} cycles/tile  {100 * s[:, k].mean() / tot:5.1f}%")

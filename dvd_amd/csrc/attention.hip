@@ -50,6 +50,16 @@ __device__ __forceinline__ int kappa(int r) {  // swap bits 2 and 3
   return (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1);
 }
 
+// max over the two 32-lane halves of a wave without the LDS: v_permlane32_swap (new on gfx950) exchanges the upper half
+// of its first operand with the lower half of its second; with both = x the two results hold x.lo and x.hi in every
+// lane.  (__shfl_xor(x, 32) compiles to ds_bpermute_b32, an LDS instruction whose lgkmcnt wait also drains every
+// fragment read in flight.)
+__device__ __forceinline__ float half_swap_max(float x) {
+  float a = x, b = x;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+  return fmaxf(a, b);
+}
+
 template <int D>
 __global__ void __launch_bounds__(256, (D == 256 ? 1 : 2)) flash_attn_kernel(AttnArgs p) {
   constexpr int KB = 64;                 // keys per tile
@@ -184,7 +194,7 @@ __global__ void __launch_bounds__(256, (D == 256 ? 1 : 2)) flash_attn_kernel(Att
 #pragma unroll
       for (int i = 0; i < 16; ++i) mx = fmaxf(mx, s[kb][i]);
     mx *= p.c;                                  // c > 0
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    mx = half_swap_max(mx);
     // Deferred rescale (guide T13): keep the running max stale while this tile's max exceeds it by less than
     // RESCALE_THR (log2 units).  P then lies in (0, 2^THR] instead of (0, 1]: f16 keeps the same RELATIVE
     // precision there, and the fp32 accumulators O^T / l have ample range.  The decision is wave-uniform and
@@ -501,7 +511,7 @@ __global__ void __launch_bounds__(256, (D == 256 ? 1 : 2)) flash_attn_glds_kerne
 #pragma unroll
       for (int i = 0; i < 16; ++i) mx = fmaxf(mx, s[kb][i]);
     mx *= p.c;
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    mx = half_swap_max(mx);
     if (__any(mx - m_run > RESCALE_THR)) {     // deferred rescale, see flash_attn_kernel
       const float m_new = fmaxf(m_run, mx);
       const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
@@ -567,6 +577,247 @@ __global__ void __launch_bounds__(256, (D == 256 ? 1 : 2)) flash_attn_glds_kerne
 #undef KLOAD
 #undef VLOAD
 #undef PEXP
+
+  const float l_tot = l_run + __shfl_xor(l_run, 32);
+  const float inv = 1.f / l_tot;
+  const int qglob = qb * 128 + wave * 32 + r;
+  if (qglob < p.tq) {
+    _Float16* op = p.O + b * p.sO + (size_t)qglob * p.ldo + (size_t)head * D;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) {
+        half4 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = (_Float16)(o[dt][4 * g4 + j] * inv);
+        *(half4*)(op + 32 * dt + 8 * g4 + 4 * h) = v;
+      }
+  }
+}
+
+
+// ================================================================================================
+// head_dim 256, SOFTWARE-PIPELINED over 32-key half tiles ("blocks").  Same data movement, LDS image, fragment maps and
+// arithmetic per element as flash_attn_glds_kernel<256>; what changes is the order of work inside a wave.  There the
+// softmax of a 64-key tile (max, rescale test, first exps: ~500 cycles) runs with the matrix pipe idle.  Here block u's
+// softmax VALU is interleaved with the 16 MFMAs of S^T(u+1), and its PV product with the combine of the next
+// accumulators:
+//     iteration u:   (a) S^T(u+1) = K(u+1).Q^T  [16 MFMA]  ||  softmax(u): max, rescale test, 13 of 16 exps
+//                    (b) O^T += V^T(u).P(u)      [16 MFMA]  ||  last 3 exps, s(u+1) = sa + sb
+//                    wait for the loads issued one block ago, barrier
+// The online softmax therefore steps per 32 keys (deferred rescale as before).  S^T(u+1) accumulates into two
+// registers sets (even / odd k-steps) because one dependent chain of MFMAs issues at ~58 instead of 32 cycles each.
+// LDS-DMA loads: V^T(t+1) during the first block of tile t, K(t+2) during the second (each has a whole block of slack
+// before its first use, so the end-of-block wait is vmcnt(8), not vmcnt(0)).
+// MEASURED (MI355X, DVD_ATTN_PIPE=1): correct (parity tests pass) but SLOWER, 830 vs 975 TF/s.  Stamps per 64-key tile:
+// block heads 860 cycles, MFMA phases 1678 + 1607, waiting for the LDS-DMA loads 1018, barriers 141 = 5303 against
+// 3751 for flash_attn_glds_kernel.  The CU's LDS port is the real limit (fragment reads alone are 4 waves x 1 KiB per
+// 32-cycle MFMA = 128 B/clk = its peak); with the softmax window filled by MFMAs + fragment reads the LDS-DMA WRITES
+// find no free port cycles and pile up to the end of the block, where every wave then waits for them.  In the
+// non-pipelined kernel the ~450-cycle softmax head is exactly the window in which those writes drain.  Not the default.
+// ================================================================================================
+template <int DBG>
+__global__ void __launch_bounds__(256, 1) flash_attn_pipe_kernel(AttnArgs p) {
+  constexpr int D = 256, KB = 64, KROWB = 512, KCPR = 32, KBYTES = KB * KROWB, VBYTES = D * 128, BUF = KBYTES + VBYTES;
+  constexpr int KINST = 8, VINST = 8, KS = 16, DT = 8;
+  constexpr float RESCALE_THR = 10.f;
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][BUF]
+  typedef __attribute__((address_space(3))) void* lptr_t;
+
+  const int nwg = gridDim.x;
+  int id = blockIdx.x;
+  {
+    const int q = nwg / 8, rr = nwg % 8, xcd = id % 8, k = id / 8;
+    id = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + k;
+  }
+  const int qb = id % p.nqb;
+  const int bh = id / p.nqb;
+  const int head = bh % p.heads, b = bh / p.heads;
+  const int kvb = b / p.kv_div;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+
+  const _Float16* Qg = p.Q + b * p.sQ + (size_t)head * D;
+  const char* Kg = (const char*)(p.K + kvb * p.sK + (size_t)head * D);
+  const char* Vg = (const char*)(p.Vt + kvb * p.sVt + (size_t)head * D * p.ldvt);
+
+  const int qrow = min(qb * 128 + wave * 32 + r, p.tq - 1);
+  half8 qf[KS];
+  {
+    const _Float16* qp = Qg + (size_t)qrow * p.ldq + 8 * h;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const half8*)(qp + 16 * ks);
+  }
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // retire the Q loads with a wait the compiler tracks (see flash_attn_glds_kernel)
+
+  unsigned koff[KINST], voff[VINST];
+#pragma unroll
+  for (int i = 0; i < KINST; ++i) {
+    const int q = (KINST * wave + i) * 64 + lane;
+    const int row = q / KCPR, pos = q % KCPR;
+    koff[i] = (unsigned)row * (unsigned)(p.ldk * 2) + (unsigned)((pos ^ (row & 15)) * 16);
+  }
+#pragma unroll
+  for (int i = 0; i < VINST; ++i) {
+    const int q = (VINST * wave + i) * 64 + lane;
+    const int row = q / 8, pos = q % 8;
+    voff[i] = (unsigned)row * (unsigned)(p.ldvt * 2) + (unsigned)((pos ^ ((row >> 1) & 7)) * 16);
+  }
+  const int kr = kappa(r);
+  int kfrag[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) kfrag[ks] = kr * KROWB + (((2 * ks + h) ^ (kr & 15)) * 16);
+  const int fv = (r >> 1) & 7;
+  int vfrag[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) vfrag[c] = KBYTES + r * 128 + (((2 * c + h) ^ fv) * 16);
+
+  floatx16 o[DT];
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) o[dt][i] = 0.f;
+  float m_run = -1e30f, l_run = 0.f;
+  const int nt = p.tk / KB;
+  const size_t ktile = (size_t)KB * p.ldk * 2;
+  const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t)smem;
+
+  // prologue: K(0), V^T(0) -> buffer 0, K(1) -> buffer 1
+  glds_group<KINST>(Kg, koff, lds0 + (KINST * wave) * 1024);
+  glds_group<VINST>(Vg, voff, lds0 + KBYTES + (VINST * wave) * 1024);
+  if (nt > 1) glds_group<KINST>(Kg + ktile, koff, lds0 + BUF + (KINST * wave) * 1024);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+#define SB() __builtin_amdgcn_sched_barrier(0)
+  unsigned long long acc_t[5] = {0, 0, 0, 0, 0};
+  unsigned long long tprev = 0;
+#define STAMP(k_)                                                              \
+  if constexpr (DBG & 1) {                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                         \
+    const unsigned long long now_ = __builtin_amdgcn_s_memtime();              \
+    __builtin_amdgcn_s_waitcnt(0xC07F);                                        \
+    acc_t[k_] += now_ - tprev;                                                 \
+    tprev = now_;                                                              \
+    __builtin_amdgcn_sched_barrier(0);                                         \
+  }
+  half8 fr[8];
+  floatx16 sa, sb, sc;
+  // ---- S^T(0), not overlapped
+  {
+    const char* kbase = smem;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { sa[i] = 0.f; sb[i] = 0.f; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) fr[i] = *(const half8*)(kbase + kfrag[i]);
+    SB();
+#pragma unroll
+    for (int i = 0; i < KS; ++i) {
+      if (i & 1) sb = mfma32_f16(fr[i & 7], qf[i], sb); else sa = mfma32_f16(fr[i & 7], qf[i], sa);
+      if (i + 4 < KS) fr[(i + 4) & 7] = *(const half8*)(kbase + kfrag[i + 4]);
+      SB();
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) sc[i] = sa[i] + sb[i];
+  }
+  if constexpr (DBG & 1) tprev = __builtin_amdgcn_s_memtime();
+
+  // One block.  HB_: which half of tile t holds block u (compile-time).  kbase_/kb_: where S^T(u+1) reads K;
+  // ISSUE_: the 8 loads of this block (macro taking the load index 0..7).
+#define PEXPB(e_)                                                                              \
+  {                                                                                            \
+    const float pv_ = __builtin_amdgcn_exp2f(fmaf(sc[e_], p.c, -m_run));                       \
+    rs += pv_;                                                                                 \
+    pf[(e_) >> 3][(e_) & 7] = (_Float16)pv_;                                                   \
+  }
+#define ATTN_BLOCK(HB_, kbase_, kbofs_, ISSUE_, nloads_)                                        \
+  {                                                                                            \
+    const char* kb_ = (kbase_) + (kbofs_);                                                     \
+    _Pragma("unroll") for (int i = 0; i < 16; ++i) { sa[i] = 0.f; sb[i] = 0.f; }                \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) fr[i] = *(const half8*)(kb_ + kfrag[i]);     \
+    /* max tree of block u while the first fragments arrive */                                 \
+    float mx = fmaxf(fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3])), fmaxf(fmaxf(sc[4], sc[5]), fmaxf(sc[6], sc[7]))); \
+    mx = fmaxf(mx, fmaxf(fmaxf(fmaxf(sc[8], sc[9]), fmaxf(sc[10], sc[11])), fmaxf(fmaxf(sc[12], sc[13]), fmaxf(sc[14], sc[15])))); \
+    mx *= p.c;                                                                                 \
+    mx = half_swap_max(mx);                                                        \
+    if (__any(mx - m_run > RESCALE_THR)) {                                                     \
+      const float m_new = fmaxf(m_run, mx);                                                    \
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);                               \
+      m_run = m_new;                                                                           \
+      l_run *= alpha;                                                                          \
+      /* the PV MFMAs of the previous block were issued > 200 cycles ago; be explicit anyway */ \
+      asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");               \
+      _Pragma("unroll") for (int dt = 0; dt < DT; ++dt) scale_acc_in_agpr(o[dt], alpha);       \
+    }                                                                                          \
+    float rs = 0.f;                                                                            \
+    half8 pf[2];                                                                               \
+    STAMP(0)                                                                                   \
+    SB();                                                                                      \
+    _Pragma("unroll") for (int i = 0; i < KS; ++i) {                                           \
+      if (i & 1) sb = mfma32_f16(fr[i & 7], qf[i], sb); else sa = mfma32_f16(fr[i & 7], qf[i], sa); \
+      if (i + 4 < KS) fr[(i + 4) & 7] = *(const half8*)(kb_ + kfrag[i + 4]);                   \
+      else fr[(i + 4) & 7] = *(const half8*)(vb_ + vfrag[2 * (HB_)] + (i + 4 - KS) * 32 * 128); \
+      if (i >= 3) PEXPB(i - 3)                                                                 \
+      if ((i & 3) == 3 && (nloads_)) { ISSUE_(i >> 2) }                                        \
+      SB();                                                                                    \
+    }                                                                                          \
+    STAMP(1)                                                                                   \
+    _Pragma("unroll") for (int j = 0; j < 16; ++j) {                                           \
+      const int cl = j >> 3, dt = j & 7;                                                       \
+      o[dt] = mfma32_f16(fr[(j + 16) & 7], pf[cl], o[dt]);                                     \
+      if (j + 4 < 16) fr[(j + 20) & 7] = *(const half8*)(vb_ + vfrag[2 * (HB_) + ((j + 4) >> 3)] + ((j + 4) & 7) * 32 * 128); \
+      if (j < 3) PEXPB(13 + j)                                                                 \
+      if (j >= 4 && j < 12) { sc[2 * (j - 4)] = sa[2 * (j - 4)] + sb[2 * (j - 4)]; sc[2 * (j - 4) + 1] = sa[2 * (j - 4) + 1] + sb[2 * (j - 4) + 1]; } \
+      if ((j & 3) == 3 && (nloads_)) { ISSUE_(4 + (j >> 2)) }                                   \
+      SB();                                                                                    \
+    }                                                                                          \
+    l_run += rs;                                                                               \
+    STAMP(2)                                                                                   \
+  }
+
+  for (int t = 0; t < nt; ++t) {
+    const char* cbase = smem + (t & 1) * BUF;
+    const char* vb_ = cbase;
+    // ---- block 2t: S^T of the second half of tile t; loads V^T(t+1) -> buffer (t+1)&1
+    {
+      const bool ld = t + 1 < nt;
+      const char* vg_n = Vg + (size_t)(t + 1) * (KB * 2);
+      const unsigned lds_n = lds0 + ((t + 1) & 1) * BUF + KBYTES + (VINST * wave) * 1024;
+#define ISSUE_V(i_) glds_one(vg_n, voff[i_], lds_n + (i_) * 1024);
+      ATTN_BLOCK(0, cbase, 32 * KROWB, ISSUE_V, ld)
+#undef ISSUE_V
+      if (ld) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      STAMP(3)
+      __syncthreads();
+      STAMP(4)
+    }
+    // ---- block 2t+1: S^T of the first half of tile t+1 (at the very end: recomputed on tile t, unused);
+    //      loads K(t+2) -> buffer t&1 (K(t) was last read in the block above)
+    {
+      const bool ld = t + 2 < nt;
+      const char* kg_n = Kg + (size_t)(t + 2) * ktile;
+      const unsigned lds_n = lds0 + (t & 1) * BUF + (KINST * wave) * 1024;
+      const char* nbase = (t + 1 < nt) ? smem + ((t + 1) & 1) * BUF : cbase + 32 * KROWB;
+#define ISSUE_K(i_) glds_one(kg_n, koff[i_], lds_n + (i_) * 1024);
+      ATTN_BLOCK(1, nbase, 0, ISSUE_K, ld)
+#undef ISSUE_K
+      if (ld) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      STAMP(3)
+      __syncthreads();
+      STAMP(4)
+    }
+  }
+  if constexpr (DBG & 1) {
+    if (lane == 0 && p.stamps) {
+      unsigned long long* o_ = p.stamps + ((size_t)blockIdx.x * 4 + wave) * 5;
+      for (int k = 0; k < 5; ++k) o_[k] = acc_t[k];
+    }
+  }
+#undef ATTN_BLOCK
+#undef PEXPB
+#undef STAMP
+#undef SB
 
   const float l_tot = l_run + __shfl_xor(l_run, 32);
   const float inv = 1.f / l_tot;
@@ -715,7 +966,7 @@ __global__ void __launch_bounds__(512, 2) flash_attn_dsplit_kernel(AttnArgs p) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) mx = fmaxf(mx, s[kb][i]);
     mx *= p.c;
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    mx = half_swap_max(mx);
     if (__any(mx - m_run > RESCALE_THR)) {
       const float m_new = fmaxf(m_run, mx);
       const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
@@ -824,6 +1075,17 @@ extern "C" int dvd_flash_attn(const dvd_attn_desc* d, void* stream) {
       (void)hipFuncSetAttribute((const void*)flash_attn_glds_kernel<256, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
       (void)hipFuncSetAttribute((const void*)flash_attn_glds_kernel<256, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
       once2 = true;
+    }
+    static bool once4 = false;
+    if (!once4) {
+      (void)hipFuncSetAttribute((const void*)flash_attn_pipe_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+      (void)hipFuncSetAttribute((const void*)flash_attn_pipe_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+      once4 = true;
+    }
+    if (getenv("DVD_ATTN_PIPE")) {   // EXPERIMENT, slower (830 vs 975 TF/s): see the kernel's header
+      if (getenv("DVD_ATTN_DEBUG")) flash_attn_pipe_kernel<1><<<(unsigned)nwg, 256, LDS, (hipStream_t)stream>>>(p);
+      else flash_attn_pipe_kernel<0><<<(unsigned)nwg, 256, LDS, (hipStream_t)stream>>>(p);
+      return check_launch("flash_attn");
     }
     const int variant = (getenv("DVD_ATTN_DEBUG") ? 1 : 0) | (getenv("DVD_ATTN_BULK") ? 2 : 0);
     if (variant == 3) flash_attn_glds_kernel<256, 3><<<(unsigned)nwg, 256, LDS, (hipStream_t)stream>>>(p);
