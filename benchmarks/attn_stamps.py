@@ -5,7 +5,8 @@ sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")
 import ctypes as C
 import torch
 from dvd_amd import lib, ops
-hd, B, T = 256, 2, 20736
+hd = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+B, T = (2 if hd == 256 else 8), 20736
 Cc = 6 * hd
 qk = torch.randn(B, T, 2 * Cc, device="cuda").half(); vt = torch.randn(B, Cc, T, device="cuda").half()
 out = torch.empty(B, T, Cc, dtype=torch.float16, device="cuda")
@@ -13,7 +14,7 @@ nwg = (T // 128) * 6 * B
 st = torch.zeros(nwg * 4 * 5, dtype=torch.int64, device="cuda")
 lib.call("dvd_attn_debug_stamps", C.c_void_p(st.data_ptr()))
 for _ in range(2):
-    ops.flash_attn(qk[:, :, :Cc], qk[:, :, Cc:], vt, out, 6, hd, 1.0 / 16)
+    ops.flash_attn(qk[:, :, :Cc], qk[:, :, Cc:], vt, out, 6, hd, 1.0 / (hd ** 0.5))
 torch.cuda.synchronize()
 s = st.view(nwg * 4, 5).cpu().double() / (T // 64)
 names = ["issue LDS-DMA (16 loads)", "S^T phase (32 MFMA)", "max/rescale + P chunk 0", "PV phase (32 MFMA) + softmax", "vmcnt(0) + barrier"]
@@ -23,4 +24,4 @@ if os.environ.get("DVD_ATTN_PIPE"):   # software-pipelined kernel: per 64-key ti
 tot = s.sum(1).mean()
 for k, n in enumerate(names):
     print(f"{n:34s} {s[:, k].mean():8.0f} cycles/tile  {100 * s[:, k].mean() / tot:5.1f}%")
-print(f"total {tot:.0f} cycles per tile (MFMA minimum 2048)")
+print(f"total {tot:.0f} cycles per tile (MFMA minimum {2048 if hd == 256 else 512})")

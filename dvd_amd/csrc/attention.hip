@@ -26,6 +26,9 @@
 #include "mfma.h"
 #include <stdlib.h>
 
+#ifndef DVD_ATTN64_OCC
+#define DVD_ATTN64_OCC 2   /* 3 waves per SIMD fit (140 VGPRs) and measure the same 838 TF/s; 4 spill */
+#endif
 #ifndef DVD_ATTN_PF
 #define DVD_ATTN_PF 4
 #endif
@@ -340,7 +343,7 @@ __device__ __forceinline__ void scale_acc_in_agpr(floatx16& acc, float alpha) {
 // structure spent ~400 v_accvgpr moves per tile shuffling spilled state.
 // ================================================================================================
 template <int D, int DBG>   // DBG bit 0: accumulate per-phase s_memtime deltas (DVD_ATTN_DEBUG=1); bit 1: bulk load issue (DVD_ATTN_BULK=1)
-__global__ void __launch_bounds__(256, (D == 256 ? 1 : 2)) flash_attn_glds_kernel(AttnArgs p) {
+__global__ void __launch_bounds__(256, (D == 256 ? 1 : DVD_ATTN64_OCC)) flash_attn_glds_kernel(AttnArgs p) {
   constexpr int KB = 64;
   constexpr int KROWB = 2 * D;             // K row bytes (512 / 128)
   constexpr int KCPR = KROWB / 16;         // chunks per K row (32 / 8)
@@ -420,6 +423,17 @@ __global__ void __launch_bounds__(256, (D == 256 ? 1 : 2)) flash_attn_glds_kerne
 #pragma unroll
     for (int i = 0; i < 16; ++i) o[dt][i] = 0.f;
   float m_run = -1e30f, l_run = 0.f;
+  // EXPERIMENT (off): take the softmax row sums off the VALU - an all-ones V^T row block makes one extra MFMA per P chunk
+  // accumulate sum_k P[k, q] into osum (4 MFMAs per tile instead of 32 v_add_f32).  Correct, but head_dim 64 measured
+  // the same with it (861 vs 895 TF/s, inside the box-to-box noise), as it did with two query row blocks per wave and
+  // with three waves per SIMD: none of LDS traffic, barrier count, VALU adds or occupancy is what holds it at ~36 %.
+  constexpr bool MFMA_ROWSUM = false;
+  floatx16 osum;
+  half8 ones8;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) osum[i] = 0.f;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) ones8[i] = (_Float16)1.f;
   const int nt = p.tk / KB;
   const size_t ktile = (size_t)KB * p.ldk * 2;   // bytes between K tiles
 
@@ -517,6 +531,10 @@ __global__ void __launch_bounds__(256, (D == 256 ? 1 : 2)) flash_attn_glds_kerne
       const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
       m_run = m_new;
       l_run *= alpha;
+      if constexpr (MFMA_ROWSUM) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) osum[i] *= alpha;
+      }
       if constexpr (D == 256) {
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) scale_acc_in_agpr(o[dt], alpha);
@@ -533,7 +551,7 @@ __global__ void __launch_bounds__(256, (D == 256 ? 1 : 2)) flash_attn_glds_kerne
 #define PEXP(c_, e_)                                                                             \
   {                                                                                              \
     const float pv_ = __builtin_amdgcn_exp2f(fmaf(s[(c_) >> 1][8 * ((c_) & 1) + (e_)], p.c, -m_run)); \
-    rs += pv_;                                                                                   \
+    if constexpr (!MFMA_ROWSUM) rs += pv_;                                                       \
     pf[c_][e_] = (_Float16)pv_;                                                                  \
   }
 #pragma unroll
@@ -544,6 +562,9 @@ __global__ void __launch_bounds__(256, (D == 256 ? 1 : 2)) flash_attn_glds_kerne
     for (int j = 0; j < NP; ++j) {
       const int c = j / DT, dt = j % DT;
       o[dt] = mfma32_f16(fr[j & FM], pf[c], o[dt]);
+      if constexpr (MFMA_ROWSUM) {
+        if (dt == DT - 1) osum = mfma32_f16(ones8, pf[c], osum);
+      }
       if (j + PF < NP) VLOAD(j + PF);
       if (c < 3) {                          // P chunk c+1: DT MFMA gaps for 8 elements
         constexpr int per = (8 + DT - 1) / DT;
@@ -578,7 +599,7 @@ __global__ void __launch_bounds__(256, (D == 256 ? 1 : 2)) flash_attn_glds_kerne
 #undef VLOAD
 #undef PEXP
 
-  const float l_tot = l_run + __shfl_xor(l_run, 32);
+  const float l_tot = MFMA_ROWSUM ? osum[0] : l_run + __shfl_xor(l_run, 32);
   const float inv = 1.f / l_tot;
   const int qglob = qb * 128 + wave * 32 + r;
   if (qglob < p.tq) {
@@ -592,6 +613,206 @@ __global__ void __launch_bounds__(256, (D == 256 ? 1 : 2)) flash_attn_glds_kerne
         for (int j = 0; j < 4; ++j) v[j] = (_Float16)(o[dt][4 * g4 + j] * inv);
         *(half4*)(op + 32 * dt + 8 * g4 + 4 * h) = v;
       }
+  }
+}
+
+
+// ================================================================================================
+// head_dim 64, TWO 32-row query blocks per wave (a workgroup = 4 waves = 256 query rows).  flash_attn_glds_kernel<64>
+// runs two waves per SIMD, and every MFMA of every wave needs its own 1-KiB fragment from LDS: 8 waves x 1 KiB per
+// 32-cycle MFMA slot = 256 B/clk, twice what the CU's LDS port delivers - that, not the softmax VALU, held the kernel at
+// ~37 % of the matrix peak.  Here each K / V^T fragment read feeds TWO MFMAs (query rows r and 32 + r), halving the
+// LDS traffic per FLOP; O^T (64 registers), S^T (64) and Q (32) for 64 rows still fit the 256 registers that two
+// waves per SIMD allow.  Same LDS image, swizzle, fragment maps, deferred-rescale softmax (one running max / sum per
+// row block) and per-element arithmetic as flash_attn_glds_kernel<64>.
+// MEASURED: no gain (872 vs 895 TF/s) - halving the LDS traffic and the barriers per FLOP changes nothing, so head_dim
+// 64 is bound by VALU ISSUE (per MFMA gap: 2 v_exp at 8 cycles + ~7 other VALU at 4 + the MFMA's own 8 = 54 cycles
+// against the 32 the matrix pipe needs), which two waves on one SIMD share.  Opt-in (DVD_ATTN_64X2=1).
+// ================================================================================================
+__global__ void __launch_bounds__(256, 2) flash_attn_glds64x2_kernel(AttnArgs p) {
+  constexpr int D = 64, KB = 64, KROWB = 128, KBYTES = KB * KROWB, VBYTES = D * 128, BUF = KBYTES + VBYTES;
+  constexpr int KINST = 2, VINST = 2, KS = 4, DT = 2, RB = 2;
+  constexpr float RESCALE_THR = 10.f;
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][BUF]
+  typedef __attribute__((address_space(3))) void* lptr_t;
+
+  const int nwg = gridDim.x;
+  int id = blockIdx.x;
+  {
+    const int q = nwg / 8, rr = nwg % 8, xcd = id % 8, k = id / 8;
+    id = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + k;
+  }
+  const int qb = id % p.nqb;          // 256-row query blocks here
+  const int bh = id / p.nqb;
+  const int head = bh % p.heads, b = bh / p.heads;
+  const int kvb = b / p.kv_div;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+
+  const _Float16* Qg = p.Q + b * p.sQ + (size_t)head * D;
+  const char* Kg = (const char*)(p.K + kvb * p.sK + (size_t)head * D);
+  const char* Vg = (const char*)(p.Vt + kvb * p.sVt + (size_t)head * D * p.ldvt);
+
+  half8 qf[RB][KS];
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) {
+    const int qrow = min(qb * 256 + wave * 64 + rb * 32 + r, p.tq - 1);
+    const _Float16* qp = Qg + (size_t)qrow * p.ldq + 8 * h;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) qf[rb][ks] = *(const half8*)(qp + 16 * ks);
+  }
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // retire the Q loads with a wait the compiler tracks (see flash_attn_glds_kernel)
+
+  unsigned koff[KINST], voff[VINST];
+#pragma unroll
+  for (int i = 0; i < KINST; ++i) {
+    const int q = (KINST * wave + i) * 64 + lane;
+    const int row = q / 8, pos = q % 8;
+    koff[i] = (unsigned)row * (unsigned)(p.ldk * 2) + (unsigned)((pos ^ ((row >> 1) & 7)) * 16);
+  }
+#pragma unroll
+  for (int i = 0; i < VINST; ++i) {
+    const int q = (VINST * wave + i) * 64 + lane;
+    const int row = q / 8, pos = q % 8;
+    voff[i] = (unsigned)row * (unsigned)(p.ldvt * 2) + (unsigned)((pos ^ ((row >> 1) & 7)) * 16);
+  }
+  const int kr = kappa(r);
+  const int fk = (kr >> 1) & 7;
+  int kfrag[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) kfrag[ks] = kr * KROWB + (((2 * ks + h) ^ fk) * 16);
+  const int fv = (r >> 1) & 7;
+  int vfrag[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) vfrag[c] = KBYTES + r * 128 + (((2 * c + h) ^ fv) * 16);
+
+  floatx16 o[RB][DT];
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) o[rb][dt][i] = 0.f;
+  float m_run[RB] = {-1e30f, -1e30f}, l_run[RB] = {0.f, 0.f};
+  const int nt = p.tk / KB;
+  const size_t ktile = (size_t)KB * p.ldk * 2;
+  const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t)smem;
+
+  glds_group<KINST>(Kg, koff, lds0 + (KINST * wave) * 1024);
+  glds_group<VINST>(Vg, voff, lds0 + KBYTES + (VINST * wave) * 1024);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+#define SB() __builtin_amdgcn_sched_barrier(0)
+  // fragment f of the first product: k-step f >> 1, key block f & 1; of the second: chunk f >> 1, d block f & 1
+#define KLOAD2(f_) fr[(f_) & 7] = *(const half8*)(base + kfrag[(f_) >> 1] + ((f_) & 1) * 32 * KROWB)
+#define VLOAD2(f_) fr[(f_) & 7] = *(const half8*)(base + vfrag[(f_) >> 1] + ((f_) & 1) * 32 * 128)
+  int cur = 0;
+  for (int t = 0; t < nt; ++t) {
+    const int tn = min(t + 1, nt - 1);
+    const char* kg_next = Kg + (size_t)tn * ktile;
+    const char* vg_next = Vg + (size_t)tn * (KB * 2);
+    const unsigned lds_next = lds0 + (cur ^ 1) * BUF;
+    const char* base = smem + cur * BUF;
+    half8 fr[8];
+    floatx16 s[RB][2];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s[rb][kb][i] = 0.f;
+    KLOAD2(0); KLOAD2(1); KLOAD2(2); KLOAD2(3);
+    SB();
+#pragma unroll
+    for (int f = 0; f < 8; ++f) {          // 8 K fragments, 2 MFMAs each
+      const int ks = f >> 1, kb = f & 1;
+      s[0][kb] = mfma32_f16(fr[f & 7], qf[0][ks], s[0][kb]);
+      s[1][kb] = mfma32_f16(fr[f & 7], qf[1][ks], s[1][kb]);
+      if (f + 4 < 8) { KLOAD2(f + 4); } else { VLOAD2(f + 4 - 8); }
+      if (f == 3) glds_one(kg_next, koff[0], lds_next + (KINST * wave) * 1024);
+      if (f == 7) glds_one(kg_next, koff[1], lds_next + (KINST * wave + 1) * 1024);
+      SB();
+    }
+
+    float mx[RB];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+      float m = -1e30f;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) m = fmaxf(m, s[rb][kb][i]);
+      mx[rb] = half_swap_max(m * p.c);
+    }
+    if (__any(fmaxf(mx[0] - m_run[0], mx[1] - m_run[1]) > RESCALE_THR)) {     // deferred rescale (both row blocks)
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) {
+        const float m_new = fmaxf(m_run[rb], mx[rb]);
+        const float alpha = __builtin_amdgcn_exp2f(m_run[rb] - m_new);
+        m_run[rb] = m_new;
+        l_run[rb] *= alpha;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) o[rb][dt][i] *= alpha;
+      }
+    }
+    float rs[RB] = {0.f, 0.f};
+    half8 pf[RB][4];
+    // chunk c of P = registers 8 (c & 1) .. +7 of s[rb][c >> 1]
+#define PEXP2(rb_, c_, e_)                                                                                  \
+  {                                                                                                         \
+    const float pv_ = __builtin_amdgcn_exp2f(fmaf(s[rb_][(c_) >> 1][8 * ((c_) & 1) + (e_)], p.c, -m_run[rb_])); \
+    rs[rb_] += pv_;                                                                                         \
+    pf[rb_][c_][e_] = (_Float16)pv_;                                                                        \
+  }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { PEXP2(0, 0, e) PEXP2(1, 0, e) }
+    SB();
+#pragma unroll
+    for (int f = 0; f < 8; ++f) {          // 8 V^T fragments (chunk c, d block dt), 2 MFMAs each
+      const int c = f >> 1, dt = f & 1;
+      o[0][dt] = mfma32_f16(fr[f & 7], pf[0][c], o[0][dt]);
+      o[1][dt] = mfma32_f16(fr[f & 7], pf[1][c], o[1][dt]);
+      if (f + 4 < 8) VLOAD2(f + 4);
+      if (c < 3) {                         // P chunk c+1 of both row blocks in the gaps of chunk c's 4 MFMAs
+#pragma unroll
+        for (int e = dt * 4; e < dt * 4 + 4; ++e) { PEXP2(0, c + 1, e) PEXP2(1, c + 1, e) }
+      }
+      if (f == 3) glds_one(vg_next, voff[0], lds_next + KBYTES + (VINST * wave) * 1024);
+      if (f == 6) glds_one(vg_next, voff[1], lds_next + KBYTES + (VINST * wave + 1) * 1024);
+      SB();
+    }
+    l_run[0] += rs[0];
+    l_run[1] += rs[1];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    cur ^= 1;
+  }
+#undef SB
+#undef KLOAD2
+#undef VLOAD2
+#undef PEXP2
+
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) {
+    const float l_tot = l_run[rb] + __shfl_xor(l_run[rb], 32);
+    const float inv = 1.f / l_tot;
+    const int qglob = qb * 256 + wave * 64 + rb * 32 + r;
+    if (qglob < p.tq) {
+      _Float16* op = p.O + b * p.sO + (size_t)qglob * p.ldo + (size_t)head * D;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          half4 v;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = (_Float16)(o[rb][dt][4 * g4 + j] * inv);
+          *(half4*)(op + 32 * dt + 8 * g4 + 4 * h) = v;
+        }
+    }
   }
 }
 
@@ -1092,9 +1313,15 @@ extern "C" int dvd_flash_attn(const dvd_attn_desc* d, void* stream) {
     else if (variant == 2) flash_attn_glds_kernel<256, 2><<<(unsigned)nwg, 256, LDS, (hipStream_t)stream>>>(p);
     else if (variant == 1) flash_attn_glds_kernel<256, 1><<<(unsigned)nwg, 256, LDS, (hipStream_t)stream>>>(p);
     else flash_attn_glds_kernel<256, 0><<<(unsigned)nwg, 256, LDS, (hipStream_t)stream>>>(p);
+  } else if (fast && getenv("DVD_ATTN_64X2")) {   // head_dim 64, two query row blocks per wave: measured = (872 vs 895 TF/s)
+    constexpr int LDS = 2 * (64 * 128 + 64 * 128);
+    const long nqb2 = cdiv(d->tq, 256);
+    p.nqb = (int)nqb2;
+    flash_attn_glds64x2_kernel<<<(unsigned)(nqb2 * d->heads * d->batch), 256, LDS, (hipStream_t)stream>>>(p);
   } else if (fast) {
     constexpr int LDS = 2 * (64 * 128 + 64 * 128);
-    if (getenv("DVD_ATTN_BULK")) flash_attn_glds_kernel<64, 2><<<(unsigned)nwg, 256, LDS, (hipStream_t)stream>>>(p);
+    if (getenv("DVD_ATTN_DEBUG")) flash_attn_glds_kernel<64, 1><<<(unsigned)nwg, 256, LDS, (hipStream_t)stream>>>(p);
+    else if (getenv("DVD_ATTN_BULK")) flash_attn_glds_kernel<64, 2><<<(unsigned)nwg, 256, LDS, (hipStream_t)stream>>>(p);
     else flash_attn_glds_kernel<64, 0><<<(unsigned)nwg, 256, LDS, (hipStream_t)stream>>>(p);
   } else if (d->head_dim == 256) {
     constexpr int LDS = 2 * (64 * (2 * 256 + 16) + 256 * (2 * 64 + 16));

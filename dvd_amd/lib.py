@@ -16,7 +16,8 @@ import os
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdvd_hip.so")
+# DVD_HIP_LIB: A/B runs of an alternative build of the SAME library (benchmarks only); default = the in-tree build
+LIB_PATH = os.environ.get("DVD_HIP_LIB") or os.path.join(_HERE, "libdvd_hip.so")
 
 
 class DvdError(RuntimeError):
