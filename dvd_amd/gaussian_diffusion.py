@@ -87,6 +87,109 @@ class GaussianDiffusion:
         """DDPM ancestral sampling (absent from the reference): BASELINE config 4."""
         return self.ddim_sample_loop(model, shape, sampler_kind="ddpm", **kw)
 
+    def ddim_sample_loop_progressive_only_mean(self, model, shape, **kw):
+        """Generator form (idf/gaussian_diffusion.py:537-644): like the reference it yields ONCE, after the last step,
+        a dict whose 'sample' and 'pred_xstart' are the hypothesis mean clamped to [-1, 1]."""
+        sample, final = self.ddim_sample_loop(model, shape, **kw)
+        yield final
+
+    def ddim_sample_loop_for_training(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None,
+                                      model_kwargs=None, device=None, progress=False, eta=0.0, sampling_kwargs=None,
+                                      logger=None, n_batch=1, time_variant=False, iter=True, mode="train", timestep=None,
+                                      pyramid=None):
+        """Training-time roll-out (idf/gaussian_diffusion.py:647-782): steps S-1 ... timestep+1, NO hypothesis mean,
+        clamp only; returns (sample [B*n_batch,2,G,G], feat [B,256,G,G]).  mode=None applies the denoiser's timestep
+        override like sampling does; any other mode feeds the raw model time (idf/cross_model.py:574-580)."""
+        final = None
+        for final in self.ddim_sample_for_training(model, shape, noise=noise, clip_denoised=clip_denoised,
+                                                   denoised_fn=denoised_fn, model_kwargs=model_kwargs, device=device,
+                                                   eta=eta, n_batch=n_batch, time_variant=time_variant, iter=iter,
+                                                   mode=mode, timestep=timestep):
+            pass
+        return final["sample"], final["feat_dict"]
+
+    def ddim_sample_for_training(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None,
+                                 model_kwargs=None, device=None, progress=False, eta=0.0, logger=None, n_batch=1,
+                                 time_variant=False, iter=False, mode="train", timestep=None, pyramid=None):
+        if clip_denoised or denoised_fn is not None:
+            raise NotImplementedError("clip_denoised / denoised_fn are off on the DvD path")
+        if not time_variant or not iter:
+            raise NotImplementedError("only the live time_variant=True / iter=True configuration is mirrored")
+        if mode is not None:
+            raise NotImplementedError("mode != None (no timestep override) is the training forward; the engine mirrors "
+                                      "the sampling configuration mode=None")
+        if timestep is None or not -1 <= int(timestep) < self.num_timesteps - 1:
+            raise ValueError(f"timestep must be in [-1, {self.num_timesteps - 2}]")
+        B, C, G, G2 = shape
+        assert C == 2 and G == G2
+        dev = device or next(model.parameters()).device
+        eng = model.engine(G, B, n_batch)
+        kw = model_kwargs
+        eng.prepare(*[kw[k].to(dev, th.float32).contiguous() for k in ("y512", "mask_cat", "mask_y512", "line_msk")])
+        if noise is not None:
+            x_T = noise.to(dev, th.float32).contiguous()
+            assert tuple(x_T.shape) == (B * n_batch, 2, G, G)
+        else:
+            _ = th.randn(*shape, device=dev)
+            x_T = th.randn((B * n_batch, 2, G, G), device=dev)
+        noise_fn = (lambda i: th.randn((B * n_batch, 2, G, G), device=dev)) if eta != 0.0 else None   # noqa: E731
+        sample = sampler.sample(eng, self.tables, x_T, eta=eta, noise_fn=noise_fn, mean_hyp=False,
+                                last_step=int(timestep) + 1)
+        yield {"sample": sample, "pred_xstart": sample, "feat_dict": eng.feat_nchw()}
+
+    # ---- single-step pieces with the reference's signatures -------------------------------------
+    def _extract(self, arr, t, shape):
+        """_extract_into_tensor (idf/gaussian_diffusion.py:1185-1195): float64 table -> gather -> float32 -> broadcast."""
+        res = th.from_numpy(np.asarray(arr, dtype=np.float64)).to(t.device)[t.long()].float()
+        while res.dim() < len(shape):
+            res = res[..., None]
+        return res.expand(shape)
+
+    def q_sample(self, x_start, t, noise=None):
+        """q(x_t | x_0) (idf/gaussian_diffusion.py:250-268)."""
+        if noise is None:
+            noise = th.randn_like(x_start)
+        ac = np.asarray(self.alphas_cumprod, dtype=np.float64)
+        return (self._extract(np.sqrt(ac), t, x_start.shape) * x_start +
+                self._extract(np.sqrt(1.0 - ac), t, x_start.shape) * noise)
+
+    def _step_index(self, t):
+        i = int(t[0])
+        if not bool((t == i).all()):
+            raise ValueError("the timestep must be identical across the batch (the denoiser's override rule is batch-global)")
+        return i
+
+    def p_mean_variance(self, model, x, t, clip_denoised=True, denoised_fn=None, model_kwargs=None):
+        """idf/gaussian_diffusion.py:294-415 for the live configuration (START_X, FIXED_LARGE/SMALL, no clipping):
+        {'mean','variance','log_variance','pred_xstart','feat'}; the denoiser runs on the HIP engine, the posterior
+        mean on the fused scheduler kernel."""
+        if clip_denoised or denoised_fn is not None:
+            raise NotImplementedError("clip_denoised / denoised_fn are off on the DvD path")
+        i = self._step_index(t)
+        t_model = th.full((x.shape[0],), self.tables.model_time(i), device=x.device)
+        x0, feat = model(x, t_model, **(model_kwargs or {}))
+        c = self.tables.ddpm_coef(i)
+        c.sigma = 0.0                                                  # mean only
+        mean = ops.sched_step(c, x.float().contiguous(), x0)
+        if self.model_var_type == ModelVarType.FIXED_LARGE:
+            logvar = float(self.tables.fixed_large_log_variance[i])
+        else:
+            logvar = float(self.posterior_log_variance_clipped[i])
+        lv = th.full_like(x0, np.float32(logvar))
+        return {"mean": mean, "variance": th.exp(lv), "log_variance": lv, "pred_xstart": x0, "feat": feat}
+
+    def ddim_sample(self, model, x, t, clip_denoised=True, denoised_fn=None, model_kwargs=None, eta=0.0):
+        """One DDIM step with the reference's signature (idf/gaussian_diffusion.py:445-491):
+        {'sample','pred_xstart','feat_dict'}."""
+        if clip_denoised or denoised_fn is not None:
+            raise NotImplementedError("clip_denoised / denoised_fn are off on the DvD path")
+        i = self._step_index(t)
+        t_model = th.full((x.shape[0],), self.tables.model_time(i), device=x.device)
+        x0, feat = model(x, t_model, **(model_kwargs or {}))
+        coef = self.tables.ddim_coef(i, eta)
+        noise = th.randn_like(x0) if coef.sigma != 0.0 else None
+        return {"sample": ops.sched_step(coef, x.float().contiguous(), x0, noise), "pred_xstart": x0, "feat_dict": feat}
+
     # reference-compatible single step (idf/gaussian_diffusion.py:445-491) on an explicit x0 prediction
     def ddim_step(self, x_t, x0, i, eta=0.0, noise=None):
         return ops.sched_step(self.tables.ddim_coef(i, eta), x_t, x0, noise)

@@ -18,17 +18,21 @@ def feat_mode_for(t_model: float, n: int, first_step: bool) -> int:
 
 
 def sample(engine: Engine, tables: schedule.Tables, x_T: torch.Tensor, sampler: str = "ddim", eta: float = 0.0,
-           noise_fn=None, mean_hyp: bool = True, trace=None):
+           noise_fn=None, mean_hyp: bool = True, trace=None, last_step: int = 0):
     """x_T [docs*H, 2, G, G] on the engine's device (sample index = doc*H + h).  The engine must have been
     prepared for its documents.  noise_fn(step) -> [N,2,G,G] supplies the per-step noise (DDPM, or DDIM with
-    eta > 0).  Returns [docs,2,G,G] (hypothesis mean + clamp, :639-640) or the clamped per-sample maps."""
+    eta > 0).  Returns [docs,2,G,G] (hypothesis mean + clamp, :639-640) or the clamped per-sample maps.
+    last_step > 0 stops the roll-out early (the training-time variant starts at S-1 and ends at `timestep + 1`,
+    idf/gaussian_diffusion.py:720)."""
     n = engine.n
     S = tables.num_timesteps
     img = x_T.contiguous()
     zeros = torch.zeros_like(img)
     x0_bufs = [torch.empty_like(img), torch.empty_like(img)]
     x0 = None
-    for k, i in enumerate(range(S - 1, -1, -1)):
+    if not 0 <= last_step < S:
+        raise ValueError(f"last_step {last_step} outside [0, {S})")
+    for k, i in enumerate(range(S - 1, last_step - 1, -1)):
         t_model = tables.model_time(i)
         first = i == S - 1
         flow = zeros if first else x0

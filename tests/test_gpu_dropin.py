@@ -80,3 +80,54 @@ def test_plugin_run_end_to_end(tmp_path, monkeypatch):
     for path, img in results:
         assert img.dtype == torch.uint8 and tuple(img.shape) == (96, 80, 3)
         assert os.path.exists(f"vis_hp/synthetic/pytest/dewarped_pred/warped_{path}.png")
+
+
+@pytest.mark.parametrize("grid", [16, 32])
+def test_training_rollout_contract_vs_reference_golden(grid):
+    """ddim_sample_loop_for_training(timestep=-1, mode=None, iter=True, n_batch=2) is the reference call that made
+    golden G3 at G = 16 / 32 (oracle/ref_harness/gen_golden.py): per-hypothesis maps, clamp only, no mean."""
+    g = np.load(os.path.join(GOLD, f"loop_g{grid}_s3.npz"))
+    assert str(g["kind"]) == "ddim_sample_loop_for_training"
+    s, model, diffusion = build(grid, 3)
+    doc = {k: torch.from_numpy(v)[None].cuda() for k, v in synth.synth_document(0, grid, 1234).items()}
+    kw = {"init_flow": torch.zeros(1, 2, grid, grid, device="cuda"), "y512": doc["y512"], "mask_cat": doc["mask_cat"],
+          "init_feat": torch.zeros(1, 256, grid, grid, device="cuda"), "mask_y512": doc["mask_y512"],
+          "line_msk": doc["line_msk"]}
+    sample, feat = diffusion.ddim_sample_loop_for_training(model, (1, 2, grid, grid), noise=torch.from_numpy(g["x_T"]),
+                                                           clip_denoised=False, model_kwargs=kw, eta=0.0, n_batch=2,
+                                                           time_variant=True, iter=True, mode=None, timestep=-1)
+    assert tuple(sample.shape) == (2, 2, grid, grid) and tuple(feat.shape) == (1, 256, grid, grid)
+    err = float(np.sqrt(((sample.cpu().numpy() - g["sample"]) ** 2).mean()))
+    assert err < 1e-3, err
+    # stopping early (timestep = 0) returns the clamped x0 prediction of step 1
+    early, _ = diffusion.ddim_sample_loop_for_training(model, (1, 2, grid, grid), noise=torch.from_numpy(g["x_T"]),
+                                                       clip_denoised=False, model_kwargs=kw, eta=0.0, n_batch=2,
+                                                       time_variant=True, iter=True, mode=None, timestep=0)
+    ref_early = np.clip(g["x0_steps"][1], -1, 1)
+    assert float(np.sqrt(((early.cpu().numpy() - ref_early) ** 2).mean())) < 1e-3
+
+
+def test_single_step_signatures_vs_reference_golden():
+    """ddim_sample / p_mean_variance with the reference's signatures: one step of the golden S = 3 loop at G = 16
+    (x_in_steps -> x0_steps), posterior mean = coef1 x0 + coef2 x_t, FIXED_LARGE log-variance (golden G1)."""
+    grid = 16
+    g = np.load(os.path.join(GOLD, f"loop_g{grid}_s3.npz"))
+    sch = np.load(os.path.join(GOLD, "schedule.npz"))
+    s, model, diffusion = build(grid, 3)
+    doc = {k: torch.from_numpy(v)[None].repeat(2, 1, 1, 1).cuda() for k, v in synth.synth_document(0, grid, 1234).items()}
+    kw = {"init_flow": torch.zeros(2, 2, grid, grid, device="cuda"), "y512": doc["y512"], "mask_cat": doc["mask_cat"],
+          "init_feat": torch.zeros(2, 256, grid, grid, device="cuda"), "mask_y512": doc["mask_y512"],
+          "line_msk": doc["line_msk"], "tv": True, "iter": True, "tmode": "stage_1_dit_cross", "mode": None}
+    x_in = torch.from_numpy(g["x_in_steps"][0]).cuda()          # first step (i = 2): init_flow = 0
+    t = torch.tensor([2, 2], device="cuda")
+    out = diffusion.ddim_sample(model, x_in, t, clip_denoised=False, model_kwargs=kw, eta=0.0)
+    assert set(out) == {"sample", "pred_xstart", "feat_dict"}
+    assert float(np.sqrt(((out["pred_xstart"].cpu().numpy() - g["x0_steps"][0]) ** 2).mean())) < 1e-3
+    assert float(np.sqrt(((out["sample"].cpu().numpy() - g["x_in_steps"][1]) ** 2).mean())) < 1e-3
+    pmv = diffusion.p_mean_variance(model, x_in, t, clip_denoised=False, model_kwargs=kw)
+    x0 = pmv["pred_xstart"]
+    c1, c2 = np.float32(sch["s3/posterior_mean_coef1"][2]), np.float32(sch["s3/posterior_mean_coef2"][2])
+    np.testing.assert_allclose(pmv["mean"].cpu().numpy(), c1 * x0.cpu().numpy() + c2 * x_in.cpu().numpy(), rtol=0, atol=1e-6)
+    np.testing.assert_allclose(pmv["log_variance"].cpu().numpy().ravel()[0], sch["s3/fixed_large_logvar_f32"][2], rtol=1e-6)
+    with pytest.raises(ValueError):
+        diffusion.ddim_sample(model, x_in, torch.tensor([2, 1], device="cuda"), clip_denoised=False, model_kwargs=kw)

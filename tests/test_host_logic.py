@@ -177,3 +177,20 @@ def test_product_never_imports_oracle():
                         bad.append(os.path.join(base, f))
     assert not bad, bad
     assert "oracle" not in open(os.path.join(root, "run_sampling.py")).read()
+
+
+def test_q_sample_matches_reference_formula():
+    """q(x_t | x_0) = sqrt(abar_t) x_0 + sqrt(1 - abar_t) eps with float64 tables gathered to float32
+    (idf/gaussian_diffusion.py:250-268, :1185-1195)."""
+    import torch
+    from dvd_amd import script_util
+    diffusion = script_util.create_gaussian_diffusion(steps=10, noise_schedule="cosine", predict_xstart=True,
+                                                      rescale_timesteps=True, timestep_respacing="")
+    x0 = torch.from_numpy(synth.uniform("q/x0", (3, 2, 4, 4), -1, 1, 1))
+    eps = torch.from_numpy(synth.uniform("q/eps", (3, 2, 4, 4), -2, 2, 1))
+    t = torch.tensor([0, 4, 9])
+    got = diffusion.q_sample(x0, t, noise=eps)
+    ac = np.asarray(diffusion.alphas_cumprod, dtype=np.float64)
+    a = torch.from_numpy(np.sqrt(ac))[t].float()[:, None, None, None]
+    b = torch.from_numpy(np.sqrt(1 - ac))[t].float()[:, None, None, None]
+    assert torch.equal(got, a * x0 + b * eps)
