@@ -1,6 +1,7 @@
 """GPU parity of the token-side HIP kernels, each against the torch-CPU op(s) it replaces (the same ops the
 oracle / the reference call)."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -65,8 +66,9 @@ def test_timestep_mlp_and_adaln(ops):
         assert (fin.cpu() - fin_ref).abs().max() < 5e-5, t
 
 
-def test_dwconv_bn_relu(ops):
-    n, side, c = 2, 8, 2048
+@pytest.mark.parametrize("side", [8, 7, 1, 13])
+def test_dwconv_bn_relu(ops, side):
+    n, c = 2, 2048
     x = rnd("dw/x", (n, c, side, side), -1, 2)
     w = rnd("dw/w", (c, 1, 3, 3), -0.5, 0.5)
     s, b = rnd("dw/s", (c,), 0.5, 1.5), rnd("dw/b", (c,), -0.3, 0.3)
@@ -76,6 +78,12 @@ def test_dwconv_bn_relu(ops):
     out = ops.dwconv3x3(x16.cuda(), w9c.cuda(), b.cuda(), n, side).float().cpu()
     got = out.reshape(n, side, side, c).permute(0, 3, 1, 2)
     assert (got - ref).abs().max() < 6e-3
+    os.environ["DVD_DWCONV_V1"] = "1"        # the one-token-per-thread kernel: same tap order -> bit-identical
+    try:
+        out_v1 = ops.dwconv3x3(x16.cuda(), w9c.cuda(), b.cuda(), n, side).float().cpu()
+    finally:
+        os.environ.pop("DVD_DWCONV_V1")
+    assert torch.equal(out, out_v1)
 
 
 def test_adaptive_posenc(ops):
