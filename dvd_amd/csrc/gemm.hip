@@ -18,6 +18,13 @@
 #include <stdlib.h>
 #include <type_traits>
 
+#ifndef DVD_GEMM_SPREAD_FIRST
+#define DVD_GEMM_SPREAD_FIRST 0
+#endif
+#ifndef DVD_GEMM_SPREAD_STEP
+#define DVD_GEMM_SPREAD_STEP 1
+#endif
+
 namespace dvd {
 
 struct GemmArgs {
@@ -85,10 +92,21 @@ __device__ __forceinline__ void epilogue_tile(const GemmArgs& p, const floatx16&
 //   stage : this wave's LDS region, 64 rows x 64 floats (256-B pitch: conflict-free for both access patterns)
 //   t00.. : accumulator tiles (rows 0-31 | 32-63) x (cols 0-31 | 32-63) of the block at (row0, col0)
 // ---------------------------------------------------------------------------------------------------------
+// EPI selects what the store loop may touch besides LDS (compile-time, so that the loop body contains NO global load):
+//   0  plain: column bias + activation only                      -> the 8 row-contiguous stores are fire-and-forget
+//   1  + residual: rows prefetched through a rolling 4-iteration window, always older than the stores they overlap
+//   3  + row bias (transposed outputs): 8 scalars before the loop
+//   2  general (pos / gate / residual with row bias): loads inside the loop (small GEMMs only)
+// Why it matters: on CDNA4 vmcnt counts stores too and retires in order, so ANY wait for a load inside the loop - even
+// the wait the compiler places after a conditional load that is skipped at run time - also waits for the previous
+// iteration's global store to be acknowledged (~1300 cycles): the epilogue took 23 000 cycles per 256 x 256 tile, a
+// quarter of the kernel, 16 stores x 1300 (s_memtime stamps, identical to the cycle with and without other CUs storing).
+template <int EPI>
 __device__ __forceinline__ void epilogue_block64(const GemmArgs& p, float* stage, const floatx16& t00,
                                                  const floatx16& t01, const floatx16& t10, const floatx16& t11,
                                                  int row0, int col0, int lane, float* C32, _Float16* C16,
-                                                 const float* bias, const float* res, const float* gate) {
+                                                 const float* bias, const float* res, const float* gate,
+                                                 unsigned long long* tmid = nullptr) {
   const int r = lane & 31, h = lane >> 5;
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
@@ -98,49 +116,95 @@ __device__ __forceinline__ void epilogue_block64(const GemmArgs& p, float* stage
     stage[(32 + rr) * 64 + r] = t10[i];
     stage[(32 + rr) * 64 + 32 + r] = t11[i];
   }
+  if (tmid) {                                   // diagnostic builds: LDS writes retired
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+    *tmid = __builtin_amdgcn_s_memtime();
+  }
   // same-wave LDS accesses execute in order; the compiler inserts the lgkmcnt wait for the reads below.
   // Read back 8 consecutive columns per lane: 8 rows x 256 B (f32, two 16-B stores) / 128 B (f16, one 16-B store)
-  // per wave-instruction - the store tail is store-ISSUE-bound, so fewer, wider stores matter (guide T21).
+  // per wave-instruction (guide T21).
   const int c8 = (lane & 7) * 8;
   const int col = col0 + c8;
+  const bool colok = col < p.N;
   float bc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  if (bias && !p.bias_row && col < p.N) {
+  if (bias && !p.bias_row && colok) {
     const floatx4 b0 = *(const floatx4*)(bias + col), b1 = *(const floatx4*)(bias + col + 4);
 #pragma unroll
     for (int e = 0; e < 4; ++e) { bc[e] = b0[e]; bc[4 + e] = b1[e]; }
   }
-#pragma unroll 2
+  // EPI 1: residual rows through a rolling window of 4 iterations - the load of iteration it + 4 is issued right after
+  // iteration it has consumed its slot and BEFORE iteration it's stores, so (vmcnt being in-order) waiting for it never
+  // waits for a store.  EPI 3: the 8 row-bias scalars up front.  All of these loads are unconditional (a conditional
+  // load is a control-flow merge, after which the compiler waits vmcnt(0)).
+  floatx4 rs0[4], rs1[4];
+  float brow[8];
+  const int cc = colok ? col : 0;
+  auto res_row = [&](int it) { return res + (size_t)min(row0 + it * 8 + (lane >> 3), p.M - 1) * p.ldres + cc; };
+  if constexpr (EPI == 1) {
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      rs0[it] = *(const floatx4*)res_row(it);
+      rs1[it] = *(const floatx4*)(res_row(it) + 4);
+    }
+  }
+  if constexpr (EPI == 3) {
+#pragma unroll
+    for (int it = 0; it < 8; ++it) brow[it] = bias[min(row0 + it * 8 + (lane >> 3), p.M - 1)];
+  }
+  const bool relu = p.act == 2;
+  // EPI 1 needs compile-time window slots (it & 3): unrolled by 4.  The other flavours are unrolled by 2 only: fully
+  // unrolled, the compiler hoists every iteration's addresses out of the persistent tile loop and spills them, and each
+  // scratch reload is a vmcnt(0) - i.e. a wait for the previous store again.
+#pragma unroll(EPI == 1 ? 4 : (EPI == 3 ? 8 : 2))
   for (int it = 0; it < 8; ++it) {
     const int lr = it * 8 + (lane >> 3);
     const int row = row0 + lr;
     const floatx4 s0 = *(const floatx4*)(stage + lr * 64 + c8), s1 = *(const floatx4*)(stage + lr * 64 + c8 + 4);
-    if (row < p.M && col < p.N) {
-      float v[8];
-      const float br = (bias && p.bias_row) ? bias[row] : 0.f;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        float x = (e < 4 ? s0[e] : s1[e - 4]) + bc[e] + br;
-        if (p.act == 1) x = gelu_tanh(x);
-        else if (p.act == 2) x = fmaxf(x, 0.f);
-        v[e] = x;
+    floatx4 rcur0 = {0.f, 0.f, 0.f, 0.f}, rcur1 = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (EPI == 1) {
+      rcur0 = rs0[it & 3];
+      rcur1 = rs1[it & 3];
+      if (it + 4 < 8) {
+        rs0[it & 3] = *(const floatx4*)res_row(it + 4);
+        rs1[it & 3] = *(const floatx4*)(res_row(it + 4) + 4);
       }
-      if (p.pos) {
-        const float* pp = p.pos + (size_t)(row % p.pos_rows) * p.ldpos + col;
-        const floatx4 p0 = *(const floatx4*)pp, p1 = *(const floatx4*)(pp + 4);
+    }
+    float br = 0.f;
+    if constexpr (EPI == 3) br = brow[it];
+    if constexpr (EPI == 2) br = (bias && p.bias_row) ? bias[min(row, p.M - 1)] : 0.f;
+    float v[8];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { v[e] += p0[e]; v[4 + e] += p1[e]; }
+    for (int e = 0; e < 8; ++e) v[e] = (e < 4 ? s0[e] : s1[e - 4]) + bc[e] + br;
+    if (p.act == 1) {                              // one uniform branch per iteration (tanhf branches internally)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = gelu_tanh(v[e]);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = relu ? fmaxf(v[e], 0.f) : v[e];
+    if (row < p.M && colok) {
+      if constexpr (EPI == 2) {
+        if (p.pos) {
+          const float* pp = p.pos + (size_t)(row % p.pos_rows) * p.ldpos + col;
+          const floatx4 p0 = *(const floatx4*)pp, p1 = *(const floatx4*)(pp + 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { v[e] += p0[e]; v[4 + e] += p1[e]; }
+        }
+        if (gate) {
+          const float* gp = gate + (size_t)(row / p.gate_rows) * p.ldgate + col;
+          const floatx4 g0 = *(const floatx4*)gp, g1 = *(const floatx4*)(gp + 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { v[e] *= g0[e]; v[4 + e] *= g1[e]; }
+        }
+        if (res) {
+          const float* rp = res + (size_t)row * p.ldres + col;
+          const floatx4 r0 = *(const floatx4*)rp, r1 = *(const floatx4*)(rp + 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[4 + e] += r1[e]; }
+        }
       }
-      if (gate) {
-        const float* gp = gate + (size_t)(row / p.gate_rows) * p.ldgate + col;
-        const floatx4 g0 = *(const floatx4*)gp, g1 = *(const floatx4*)(gp + 4);
+      if constexpr (EPI == 1) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { v[e] *= g0[e]; v[4 + e] *= g1[e]; }
-      }
-      if (res) {
-        const float* rp = res + (size_t)row * p.ldres + col;
-        const floatx4 r0 = *(const floatx4*)rp, r1 = *(const floatx4*)(rp + 4);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { v[e] += r0[e]; v[4 + e] += r1[e]; }
+        for (int e = 0; e < 4; ++e) { v[e] += rcur0[e]; v[4 + e] += rcur1[e]; }
       }
       if (C32) {
         float* cp = C32 + (size_t)row * p.ldc + col;
@@ -157,6 +221,16 @@ __device__ __forceinline__ void epilogue_block64(const GemmArgs& p, float* stage
     }
   }
 }
+
+// run-time (wave-uniform) choice of the epilogue flavour
+#define DVD_EPILOGUE_BLOCK64(...)                                                           \
+  {                                                                                         \
+    const bool brow_ = bias && p.bias_row;                                                  \
+    if (p.pos || gate || (res && brow_)) epilogue_block64<2>(__VA_ARGS__);                  \
+    else if (res) epilogue_block64<1>(__VA_ARGS__);                                         \
+    else if (brow_) epilogue_block64<3>(__VA_ARGS__);                                       \
+    else epilogue_block64<0>(__VA_ARGS__);                                                  \
+  }
 
 template <bool F32>
 __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(GemmArgs p) {
@@ -325,8 +399,8 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(GemmArgs p) {
     // the K loop ended with a barrier (or the tail compute): make sure every wave is done reading operands
     __syncthreads();
     float* stage = (float*)(&smem[0][0][0]) + wave * (64 * 64);     // 4 x 16 KiB of the 72 KiB operand buffers
-    epilogue_block64(p, stage, acc[0][0], acc[0][1], acc[1][0], acc[1][1], bm0 + 64 * wr, bn0 + 64 * wc, lane, C32,
-                     C16, bias, res, gate);
+    DVD_EPILOGUE_BLOCK64(p, stage, acc[0][0], acc[0][1], acc[1][0], acc[1][1], bm0 + 64 * wr, bn0 + 64 * wc, lane, C32,
+                         C16, bias, res, gate)
   } else {
 #pragma unroll
     for (int n = 0; n < 2; ++n) {
@@ -515,9 +589,13 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_big_kernel(GemmArgs p) {
           if (m < 2) fb[cs ^ 1][m] = *(const half8*)(base + b_base + m * 32 * 128 + frag[s4 + 1]);
         }
         if constexpr (SPREAD) {
-          const int g = s4 * 4 + m;                       // 16 MFMA groups per slab, a load after every odd one
-          if ((g & 1) && (g >> 1) < 4) glds_one4(a_nx, aoff[(g >> 1) & 3], lds_nx + ((g >> 1) & 3) * 1024);
-          if ((g & 1) && (g >> 1) >= 4) glds_one4(b_nx, boff[(g >> 1) & 3], lds_nx + TILE + ((g >> 1) & 3) * 1024);
+          const int g = s4 * 4 + m;                       // 16 MFMA groups per slab; loads after groups SPREAD_AT(k)
+          constexpr int FIRST = DVD_GEMM_SPREAD_FIRST, STEP = DVD_GEMM_SPREAD_STEP;
+          if (g >= FIRST && (g - FIRST) % STEP == 0 && (g - FIRST) / STEP < 8) {
+            const int k = (g - FIRST) / STEP;
+            if (k < 4) glds_one4(a_nx, aoff[k & 3], lds_nx + (k & 3) * 1024);
+            else glds_one4(b_nx, boff[k & 3], lds_nx + TILE + (k & 3) * 1024);
+          }
         }
         SB();
       }
@@ -539,18 +617,38 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_big_kernel(GemmArgs p) {
 #undef LDFRAG
 
   if constexpr (DBG == 3) t2 = __builtin_amdgcn_s_memtime();
+  unsigned long long te[3] = {0, 0, 0};
   // ---------------- epilogue (same semantics as gemm_nt_kernel) ----------------
   float* C32 = p.C32 ? p.C32 + z * p.sC32 : nullptr;
   _Float16* C16 = p.C16 ? p.C16 + z * p.sC16 : nullptr;
   const float* bias = p.bias ? p.bias + z * p.sBias : nullptr;
   const float* res = p.res ? p.res + z * p.sRes : nullptr;
   const float* gate = p.gate ? p.gate + z * p.sGate : nullptr;
-  if (p.vec_epilogue) {
+  // the large-tile kernel carries only the two staged flavours its callers need (plain / residual); the rare pos /
+  // gate / row-bias epilogues at N % 256 == 0 take the scalar path below (fewer live values across the K loop)
+  if (p.vec_epilogue && !p.pos && !gate && !(bias && p.bias_row)) {
     float* stage = (float*)smem + wave * (64 * 64);                  // 8 x 16 KiB = the whole 128 KiB
     const int row0 = bm0 + 128 * wr, col0 = bn0 + 64 * wc;
-    epilogue_block64(p, stage, acc[0][0], acc[0][1], acc[1][0], acc[1][1], row0, col0, lane, C32, C16, bias, res, gate);
-    epilogue_block64(p, stage, acc[2][0], acc[2][1], acc[3][0], acc[3][1], row0 + 64, col0, lane, C32, C16, bias, res,
-                     gate);
+    // Launder the lane id: everything the epilogue derives from it (staging offsets, row / column of a lane) is then
+    // recomputed here instead of being hoisted above the K loop of the persistent tile loop, kept live across it and
+    // SPILLED - each scratch reload is a serialized ~500-cycle vmcnt(0) wait (24 of them: 12 000 cycles per tile).
+    int lane_e = lane;
+    asm volatile("" : "+v"(lane_e));
+#define lane lane_e
+    if (res) {
+      epilogue_block64<1>(p, stage, acc[0][0], acc[0][1], acc[1][0], acc[1][1], row0, col0, lane, C32, C16, bias, res,
+                          gate, DBG == 3 ? &te[0] : nullptr);
+      if constexpr (DBG == 3) te[1] = __builtin_amdgcn_s_memtime();
+      epilogue_block64<1>(p, stage, acc[2][0], acc[2][1], acc[3][0], acc[3][1], row0 + 64, col0, lane, C32, C16, bias,
+                          res, gate, DBG == 3 ? &te[2] : nullptr);
+    } else {
+      epilogue_block64<0>(p, stage, acc[0][0], acc[0][1], acc[1][0], acc[1][1], row0, col0, lane, C32, C16, bias, res,
+                          gate, DBG == 3 ? &te[0] : nullptr);
+      if constexpr (DBG == 3) te[1] = __builtin_amdgcn_s_memtime();
+      epilogue_block64<0>(p, stage, acc[2][0], acc[2][1], acc[3][0], acc[3][1], row0 + 64, col0, lane, C32, C16, bias,
+                          res, gate, DBG == 3 ? &te[2] : nullptr);
+    }
+#undef lane
   } else {
   // written out (not a loop): hipcc refuses to fully unroll an 8 x 16-element epilogue loop and would then
   // index acc[][] dynamically
@@ -570,8 +668,8 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_big_kernel(GemmArgs p) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const unsigned long long t4 = __builtin_amdgcn_s_memtime();      // stores drained
     if (lane == 0 && p.stamps && vid < 256 * 64) {
-      unsigned long long* o = p.stamps + ((size_t)vid * 8 + wave) * 5;
-      o[0] = t0; o[1] = t1; o[2] = t2; o[3] = t3; o[4] = t4;
+      unsigned long long* o = p.stamps + ((size_t)vid * 8 + wave) * 8;
+      o[0] = t0; o[1] = t1; o[2] = t2; o[3] = t3; o[4] = t4; o[5] = te[0]; o[6] = te[1]; o[7] = te[2];
     }
   }
   __syncthreads();   // every wave has read its staging region back: the next tile's LDS-DMA may overwrite it
