@@ -56,7 +56,7 @@ static std::vector<TensorSpec> tensor_specs(int G) {
   const long T = (long)(G / 2) * (G / 2), side = G / 2;
   std::vector<TensorSpec> v;
   auto f32 = [&](const std::string& n, long e) { v.push_back({n, 0, e}); };
-  // every f16 weight comes as a (hi, lo) pair: W = hi + 2^-11 * lo  (see dvd_gemm_desc.B_lo)
+  // every f16 weight comes as a (hi, lo) pair: W = hi + lo, lo unscaled  (see dvd_gemm_desc.B_lo)
   auto f16 = [&](const std::string& n, long e) { v.push_back({n, 1, e}); v.push_back({n + "_lo", 1, e}); };
   f32("obs_w", HID * 8); f32("obs_b", HID); f32("pos", T * HID);
   f16("r_w16", (long)HID * RK); f32("r_b", HID);
@@ -176,7 +176,7 @@ static int gemm(int dtype, int M, int N, int K, int batch, const void* A, int ld
                 const void* Blo = nullptr) {
   dvd_gemm_desc d;
   memset(&d, 0, sizeof(d));
-  d.A_lo = Alo; d.B_lo = Blo; d.lo_scale = 1.f / 2048.f;
+  d.A_lo = Alo; d.B_lo = Blo; d.lo_scale = 1.f;
   d.dtype = dtype; d.M = M; d.N = N; d.K = K; d.batch = batch;
   d.A = A; d.lda = lda; d.strideA = sA;
   d.B = Bm; d.ldb = ldb; d.strideB = sB;

@@ -676,6 +676,165 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_big_kernel(GemmArgs p) {
   }  // persistent tile loop
 }
 
+
+// ================================================================================================
+// Split-weight GEMM in ONE pass over K:  C = A . (B + Blo)^T  with Blo stored UNSCALED (f16 subnormals allowed: the
+// f16 MFMA honours them on gfx950, checked in benchmarks/lab/denorm_lab.hip), so both products go into the same fp32
+// accumulators and no second sweep / rescale is needed.  Per 32-deep K slab a workgroup loads three 16-KiB tiles
+// [A | B | Blo] instead of [A | B] twice: 25 % fewer bytes through the 33 B/clk L2->LDS path, one A fragment read feeds
+// four MFMAs instead of two (0.5 instead of 0.75 ds_read_b128 per MFMA), same 32 MFMAs per wave between barriers, and
+// three 48-KiB stages (prefetch distance two slabs) fit the LDS.  Same 256 x 256 tile, wave layout, persistent tile
+// walk and epilogue as gemm_nt_big_kernel.  64-byte LDS rows: 16-byte chunk c of row r lives at c ^ ((r >> 2) & 3).
+// ================================================================================================
+__global__ void __launch_bounds__(512, 2) gemm_nt_split_kernel(GemmArgs p) {
+  constexpr int BK = 32, TILE = 256 * 64, STAGE = 3 * TILE, NST = 3;
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [3 stages][A | B | Blo]
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  const int nwg = p.ntm * p.ntn;
+  const int z = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const int wr = wave >> 2, wc = wave & 3;
+  for (int vid = blockIdx.x; vid < nwg; vid += gridDim.x) {
+  int id = vid;
+  {
+    const int q = nwg / 8, rr = nwg % 8, xcd = id % 8, k = id / 8;
+    id = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + k;
+  }
+  const int tm = id / p.ntn, tn = id % p.ntn;
+  const int bm0 = tm * 256, bn0 = tn * 256;
+  const _Float16* A = (const _Float16*)p.A + z * p.sA;
+  const _Float16* B = (const _Float16*)p.B + z * p.sB;
+  const _Float16* Blo = (const _Float16*)p.Blo + z * p.sB;
+
+  // per-lane source offsets of this wave's 2 + 2 + 2 loads (1 KiB = 16 rows x 64 B each)
+  unsigned aoff[2], boff[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = 16 * (2 * wave + i) + (lane >> 2), pos = lane & 3;
+    const int logical = pos ^ ((row >> 2) & 3);
+    const int ra = min(bm0 + row, p.M - 1) - bm0, rb = min(bn0 + row, p.N - 1) - bn0;
+    aoff[i] = (unsigned)ra * (unsigned)(p.lda * 2) + logical * 16;
+    boff[i] = (unsigned)rb * (unsigned)(p.ldb * 2) + logical * 16;
+  }
+  const char* Atile = (const char*)(A + (size_t)bm0 * p.lda);
+  const char* Btile = (const char*)(B + (size_t)bn0 * p.ldb);
+  const char* Ltile = (const char*)(Blo + (size_t)bn0 * p.ldb);
+  const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t)smem;
+
+  int frag[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) frag[ks] = r * 64 + (((2 * ks + h) ^ ((r >> 2) & 3)) * 16);
+  const int a_base = wr * 128 * 64;
+  const int b_base = TILE + wc * 64 * 64;
+  const int l_base = 2 * TILE + wc * 64 * 64;
+
+  floatx16 acc[4][2];
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[m][n][i] = 0.f;
+  const int nk = p.K / BK;
+
+#define SPLIT_ISSUE(t_, stage_)                                                                          \
+  {                                                                                                      \
+    const size_t kb_ = (size_t)(t_) * (BK * 2);                                                          \
+    const unsigned l_ = lds0 + (stage_) * STAGE + (2 * wave) * 1024;                                     \
+    glds_one4(Atile + kb_, aoff[0], l_);            glds_one4(Atile + kb_, aoff[1], l_ + 1024);          \
+    glds_one4(Btile + kb_, boff[0], l_ + TILE);     glds_one4(Btile + kb_, boff[1], l_ + TILE + 1024);   \
+    glds_one4(Ltile + kb_, boff[0], l_ + 2 * TILE); glds_one4(Ltile + kb_, boff[1], l_ + 2 * TILE + 1024); \
+  }
+#define SB() __builtin_amdgcn_sched_barrier(0)
+  // prologue: slabs 0 and 1 (clamped: K = 32 has a single slab)
+  SPLIT_ISSUE(0, 0)
+  SPLIT_ISSUE(min(1, nk - 1), 1)
+  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");     // slab 0 landed (this wave's part); slab 1 may be in flight
+  __syncthreads();
+  int cur = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    // slab kt + 2 -> the stage slab kt - 1 used (all waves passed the barrier that ended it)
+    {
+      int nx = cur + 2; if (nx >= NST) nx -= NST;
+      SPLIT_ISSUE(min(kt + 2, nk - 1), nx)
+    }
+    const char* base = smem + cur * STAGE;
+    half8 fa[2][4], fh[2][2], fl[2][2];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) fa[0][m] = *(const half8*)(base + a_base + m * 32 * 64 + frag[0]);
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+      fh[0][n] = *(const half8*)(base + b_base + n * 32 * 64 + frag[0]);
+      fl[0][n] = *(const half8*)(base + l_base + n * 32 * 64 + frag[0]);
+    }
+    SB();
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      // 16 MFMAs of k-step ks (8 hi then 8 lo: an accumulator is revisited after 8 others); the 8 fragment reads of
+      // step ks + 1 are spread between the first 8
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+#pragma unroll
+        for (int n = 0; n < 2; ++n) acc[m][n] = mfma32_f16(fa[ks][m], fh[ks][n], acc[m][n]);
+        if (ks == 0) {
+          fa[1][m] = *(const half8*)(base + a_base + m * 32 * 64 + frag[1]);
+          if (m < 2) fh[1][m] = *(const half8*)(base + b_base + m * 32 * 64 + frag[1]);
+          else fl[1][m - 2] = *(const half8*)(base + l_base + (m - 2) * 32 * 64 + frag[1]);
+        }
+        SB();
+      }
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+#pragma unroll
+        for (int n = 0; n < 2; ++n) acc[m][n] = mfma32_f16(fa[ks][m], fl[ks][n], acc[m][n]);
+        SB();
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // slab kt + 1 landed; the 6 loads of slab kt + 2 may be in flight
+    __syncthreads();
+    cur = cur + 1 == NST ? 0 : cur + 1;
+  }
+#undef SPLIT_ISSUE
+#undef SB
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the clamped tail loads: nobody may still be writing LDS
+  __syncthreads();
+
+  // ---------------- epilogue (same as gemm_nt_big_kernel) ----------------
+  float* C32 = p.C32 ? p.C32 + z * p.sC32 : nullptr;
+  _Float16* C16 = p.C16 ? p.C16 + z * p.sC16 : nullptr;
+  const float* bias = p.bias ? p.bias + z * p.sBias : nullptr;
+  const float* res = p.res ? p.res + z * p.sRes : nullptr;
+  const float* gate = p.gate ? p.gate + z * p.sGate : nullptr;
+  if (p.vec_epilogue && !p.pos && !gate && !(bias && p.bias_row)) {
+    float* stage = (float*)smem + wave * (64 * 64);                  // 8 x 16 KiB of the 144 KiB
+    const int row0 = bm0 + 128 * wr, col0 = bn0 + 64 * wc;
+    int lane_e = lane;
+    asm volatile("" : "+v"(lane_e));                                 // see gemm_nt_big_kernel
+    if (res) {
+      epilogue_block64<1>(p, stage, acc[0][0], acc[0][1], acc[1][0], acc[1][1], row0, col0, lane_e, C32, C16, bias, res, gate);
+      epilogue_block64<1>(p, stage, acc[2][0], acc[2][1], acc[3][0], acc[3][1], row0 + 64, col0, lane_e, C32, C16, bias, res, gate);
+    } else {
+      epilogue_block64<0>(p, stage, acc[0][0], acc[0][1], acc[1][0], acc[1][1], row0, col0, lane_e, C32, C16, bias, res, gate);
+      epilogue_block64<0>(p, stage, acc[2][0], acc[2][1], acc[3][0], acc[3][1], row0 + 64, col0, lane_e, C32, C16, bias, res, gate);
+    }
+  } else {
+#define BIG_EP(m_, n_)                                                                                    \
+  {                                                                                                       \
+    const int col = bn0 + 64 * wc + 32 * (n_) + r;                                                        \
+    if (col < p.N) {                                                                                      \
+      const float bcol = (bias && !p.bias_row) ? bias[col] : 0.f;                                         \
+      epilogue_tile(p, acc[m_][n_], bm0 + 128 * wr + 32 * (m_), col, h, bcol, C32, C16, bias, res, gate); \
+    }                                                                                                     \
+  }
+  BIG_EP(0, 0) BIG_EP(0, 1) BIG_EP(1, 0) BIG_EP(1, 1) BIG_EP(2, 0) BIG_EP(2, 1) BIG_EP(3, 0) BIG_EP(3, 1)
+#undef BIG_EP
+  }
+  __syncthreads();   // staging regions read back: the next tile's loads may overwrite them
+  }  // persistent tile loop
+}
+
 }  // namespace dvd
 
 using namespace dvd;
@@ -728,7 +887,22 @@ extern "C" int dvd_gemm_nt(const dvd_gemm_desc* d, void* stream) {
   p.stamps = g_gemm_stamps;
   { const char* sg = getenv("DVD_GEMM_STAGGER"); p.stagger = sg ? atoi(sg) : 0; }   // measured: no effect
   // large-tile kernel for the big f16 GEMMs (decoder): N a multiple of 256, at least a few row tiles
-  const bool big = d->dtype == 0 && d->N % 256 == 0 && d->M >= 1024 && !getenv("DVD_GEMM_V1");
+  // kernel choice depends on (dtype, N, K, split) only, never on M: a document then takes the same kernels - and the
+  // same fp32 summation order - whether it is sampled alone or in a batch (bit-identical results, tested)
+  const bool big = d->dtype == 0 && d->N % 256 == 0 && !getenv("DVD_GEMM_V1");
+  if (big && d->B_lo && !d->A_lo && d->lo_scale == 1.f && d->K % 32 == 0 && !getenv("DVD_GEMM_TWOPASS")) {
+    p.ntm = cdiv(d->M, 256); p.ntn = d->N / 256;
+    constexpr int LDS = 3 * 3 * 256 * 64;
+    static bool once_s = false;
+    if (!once_s) {
+      (void)hipFuncSetAttribute((const void*)gemm_nt_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+      once_s = true;
+    }
+    int nblk = p.ntm * p.ntn;
+    if (nblk > 256) nblk = 256;
+    gemm_nt_split_kernel<<<dim3(nblk, d->batch), 512, LDS, (hipStream_t)stream>>>(p);
+    return check_launch("gemm_nt(split)");
+  }
   if (big) {
     p.ntm = cdiv(d->M, 256); p.ntn = d->N / 256;
     constexpr int LDS = 2 * 2 * 256 * 128;

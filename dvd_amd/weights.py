@@ -127,9 +127,10 @@ def pack(sd, grid: int):
         wp[:, :flat.shape[1]] = flat
         out[f"pyr{i}_w"] = wp
         out[f"pyr{i}_b"] = W(f"pyramid.{n}.bias")
-    # split every f16 weight into hi + 2^-11 * lo (both f16): removes the systematic f16 weight-rounding error
-    # (which accumulates linearly over the diffusion steps) at 2x the GEMM MFMAs - see dvd_gemm_desc.B_lo
+    # split every f16 weight into hi + lo (both f16, lo UNSCALED - mostly f16 subnormals, absolute precision 2^-25,
+    # which the gfx950 f16 MFMA honours): removes the systematic f16 weight-rounding error (which accumulates
+    # linearly over the diffusion steps) at 2x the GEMM MFMAs, in one pass over K - see dvd_gemm_desc.B_lo
     for k in [k for k in out if k.endswith("16")]:
         hi = out[k]
-        out[k + "_lo"] = ((full32[k] - hi.float()) * 2048.0).half()
+        out[k + "_lo"] = (full32[k] - hi.float()).half()
     return {k: v.contiguous() for k, v in out.items()}

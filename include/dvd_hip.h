@@ -101,7 +101,7 @@ int dvd_hyp_mean_clamp(const float* x0, float* out, int docs, int n_hyp, int g, 
  * dtype 0: A,B f16, fp32 accumulate (MFMA 32x32x16 f16);  dtype 1: A,B f32, exact fp32 MFMA.
  *   out = acc (+ bias[col] or bias[row]) -> act -> (+ pos[row % pos_rows][col]) -> (* gate[row / gate_rows][col])
  *         -> (+ res[row][col]);  stored to C32 (f32) and/or C16 (f16).
- * B_lo/lo_scale: weights split into two f16 parts (hi + 2^-11 * lo) give fp32-grade weights at twice the MFMA
+ * B_lo/lo_scale: weights split into two f16 parts (hi + lo_scale * lo) give fp32-grade weights at twice the MFMA
  * work; used for every per-step weight because f16 weight rounding is a SYSTEMATIC error that accumulates
  * linearly over the diffusion steps (precision).
  * Batched over `batch` with element strides (0 = shared operand).  K % 64 == 0 (f16) / % 16 (f32);

@@ -1,5 +1,7 @@
 """GPU parity of the MFMA GEMM (f16 and exact-f32 variants, every epilogue) vs a float64 CPU
 reference of the same op."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -153,3 +155,36 @@ def test_gemm_large_tile_split_weights(ops):
     ops.gemm_nt(hi.cuda(), a.cuda(), out32=out_t, a_lo=lo.cuda())       # weight on the A side, N = M % 256 == 0
     e_a = (out_t.cpu().double().t() - ref).abs().max().item()
     assert e_b < 2e-5 and e_a < 2e-5, (e_b, e_a)
+
+
+@pytest.mark.parametrize("M,N,K", [(2048, 1536, 1536), (1100, 512, 128), (4096, 256, 64), (1024, 2048, 1536)])
+def test_gemm_fused_split_kernel(ops, M, N, K):
+    """lo_scale = 1 with an UNSCALED lo part (f16 subnormals) routes to the one-pass kernel (three LDS tiles, one
+    accumulator set).  Result: fp32-weight grade, and equal to the two-pass kernel up to fp32 summation order;
+    residual + bias + ReLU epilogue and a ragged M included."""
+    a = rnd(f"fa{M}{K}", (M, K)).half()
+    w = rnd(f"fw{N}{K}", (N, K)) * 0.05
+    hi = w.half()
+    lo = (w - hi.float()).half()                      # mostly subnormal
+    assert (lo.float().abs() < 6.2e-5).float().mean() > 0.9
+    ref = a.double() @ w.double().t()
+    out = torch.zeros(M, N, device="cuda")
+    ops.gemm_nt(a.cuda(), hi.cuda(), out32=out, b_lo=lo.cuda(), lo_scale=1.0)
+    e_fused = (out.cpu().double() - ref).abs().max().item()
+    ops.gemm_nt(a.cuda(), hi.cuda(), out32=out)
+    e_plain = (out.cpu().double() - ref).abs().max().item()
+    os.environ["DVD_GEMM_TWOPASS"] = "1"
+    try:
+        out2 = torch.zeros(M, N, device="cuda")
+        ops.gemm_nt(a.cuda(), hi.cuda(), out32=out2, b_lo=lo.cuda(), lo_scale=1.0)
+    finally:
+        os.environ.pop("DVD_GEMM_TWOPASS")
+    e_two = (out2.cpu().double() - ref).abs().max().item()
+    print("fused split", M, N, K, e_plain, e_fused, e_two)
+    assert e_fused < 3e-5 * (K / 1536) ** 0.5 + 2e-6 and e_fused < e_plain / 10, (e_plain, e_fused, e_two)
+    assert e_two < 3e-5
+    bias, res = rnd("fbias", (N,)), rnd("fres", (M, N))
+    o3 = res.clone().cuda()
+    ops.gemm_nt(a.cuda(), hi.cuda(), out32=o3, b_lo=lo.cuda(), lo_scale=1.0, bias=bias.cuda(), act=2, res=o3)
+    ref3 = torch.relu(ref + bias.double()) + res.double()
+    assert (o3.cpu().double() - ref3).abs().max() < 5e-5

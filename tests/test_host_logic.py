@@ -108,7 +108,7 @@ def test_bn_fold_and_split_weights():
                                          torch.from_numpy(sd[pre + "bn.running_var"]),
                                          torch.from_numpy(sd[pre + "bn.weight"]), torch.from_numpy(sd[pre + "bn.bias"]),
                                          False, 0.0, 1e-5)
-    w = p["d2_c1w16"].float() + p["d2_c1w16_lo"].float() / 2048.0
+    w = p["d2_c1w16"].float() + p["d2_c1w16_lo"].float()
     got = torch.einsum("oc,nchw->nohw", w, x) + p["d2_c1b"][None, :, None, None]
     assert (got - ref).abs().max() < 2e-5
     # the split reconstructs the fp32 weight ~2^11 times better than a single f16
