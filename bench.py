@@ -150,7 +150,7 @@ def main():
         if launches:
             avg_s = attn_ms / launches * 1e-3
             achieved = attn_launch_per_sample * n / avg_s / 1e12
-            roof = {"kernel": "flash_attn_glds_kernel<256,0> (decoder self-attention, 6 heads x 256)", "bound": "mfma",
+            roof = {"kernel": "flash_attn_r64_kernel<0> (decoder self-attention, 6 heads x 256)", "bound": "mfma",
                     "achieved": round(achieved, 1), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved / PEAK_F16_TFLOPS, 4), "traffic": None,
                     "algorithmic_bytes_per_launch": 4 * n * (G // 2) ** 2 * 1536 * 2,   # Q, K, V^T read + O written, f16
@@ -162,7 +162,7 @@ def main():
             tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_pmc_traffic.json")
             if os.path.exists(tpath) and (n, G) == (16, 288):
                 tj = json.load(open(tpath))
-                key = [k for k in tj if "flash_attn_glds_kernel<256" in k]
+                key = [k for k in tj if "flash_attn_r64_kernel" in k or "flash_attn_glds_kernel<256" in k]
                 if key:
                     roof["traffic"] = int(tj[key[0]]["hbm_bytes_per_launch"])
                     roof["traffic_unit"] = "bytes/launch"

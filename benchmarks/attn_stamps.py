@@ -11,12 +11,15 @@ Cc = 6 * hd
 qk = torch.randn(B, T, 2 * Cc, device="cuda").half(); vt = torch.randn(B, Cc, T, device="cuda").half()
 out = torch.empty(B, T, Cc, dtype=torch.float16, device="cuda")
 nwg = (T // 128) * 6 * B
+if not os.environ.get("DVD_ATTN_R32") and not os.environ.get("DVD_ATTN_PIPE") and not os.environ.get("DVD_ATTN_BULK"):
+    nwg = (T // 256) * 6 * B
 st = torch.zeros(nwg * 4 * 5, dtype=torch.int64, device="cuda")
 lib.call("dvd_attn_debug_stamps", C.c_void_p(st.data_ptr()))
 for _ in range(2):
     ops.flash_attn(qk[:, :, :Cc], qk[:, :, Cc:], vt, out, 6, hd, 1.0 / (hd ** 0.5))
 torch.cuda.synchronize()
-s = st.view(nwg * 4, 5).cpu().double() / (T // 64)
+per_tile = 64 if (os.environ.get("DVD_ATTN_R32") or os.environ.get("DVD_ATTN_PIPE") or os.environ.get("DVD_ATTN_BULK")) else 32
+s = st.view(nwg * 4, 5).cpu().double() / (T // per_tile)
 names = ["issue LDS-DMA (16 loads)", "S^T phase (32 MFMA)", "max/rescale + P chunk 0", "PV phase (32 MFMA) + softmax", "vmcnt(0) + barrier"]
 if os.environ.get("DVD_ATTN_PIPE"):   # software-pipelined kernel: per 64-key tile = 2 blocks
     names = ["2 x (K prefetch issue + max tree + rescale test)", "2 x (16 S^T MFMA || 13 exps)", "2 x (16 PV MFMA || 3 exps, sa+sb)",

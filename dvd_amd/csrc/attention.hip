@@ -618,6 +618,226 @@ __global__ void __launch_bounds__(256, (D == 256 ? 1 : DVD_ATTN64_OCC)) flash_at
 
 
 // ================================================================================================
+// head_dim 256, TWO 32-row query blocks per wave, 32-key tiles ("r64").  flash_attn_glds_kernel<256> is bound by the CU's
+// LDS port: every MFMA of every wave needs its own 1-KiB fragment (4 waves x 1 KiB per 32-cycle MFMA = 128 B/clk = the
+// port's peak; benchmarks/lab/mix_lab.hip: 33.2 cycles per MFMA with fragment reads alone, 42.9 with the tile refill on
+// top).  Here one K / V^T fragment read feeds TWO MFMAs (query rows r and 32 + r), which needs O^T for 64 rows = all 256
+// AGPRs and Q for 64 rows = 128 VGPRs; the rest fits only because the key tile is halved to 32 keys (S^T 32 + P 16
+// registers for both row blocks) and the swizzled fragment offsets are recomputed with one v_xor instead of being kept.
+// A workgroup = 4 waves = 256 query rows, so K / V^T are also streamed from L2 half as often.  Same fragment maps,
+// deferred-rescale online softmax (one running max / sum per row block) and per-element arithmetic as the 32-row kernel.
+// LDS image: K tile 32 keys x 512 B, chunk c of row r at c ^ (r & 15); V^T tile 256 rows x 64 B, chunk c of row r at
+// c ^ ((r >> 2) & 3); two 32-KiB buffers.
+// ================================================================================================
+template <int DBG>
+__global__ void __launch_bounds__(256, 1) flash_attn_r64_kernel(AttnArgs p) {
+  constexpr int D = 256, KB = 32, KROWB = 512, KBYTES = KB * KROWB, VROWB = 64, VBYTES = D * VROWB, BUF = KBYTES + VBYTES;
+  constexpr int KS = 16, DT = 8, RB = 2;
+  constexpr float RESCALE_THR = 10.f;
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][BUF]
+  typedef __attribute__((address_space(3))) void* lptr_t;
+
+  const int nwg = gridDim.x;
+  int id = blockIdx.x;
+  {
+    const int q = nwg / 8, rr = nwg % 8, xcd = id % 8, k = id / 8;
+    id = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + k;
+  }
+  const int qb = id % p.nqb;          // 256-row query blocks
+  const int bh = id / p.nqb;
+  const int head = bh % p.heads, b = bh / p.heads;
+  const int kvb = b / p.kv_div;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+
+  const _Float16* Qg = p.Q + b * p.sQ + (size_t)head * D;
+  const char* Kg = (const char*)(p.K + kvb * p.sK + (size_t)head * D);
+  const char* Vg = (const char*)(p.Vt + kvb * p.sVt + (size_t)head * D * p.ldvt);
+
+  half8 qf[RB][KS];
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) {
+    const int qrow = min(qb * 256 + wave * 64 + rb * 32 + r, p.tq - 1);
+    const _Float16* qp = Qg + (size_t)qrow * p.ldq + 8 * h;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) qf[rb][ks] = *(const half8*)(qp + 16 * ks);
+  }
+  __builtin_amdgcn_s_waitcnt(0x0F70);   // retire the Q loads with a wait the compiler tracks (see flash_attn_glds_kernel)
+
+  // per-lane SOURCE offsets of this wave's 4 + 4 direct-to-LDS loads per tile
+  unsigned koff[4], voff[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int q = (4 * wave + i) * 64 + lane;
+    const int krow = q >> 5, kpos = q & 31;
+    koff[i] = (unsigned)krow * (unsigned)(p.ldk * 2) + (unsigned)((kpos ^ (krow & 15)) * 16);
+    const int vrow = q >> 2, vpos = q & 3;
+    voff[i] = (unsigned)vrow * (unsigned)(p.ldvt * 2) + (unsigned)((vpos ^ ((vrow >> 2) & 3)) * 16);
+  }
+  // fragment read offsets, recomputed per read from two per-lane bases:
+  //   K, k-step ks :  kr*512 + (((2 ks + h) ^ (kr & 15)) * 16)   =  kbase ^ (ks * 32)      (kr & 15 only touches bits 4..7,
+  //                                                                   2 ks * 16 = ks * 32 touches bits 5..8: plain XOR)
+  //   V^T, chunk c, d block dt :  KBYTES + (32 dt + r)*64 + (((2 c + h) ^ ((r >> 2) & 3)) * 16)  =  (vbase ^ (c * 32)) + dt * 2048
+  const int kr = kappa(r);
+  const int kbase = kr * KROWB + ((h ^ (kr & 15)) * 16);
+  const int vbase = KBYTES + r * VROWB + ((h ^ ((r >> 2) & 3)) * 16);
+
+  floatx16 o[RB][DT];
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) o[rb][dt][i] = 0.f;
+  float m_run[RB] = {-1e30f, -1e30f}, l_run[RB] = {0.f, 0.f};
+  const int nt = p.tk / KB;
+  const size_t ktile = (size_t)KB * p.ldk * 2;
+  const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t)smem;
+
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    glds_one(Kg, koff[i], lds0 + (4 * wave + i) * 1024);
+    glds_one(Vg, voff[i], lds0 + KBYTES + (4 * wave + i) * 1024);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+#define SB() __builtin_amdgcn_sched_barrier(0)
+#define KFRAG(ks_) (*(const half8*)(base + (kbase ^ ((ks_) * 32))))
+#define VFRAG(c_, dt_) (*(const half8*)(base + (vbase ^ ((c_) * 32)) + (dt_) * 2048))
+  unsigned long long acc_t[5] = {0, 0, 0, 0, 0};
+  unsigned long long tprev = 0;
+#define STAMP(k_)                                                              \
+  if constexpr (DBG & 1) {                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                         \
+    const unsigned long long now_ = __builtin_amdgcn_s_memtime();              \
+    __builtin_amdgcn_s_waitcnt(0xC07F);                                        \
+    acc_t[k_] += now_ - tprev;                                                 \
+    tprev = now_;                                                              \
+    __builtin_amdgcn_sched_barrier(0);                                         \
+  }
+  if constexpr (DBG & 1) tprev = __builtin_amdgcn_s_memtime();
+  int cur = 0;
+  for (int t = 0; t < nt; ++t) {
+    const int tn = min(t + 1, nt - 1);
+    const char* kg_next = Kg + (size_t)tn * ktile;
+    const char* vg_next = Vg + (size_t)tn * (KB * 2);
+    const unsigned lds_next = lds0 + (cur ^ 1) * BUF + (4 * wave) * 1024;
+    const char* base = smem + cur * BUF;
+    STAMP(0)
+    half8 fr[4];
+    floatx16 s[RB];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) fr[f] = KFRAG(f);
+    SB();
+    // ---- S^T = K.Q^T : 16 K fragments, two MFMAs each; the next tile's 8 loads go out after every second fragment
+#pragma unroll
+    for (int f = 0; f < KS; ++f) {
+      // S^T accumulates in ARCHITECTURAL VGPRs, by inline asm: left to the compiler these MFMAs get AGPR destinations,
+      // and as O^T owns all 256 AGPRs it then evicts two O^T accumulators to VGPRs and back every tile (64 moves).
+      // The two chains alternate, so a dependent MFMA is always one independent 8-pass MFMA behind its producer.
+      if (f == 0) {      // first step: C = 0 as an inline constant instead of 32 v_mov per tile
+        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=v"(s[0]) : "v"(fr[0]), "v"(qf[0][0]));
+        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=v"(s[1]) : "v"(fr[0]), "v"(qf[1][0]));
+      } else {
+        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(s[0]) : "v"(fr[f & 3]), "v"(qf[0][f]));
+        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(s[1]) : "v"(fr[f & 3]), "v"(qf[1][f]));
+      }
+      if (f + 4 < KS) fr[f & 3] = KFRAG(f + 4);
+      else fr[f & 3] = VFRAG(0, f + 4 - KS);
+      if (f & 1) {
+        if (f < 8) glds_one(kg_next, koff[f >> 1], lds_next + (f >> 1) * 1024);
+        else glds_one(vg_next, voff[(f >> 1) - 4], lds_next + KBYTES + ((f >> 1) - 4) * 1024);
+      }
+      SB();
+    }
+    asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");      // the last two MFMAs' results must have landed before the VALU reads them
+    STAMP(1)
+    // ---- online softmax, per row block
+    float mx[RB];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+      float m = -1e30f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) m = fmaxf(m, s[rb][i]);
+      mx[rb] = half_swap_max(m * p.c);
+    }
+    if (__any(fmaxf(mx[0] - m_run[0], mx[1] - m_run[1]) > RESCALE_THR)) {     // deferred rescale
+#pragma unroll
+      for (int rb = 0; rb < RB; ++rb) {
+        const float m_new = fmaxf(m_run[rb], mx[rb]);
+        const float alpha = __builtin_amdgcn_exp2f(m_run[rb] - m_new);
+        m_run[rb] = m_new;
+        l_run[rb] *= alpha;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) scale_acc_in_agpr(o[rb][dt], alpha);
+      }
+    }
+    float rs[RB] = {0.f, 0.f};
+    half8 pf[RB][2];
+#define PEXP4(rb_, c_, e_)                                                                          \
+  {                                                                                                 \
+    const float pv_ = __builtin_amdgcn_exp2f(fmaf(s[rb_][8 * (c_) + (e_)], p.c, -m_run[rb_]));      \
+    rs[rb_] += pv_;                                                                                 \
+    pf[rb_][c_][e_] = (_Float16)pv_;                                                                \
+  }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { PEXP4(0, 0, e) PEXP4(1, 0, e) }
+    STAMP(2)
+    SB();
+    // ---- O^T += V^T.P : 16 V^T fragments (chunk c, d block dt), two MFMAs each; chunk 1's exps in chunk 0's gaps
+#pragma unroll
+    for (int f = 0; f < 2 * DT; ++f) {
+      const int c = f >> 3, dt = f & 7;
+      o[0][dt] = mfma32_f16(fr[f & 3], pf[0][c], o[0][dt]);
+      o[1][dt] = mfma32_f16(fr[f & 3], pf[1][c], o[1][dt]);
+      if (f + 4 < 2 * DT) fr[f & 3] = VFRAG((f + 4) >> 3, (f + 4) & 7);
+      if (c == 0) { PEXP4(0, 1, dt) PEXP4(1, 1, dt) }
+      SB();
+    }
+    l_run[0] += rs[0];
+    l_run[1] += rs[1];
+    STAMP(3)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    STAMP(4)
+    cur ^= 1;
+  }
+  if constexpr (DBG & 1) {
+    if (lane == 0 && p.stamps) {
+      unsigned long long* o_ = p.stamps + ((size_t)blockIdx.x * 4 + wave) * 5;
+      for (int k = 0; k < 5; ++k) o_[k] = acc_t[k];
+    }
+  }
+#undef STAMP
+#undef SB
+#undef KFRAG
+#undef VFRAG
+#undef PEXP4
+
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) {
+    const float l_tot = l_run[rb] + __shfl_xor(l_run[rb], 32);
+    const float inv = 1.f / l_tot;
+    const int qglob = qb * 256 + wave * 64 + rb * 32 + r;
+    if (qglob < p.tq) {
+      _Float16* op = p.O + b * p.sO + (size_t)qglob * p.ldo + (size_t)head * D;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          half4 v;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = (_Float16)(o[rb][dt][4 * g4 + j] * inv);
+          *(half4*)(op + 32 * dt + 8 * g4 + 4 * h) = v;
+        }
+    }
+  }
+}
+
+
+// ================================================================================================
 // head_dim 64, TWO 32-row query blocks per wave (a workgroup = 4 waves = 256 query rows).  flash_attn_glds_kernel<64>
 // runs two waves per SIMD, and every MFMA of every wave needs its own 1-KiB fragment from LDS: 8 waves x 1 KiB per
 // 32-cycle MFMA slot = 256 B/clk, twice what the CU's LDS port delivers - that, not the softmax VALU, held the kernel at
@@ -1296,6 +1516,25 @@ extern "C" int dvd_flash_attn(const dvd_attn_desc* d, void* stream) {
       (void)hipFuncSetAttribute((const void*)flash_attn_glds_kernel<256, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
       (void)hipFuncSetAttribute((const void*)flash_attn_glds_kernel<256, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
       once2 = true;
+    }
+    // 64 query rows per wave (256 per workgroup) when that still fills the chip at least twice over; small problems
+    // keep the 128-row workgroups.  DVD_ATTN_R32=1 forces the 32-row kernel (A/B runs).
+    const long wg256 = (long)cdiv(d->tq, 256) * d->heads * d->batch;
+    if ((wg256 >= 512 || getenv("DVD_ATTN_R64")) && !getenv("DVD_ATTN_R32") && !getenv("DVD_ATTN_PIPE") &&
+        !getenv("DVD_ATTN_BULK")) {
+      constexpr int LDS64 = 2 * (32 * 512 + 256 * 64);
+      static bool once5 = false;
+      if (!once5) {
+        (void)hipFuncSetAttribute((const void*)flash_attn_r64_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS64);
+        (void)hipFuncSetAttribute((const void*)flash_attn_r64_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS64);
+        once5 = true;
+      }
+      const long nqb2 = cdiv(d->tq, 256);
+      p.nqb = (int)nqb2;
+      const unsigned g = (unsigned)(nqb2 * d->heads * d->batch);
+      if (getenv("DVD_ATTN_DEBUG")) flash_attn_r64_kernel<1><<<g, 256, LDS64, (hipStream_t)stream>>>(p);
+      else flash_attn_r64_kernel<0><<<g, 256, LDS64, (hipStream_t)stream>>>(p);
+      return check_launch("flash_attn");
     }
     static bool once4 = false;
     if (!once4) {

@@ -755,11 +755,6 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_split_kernel(GemmArgs p) {
   __syncthreads();
   int cur = 0;
   for (int kt = 0; kt < nk; ++kt) {
-    // slab kt + 2 -> the stage slab kt - 1 used (all waves passed the barrier that ended it)
-    {
-      int nx = cur + 2; if (nx >= NST) nx -= NST;
-      SPLIT_ISSUE(min(kt + 2, nk - 1), nx)
-    }
     const char* base = smem + cur * STAGE;
     half8 fa[2][4], fh[2][2], fl[2][2];
 #pragma unroll
@@ -768,6 +763,13 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_split_kernel(GemmArgs p) {
     for (int n = 0; n < 2; ++n) {
       fh[0][n] = *(const half8*)(base + b_base + n * 32 * 64 + frag[0]);
       fl[0][n] = *(const half8*)(base + l_base + n * 32 * 64 + frag[0]);
+    }
+    SB();
+    // slab kt + 2 -> the stage slab kt - 1 used (all waves passed the barrier that ended it); issued AFTER the first
+    // fragment reads so that these are not queued behind six LDS-DMA issues
+    {
+      int nx = cur + 2; if (nx >= NST) nx -= NST;
+      SPLIT_ISSUE(min(kt + 2, nk - 1), nx)
     }
     SB();
 #pragma unroll
