@@ -29,6 +29,9 @@
 #ifndef DVD_ATTN64_OCC
 #define DVD_ATTN64_OCC 2   /* 3 waves per SIMD fit (140 VGPRs) and measure the same 838 TF/s; 4 spill */
 #endif
+#ifndef DVD_ATTN64_ROWSUM
+#define DVD_ATTN64_ROWSUM 0
+#endif
 #ifndef DVD_ATTN_PF
 #define DVD_ATTN_PF 4
 #endif
@@ -427,7 +430,7 @@ __global__ void __launch_bounds__(256, (D == 256 ? 1 : DVD_ATTN64_OCC)) flash_at
   // accumulate sum_k P[k, q] into osum (4 MFMAs per tile instead of 32 v_add_f32).  Correct, but head_dim 64 measured
   // the same with it (861 vs 895 TF/s, inside the box-to-box noise), as it did with two query row blocks per wave and
   // with three waves per SIMD: none of LDS traffic, barrier count, VALU adds or occupancy is what holds it at ~36 %.
-  constexpr bool MFMA_ROWSUM = false;
+  constexpr bool MFMA_ROWSUM = (D == 64) && DVD_ATTN64_ROWSUM;
   floatx16 osum;
   half8 ones8;
 #pragma unroll
