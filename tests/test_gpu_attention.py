@@ -66,3 +66,33 @@ def test_attention_fused_qkv_views(ops):
     ops.flash_attn(qk[:, :, :C], qk[:, :, C:], vt, out, heads, hd, 0.125)
     ref = ref_attn(qk[:, :, :C].cpu(), qk[:, :, C:].cpu(), v, heads, hd, 0.125, 1)
     assert (out.cpu().double() - ref).abs().max() < 2e-3
+
+
+VARIANTS = {
+    "r64 (64 query rows per wave; the default at production sizes)": {"DVD_ATTN_R64": "1"},
+    "r32 (flash_attn_glds_kernel)": {"DVD_ATTN_R32": "1"},
+    "bulk LDS-DMA issue": {"DVD_ATTN_BULK": "1"},
+    "register-staged v1": {"DVD_ATTN_V1": "1"},
+    "half-tile software pipeline (experiment)": {"DVD_ATTN_PIPE": "1"},
+    "head-dim split, two waves per SIMD (experiment)": {"DVD_ATTN_DSPLIT": "1"},
+    "hd64 two row blocks per wave (experiment)": {"DVD_ATTN_64X2": "1"},
+}
+
+
+@pytest.mark.parametrize("variant", list(VARIANTS))
+@pytest.mark.parametrize("hd,scale", [(64, 0.125), (256, 0.0625)])
+def test_attention_kernel_variants(ops, monkeypatch, variant, hd, scale):
+    """Every kernel behind a DVD_ATTN_* switch - the production ones selected by problem size and the documented
+    experiments alike - against the float64 reference: ragged query count, shared K/V, a forced rescale."""
+    for k, v in VARIANTS[variant].items():
+        monkeypatch.setenv(k, v)
+    err, mag = run(ops, 4, 2, 300, 512, 6, hd, scale)
+    assert err < 2e-3 * max(1.0, mag), (variant, err, mag)
+    err, mag = run(ops, 1, 1, 128, 512, 6, hd, scale, amp=1.5, spike=True)
+    assert err < 3e-3 * max(1.0, mag), (variant, err, mag)
+
+
+def test_attention_r64_large(ops):
+    """A problem large enough to take the 64-row kernel WITHOUT any switch (>= 512 workgroups of 256 rows)."""
+    err, mag = run(ops, 24, 24, 1024, 512, 6, 256, 0.0625)
+    assert err < 2e-3 * max(1.0, mag), (err, mag)
