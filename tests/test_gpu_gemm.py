@@ -188,3 +188,28 @@ def test_gemm_fused_split_kernel(ops, M, N, K):
     ops.gemm_nt(a.cuda(), hi.cuda(), out32=o3, b_lo=lo.cuda(), lo_scale=1.0, bias=bias.cuda(), act=2, res=o3)
     ref3 = torch.relu(ref + bias.double()) + res.double()
     assert (o3.cpu().double() - ref3).abs().max() < 5e-5
+
+
+@pytest.mark.parametrize("env", [{}, {"DVD_GEMM_TWOPASS": "1"}, {"DVD_GEMM_V1": "1"}, {"DVD_GEMM_SPREAD": "1"},
+                                 {"DVD_GEMM_SCALAR_EPILOGUE": "1"}, {"DVD_GEMM_NONPERSISTENT": "1"}],
+                         ids=lambda e: next(iter(e), "default"))
+def test_gemm_kernel_variants(ops, monkeypatch, env):
+    """Every GEMM path behind a DVD_GEMM_* switch: split weights (scaled and unscaled lo), residual + bias + ReLU, f16
+    output with GELU, ragged M - against float64."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    M, N, K = 1100, 512, 256
+    a = rnd("va", (M, K)).half()
+    w = rnd("vw", (N, K)) * 0.05
+    hi = w.half()
+    ref = a.double() @ w.double().t()
+    bias, res = rnd("vbias", (N,)), rnd("vres", (M, N))
+    for lo, scale in (((w - hi.float()).half(), 1.0), (((w - hi.float()) * 2048.0).half(), 2.0 ** -11)):
+        out = res.clone().cuda()
+        ops.gemm_nt(a.cuda(), hi.cuda(), out32=out, b_lo=lo.cuda(), lo_scale=scale, bias=bias.cuda(), act=2, res=out)
+        ref2 = torch.relu(ref + bias.double()) + res.double()
+        assert (out.cpu().double() - ref2).abs().max() < 2e-5, (env, scale)
+    out16 = torch.zeros(M, N, dtype=torch.float16, device="cuda")
+    ops.gemm_nt(a.cuda(), hi.cuda(), out16=out16, bias=bias.cuda(), act=1)
+    refg = torch.nn.functional.gelu((a.double() @ hi.double().t()) + bias.double(), approximate="tanh")
+    assert (out16.cpu().double() - refg).abs().max() < 2e-3, env
