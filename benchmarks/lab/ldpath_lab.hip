@@ -48,6 +48,14 @@ __global__ void __launch_bounds__(256) ld_kernel(const char* __restrict__ g, uns
   for (int t = 0; t < NT; ++t) {
     const char* gt = g + (size_t)((t + (blockIdx.x >> SHIFT)) % NT) * TILE;
     if (wave >= active) {
+    } else if (MODE == 3) {          // half the tile by LDS-DMA, the other half through registers + ds_write
+      glds8(gt, voff, lds0 + (wave * 16) * 1024);
+      u32x4 v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const u32x4*>(gt + (wave * 16 + 8 + j) * 1024 + lane * 16);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) *reinterpret_cast<u32x4*>(lds + (wave * 16 + 8 + j) * 1024 + lane * 16) = v[j];
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else if (MODE == 0) {
       glds8(gt, voff, lds0 + (wave * 16) * 1024);
       glds8(gt + 8192, voff, lds0 + (wave * 16 + 8) * 1024);
@@ -80,15 +88,16 @@ int main() {
   CK(hipMalloc(&g, (size_t)NT * TILE)); CK(hipMemset(g, 1, (size_t)NT * TILE));
   CK(hipMalloc(&sink, 256 * 256 * 4)); CK(hipMalloc(&clk, 256 * 8));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  const char* names[3] = {"LDS-DMA global_load_lds_dwordx4", "global_load_dwordx4 -> VGPR", "global_load_dwordx4 -> VGPR -> ds_write_b128"};
+  const char* names[4] = {"LDS-DMA global_load_lds_dwordx4", "global_load_dwordx4 -> VGPR", "global_load_dwordx4 -> VGPR -> ds_write_b128", "half LDS-DMA + half VGPR -> ds_write"};
   constexpr int SH = 10;   // all workgroups stream the same tile sequence (L2 hits), like the q-blocks of one head
   for (int active : {4, 2, 1})
   for (int wgs : {256}) {
-    for (int mode = 0; mode < 3; ++mode) {
+    for (int mode = 0; mode < 4; ++mode) {
       auto launch = [&]() {
         if (mode == 0) ld_kernel<0, SH><<<wgs, 256, TILE>>>(g, sink, clk, active);
         if (mode == 1) ld_kernel<1, SH><<<wgs, 256, TILE>>>(g, sink, clk, active);
         if (mode == 2) ld_kernel<2, SH><<<wgs, 256, TILE>>>(g, sink, clk, active);
+        if (mode == 3) ld_kernel<3, SH><<<wgs, 256, TILE>>>(g, sink, clk, active);
       };
       launch(); CK(hipDeviceSynchronize());
       CK(hipEventRecord(e0)); launch(); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));

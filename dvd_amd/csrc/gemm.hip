@@ -753,51 +753,52 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_split_kernel(GemmArgs p) {
   SPLIT_ISSUE(min(1, nk - 1), 1)
   asm volatile("s_waitcnt vmcnt(6)" ::: "memory");     // slab 0 landed (this wave's part); slab 1 may be in flight
   __syncthreads();
+  // The loop is skewed by half a slab so that no wave ever starts a slab with cold fragment registers: the barrier
+  // that publishes slab kt + 1 sits in the MIDDLE of slab kt, and the second half of slab kt already reads the first
+  // fragments of slab kt + 1 between its MFMAs.  (With the barrier at the end of the slab both waves of a SIMD stall
+  // together on ~150 cycles of LDS latency + the barrier, once per 32 MFMAs.)
+  half8 fa[2][4], fh[2][2], fl[2][2];
+#define SPLIT_READ(set_, base_, ks_)                                                                  \
+  {                                                                                                   \
+    _Pragma("unroll") for (int m = 0; m < 4; ++m) fa[set_][m] = *(const half8*)((base_) + a_base + m * 32 * 64 + frag[ks_]); \
+    _Pragma("unroll") for (int n = 0; n < 2; ++n) {                                                   \
+      fh[set_][n] = *(const half8*)((base_) + b_base + n * 32 * 64 + frag[ks_]);                      \
+      fl[set_][n] = *(const half8*)((base_) + l_base + n * 32 * 64 + frag[ks_]);                      \
+    }                                                                                                 \
+  }
+  // 16 MFMAs of one k-step (8 hi then 8 lo: an accumulator is revisited after 8 others); the 8 fragment reads of the
+  // NEXT k-step (set nset_, from nbase_ at k-step nks_) are spread between the first 8
+#define SPLIT_KSTEP(set_, nset_, nbase_, nks_)                                                        \
+  {                                                                                                   \
+    _Pragma("unroll") for (int m = 0; m < 4; ++m) {                                                   \
+      _Pragma("unroll") for (int n = 0; n < 2; ++n) acc[m][n] = mfma32_f16(fa[set_][m], fh[set_][n], acc[m][n]); \
+      fa[nset_][m] = *(const half8*)((nbase_) + a_base + m * 32 * 64 + frag[nks_]);                   \
+      if (m < 2) fh[nset_][m] = *(const half8*)((nbase_) + b_base + m * 32 * 64 + frag[nks_]);        \
+      else fl[nset_][m - 2] = *(const half8*)((nbase_) + l_base + (m - 2) * 32 * 64 + frag[nks_]);    \
+      SB();                                                                                           \
+    }                                                                                                 \
+    _Pragma("unroll") for (int m = 0; m < 4; ++m) {                                                   \
+      _Pragma("unroll") for (int n = 0; n < 2; ++n) acc[m][n] = mfma32_f16(fa[set_][m], fl[set_][n], acc[m][n]); \
+      SB();                                                                                           \
+    }                                                                                                 \
+  }
+  SPLIT_READ(0, smem, 0)
+  SB();
   int cur = 0;
   for (int kt = 0; kt < nk; ++kt) {
     const char* base = smem + cur * STAGE;
-    half8 fa[2][4], fh[2][2], fl[2][2];
-#pragma unroll
-    for (int m = 0; m < 4; ++m) fa[0][m] = *(const half8*)(base + a_base + m * 32 * 64 + frag[0]);
-#pragma unroll
-    for (int n = 0; n < 2; ++n) {
-      fh[0][n] = *(const half8*)(base + b_base + n * 32 * 64 + frag[0]);
-      fl[0][n] = *(const half8*)(base + l_base + n * 32 * 64 + frag[0]);
-    }
+    int n1 = cur + 1; if (n1 >= NST) n1 -= NST;
+    int n2 = cur + 2; if (n2 >= NST) n2 -= NST;
+    SPLIT_KSTEP(0, 1, base, 1)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // slab kt + 1 (issued half a slab ago or in the prologue) landed
+    __syncthreads();                                   // ... for everyone; and everyone is past slab kt - 1
+    SPLIT_ISSUE(min(kt + 2, nk - 1), n2)               // -> the stage slab kt - 1 used
     SB();
-    // slab kt + 2 -> the stage slab kt - 1 used (all waves passed the barrier that ended it); issued AFTER the first
-    // fragment reads so that these are not queued behind six LDS-DMA issues
-    {
-      int nx = cur + 2; if (nx >= NST) nx -= NST;
-      SPLIT_ISSUE(min(kt + 2, nk - 1), nx)
-    }
-    SB();
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      // 16 MFMAs of k-step ks (8 hi then 8 lo: an accumulator is revisited after 8 others); the 8 fragment reads of
-      // step ks + 1 are spread between the first 8
-#pragma unroll
-      for (int m = 0; m < 4; ++m) {
-#pragma unroll
-        for (int n = 0; n < 2; ++n) acc[m][n] = mfma32_f16(fa[ks][m], fh[ks][n], acc[m][n]);
-        if (ks == 0) {
-          fa[1][m] = *(const half8*)(base + a_base + m * 32 * 64 + frag[1]);
-          if (m < 2) fh[1][m] = *(const half8*)(base + b_base + m * 32 * 64 + frag[1]);
-          else fl[1][m - 2] = *(const half8*)(base + l_base + (m - 2) * 32 * 64 + frag[1]);
-        }
-        SB();
-      }
-#pragma unroll
-      for (int m = 0; m < 4; ++m) {
-#pragma unroll
-        for (int n = 0; n < 2; ++n) acc[m][n] = mfma32_f16(fa[ks][m], fl[ks][n], acc[m][n]);
-        SB();
-      }
-    }
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // slab kt + 1 landed; the 6 loads of slab kt + 2 may be in flight
-    __syncthreads();
-    cur = cur + 1 == NST ? 0 : cur + 1;
+    SPLIT_KSTEP(1, 0, smem + n1 * STAGE, 0)            // second half: already reads slab kt + 1's first fragments
+    cur = n1;
   }
+#undef SPLIT_READ
+#undef SPLIT_KSTEP
 #undef SPLIT_ISSUE
 #undef SB
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the clamped tail loads: nobody may still be writing LDS
