@@ -162,7 +162,7 @@ def main():
             tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_pmc_traffic.json")
             if os.path.exists(tpath) and (n, G) == (16, 288):
                 tj = json.load(open(tpath))
-                key = [k for k in tj if "flash_attn_r64_kernel" in k or "flash_attn_glds_kernel<256" in k]
+                key = [k for k in tj if "flash_attn_r64_kernel" in k] or [k for k in tj if "flash_attn_glds_kernel<256" in k]
                 if key:
                     roof["traffic"] = int(tj[key[0]]["hbm_bytes_per_launch"])
                     roof["traffic_unit"] = "bytes/launch"
