@@ -155,7 +155,8 @@ __device__ __forceinline__ void epilogue_block64(const GemmArgs& p, float* stage
   // EPI 1 needs compile-time window slots (it & 3): unrolled by 4.  The other flavours are unrolled by 2 only: fully
   // unrolled, the compiler hoists every iteration's addresses out of the persistent tile loop and spills them, and each
   // scratch reload is a vmcnt(0) - i.e. a wait for the previous store again.
-#pragma unroll(EPI == 1 ? 4 : (EPI == 3 ? 8 : 2))
+  constexpr int EPI_UNROLL = EPI == 1 ? 4 : (EPI == 3 ? 8 : 2);
+#pragma unroll EPI_UNROLL
   for (int it = 0; it < 8; ++it) {
     const int lr = it * 8 + (lane >> 3);
     const int row = row0 + lr;
