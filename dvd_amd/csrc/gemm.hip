@@ -793,9 +793,31 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_split_kernel(GemmArgs p) {
     SPLIT_KSTEP(0, 1, base, 1)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // slab kt + 1 (issued half a slab ago or in the prologue) landed
     __syncthreads();                                   // ... for everyone; and everyone is past slab kt - 1
-    SPLIT_ISSUE(min(kt + 2, nk - 1), n2)               // -> the stage slab kt - 1 used
+    // -> the stage slab kt - 1 used.  The two waves of a SIMD issue their six loads at different points of the second
+    // half (right after the barrier / between its hi and lo MFMAs), so one's issue stalls sit under the other's MFMAs
+    // (+1..3 %; spreading the six loads one by one behind run-time wave-group tests was slower again)
+    if (wave < 4) SPLIT_ISSUE(min(kt + 2, nk - 1), n2)
     SB();
-    SPLIT_KSTEP(1, 0, smem + n1 * STAGE, 0)            // second half: already reads slab kt + 1's first fragments
+    {
+      const char* nb = smem + n1 * STAGE;              // second half: already reads slab kt + 1's first fragments
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+#pragma unroll
+        for (int n = 0; n < 2; ++n) acc[m][n] = mfma32_f16(fa[1][m], fh[1][n], acc[m][n]);
+        fa[0][m] = *(const half8*)(nb + a_base + m * 32 * 64 + frag[0]);
+        if (m < 2) fh[0][m] = *(const half8*)(nb + b_base + m * 32 * 64 + frag[0]);
+        else fl[0][m - 2] = *(const half8*)(nb + l_base + (m - 2) * 32 * 64 + frag[0]);
+        SB();
+      }
+      if (wave >= 4) SPLIT_ISSUE(min(kt + 2, nk - 1), n2)
+      SB();
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+#pragma unroll
+        for (int n = 0; n < 2; ++n) acc[m][n] = mfma32_f16(fa[1][m], fl[1][n], acc[m][n]);
+        SB();
+      }
+    }
     cur = n1;
   }
 #undef SPLIT_READ
