@@ -560,7 +560,9 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_big_kernel(GemmArgs p) {
   // the one-wave-per-SIMD attention kernel where spreading gained 10 %.
   constexpr bool SPREAD = (DBG == 4);
   for (int kt = 0; kt < nk; ++kt) {
-    if (!SPREAD && DBG != 1 && kt + 1 < nk) BIG_ISSUE(kt + 1, cur ^ 1)
+    // waves 0-3 (one per SIMD) issue their burst here, waves 4-7 after the first of the four k-steps: the two waves of
+    // a SIMD then do not sit in their issue stalls at the same time
+    if (!SPREAD && DBG != 1 && kt + 1 < nk && wave < 4) BIG_ISSUE(kt + 1, cur ^ 1)
     const int tnx = min(kt + 1, nk - 1);
     const bool lo_nx = tnx < nlo;
     const size_t kb_nx = (size_t)(lo_nx ? tnx : tnx - nlo) * (BK * 2);
@@ -598,6 +600,10 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_big_kernel(GemmArgs p) {
             else glds_one4(b_nx, boff[k & 3], lds_nx + TILE + (k & 3) * 1024);
           }
         }
+        SB();
+      }
+      if (s4 == 0) {
+        if (!SPREAD && DBG != 1 && kt + 1 < nk && wave >= 4) BIG_ISSUE(kt + 1, cur ^ 1)
         SB();
       }
     }
