@@ -17,6 +17,14 @@ if which == "gemm":
     out = torch.empty(M, N, dtype=torch.float16, device="cuda")
     for _ in range(3):
         ops.gemm_nt(a, b, out16=out)
+elif which == "gemm_split":
+    M, N, K = 331776, 3072, 1536
+    a = torch.randn(M, K, device="cuda").half()
+    w = torch.randn(N, K, device="cuda") * 0.05
+    hi = w.half(); lo = (w - hi.float()).half()
+    out = torch.empty(M, N, dtype=torch.float16, device="cuda")
+    for _ in range(3):
+        ops.gemm_nt(a, hi, out16=out, b_lo=lo, lo_scale=1.0)
 elif which in ("attn256", "attn64"):  # attn256 at PROBE_B=16 is the bench launch shape (r64 kernel)
     hd = 256 if which == "attn256" else 64
     B, T = (int(os.environ.get("PROBE_B", "2")), 20736) if hd == 256 else (int(os.environ.get("PROBE_B", "8")), 20736)
