@@ -167,6 +167,13 @@ def main():
                     roof["traffic"] = int(tj[key[0]]["hbm_bytes_per_launch"])
                     roof["traffic_unit"] = "bytes/launch"
                     roof["traffic_source"] = "profiles/r1_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE; 2*FETCH+WRITE)"
+            mpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_pmc_mfma.json")
+            if os.path.exists(mpath) and (n, G) == (16, 288):
+                mj = json.load(open(mpath)).get("flash_attn_r64_kernel")
+                if mj:   # hardware-side view of the same kernel at the same launch shape (separate PMC pass)
+                    roof["mfma_busy_pmc"] = mj["mfma_busy"]
+                    roof["sustained_clock_ghz_pmc"] = mj["sustained_clock_ghz"]
+                    roof["pmc_source"] = "profiles/r1_pmc_mfma.json"
         flops_total = per_sample_step * n * S * world * args.steps
         if not args.no_split_weights:
             pass   # split weights double the GEMM MFMAs; algorithmic FLOPs are unchanged by definition
