@@ -1,0 +1,18 @@
+import os, sys, torch
+sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
+from dvd_amd import ops
+M = 4 * 331776
+a = torch.randn(M, 384, device="cuda").half()
+def t(fn, it=10):
+    for _ in range(3): fn()
+    torch.cuda.synchronize(); e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True); e0.record()
+    for _ in range(it): fn()
+    e1.record(); torch.cuda.synchronize(); return e0.elapsed_time(e1) / it
+for N, K in ((384, 384), (1152, 384)):
+    aa = a if K == 384 else torch.randn(M, K, device="cuda").half()
+    w = torch.randn(N, K, device="cuda") * 0.05; hi = w.half(); lo = (w - hi.float()).half()
+    out = torch.empty(M, N, dtype=torch.float16, device="cuda")
+    f = lambda: ops.gemm_nt(aa, hi, out16=out, b_lo=lo, lo_scale=1.0)
+    ms = t(f); os.environ["DVD_GEMM_TWOPASS"] = "1"; ms2 = t(f); os.environ.pop("DVD_GEMM_TWOPASS")
+    fl = 2 * M * N * K * 2 / 1e12
+    print(f"M={M} N={N} K={K}: split128 {ms:.3f} ms ({fl / ms * 1e3:.0f} TF/s executed)   v1 two-pass {ms2:.3f} ms ({fl / ms2 * 1e3:.0f} TF/s)")

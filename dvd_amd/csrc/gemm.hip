@@ -867,6 +867,179 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_split_kernel(GemmArgs p) {
   }  // persistent tile loop
 }
 
+// Same kernel for N % 128 == 0 (the DiT block's N = 384 / 1152 projections): 256 x 128 tiles, a wave owns 64 x 64, the
+// general (pos / gate / residual) staged epilogue is available because only 64 accumulator registers are live.
+__global__ void __launch_bounds__(512, 2) gemm_nt_split128_kernel(GemmArgs p) {
+  constexpr int BK = 32, TILE = 256 * 64, TILEB = 128 * 64, STAGE = TILE + 2 * TILEB, NST = 3;
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [3 stages][A 16K | B 8K | Blo 8K] (>= 128 KiB for the epilogue)
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  const int nwg = p.ntm * p.ntn;
+  const int z = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const int wr = wave >> 1, wc = wave & 1;
+  for (int vid = blockIdx.x; vid < nwg; vid += gridDim.x) {
+  int id = vid;
+  {
+    const int q = nwg / 8, rr = nwg % 8, xcd = id % 8, k = id / 8;
+    id = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + k;
+  }
+  const int tm = id / p.ntn, tn = id % p.ntn;
+  const int bm0 = tm * 256, bn0 = tn * 128;
+  const _Float16* A = (const _Float16*)p.A + z * p.sA;
+  const _Float16* B = (const _Float16*)p.B + z * p.sB;
+  const _Float16* Blo = (const _Float16*)p.Blo + z * p.sB;
+
+  // per-lane source offsets of this wave's 2 + 1 + 1 loads (1 KiB = 16 rows x 64 B each)
+  unsigned aoff[2], boff;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = 16 * (2 * wave + i) + (lane >> 2), pos = lane & 3;
+    const int ra = min(bm0 + row, p.M - 1) - bm0;
+    aoff[i] = (unsigned)ra * (unsigned)(p.lda * 2) + (pos ^ ((row >> 2) & 3)) * 16;
+  }
+  {
+    const int row = 16 * wave + (lane >> 2), pos = lane & 3;
+    const int rb = min(bn0 + row, p.N - 1) - bn0;
+    boff = (unsigned)rb * (unsigned)(p.ldb * 2) + (pos ^ ((row >> 2) & 3)) * 16;
+  }
+  const char* Atile = (const char*)(A + (size_t)bm0 * p.lda);
+  const char* Btile = (const char*)(B + (size_t)bn0 * p.ldb);
+  const char* Ltile = (const char*)(Blo + (size_t)bn0 * p.ldb);
+  const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t)smem;
+
+  int frag[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) frag[ks] = r * 64 + (((2 * ks + h) ^ ((r >> 2) & 3)) * 16);
+  const int a_base = wr * 64 * 64;
+  const int b_base = TILE + wc * 64 * 64;
+  const int l_base = TILE + TILEB + wc * 64 * 64;
+
+  floatx16 acc[2][2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[m][n][i] = 0.f;
+  const int nk = p.K / BK;
+
+#define SPLIT_ISSUE(t_, stage_)                                                                          \
+  {                                                                                                      \
+    const size_t kb_ = (size_t)(t_) * (BK * 2);                                                          \
+    const unsigned l_ = lds0 + (stage_) * STAGE;                                                         \
+    glds_one4(Atile + kb_, aoff[0], l_ + (2 * wave) * 1024); glds_one4(Atile + kb_, aoff[1], l_ + (2 * wave + 1) * 1024); \
+    glds_one4(Btile + kb_, boff, l_ + TILE + wave * 1024);                                               \
+    glds_one4(Ltile + kb_, boff, l_ + TILE + TILEB + wave * 1024);                                       \
+  }
+#define SB() __builtin_amdgcn_sched_barrier(0)
+  // prologue: slabs 0 and 1 (clamped: K = 32 has a single slab)
+  SPLIT_ISSUE(0, 0)
+  SPLIT_ISSUE(min(1, nk - 1), 1)
+  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");     // slab 0 landed (this wave's part); slab 1 may be in flight
+  __syncthreads();
+  // The loop is skewed by half a slab so that no wave ever starts a slab with cold fragment registers: the barrier
+  // that publishes slab kt + 1 sits in the MIDDLE of slab kt, and the second half of slab kt already reads the first
+  // fragments of slab kt + 1 between its MFMAs.  (With the barrier at the end of the slab both waves of a SIMD stall
+  // together on ~150 cycles of LDS latency + the barrier, once per 32 MFMAs.)
+  half8 fa[2][2], fh[2][2], fl[2][2];
+#define SPLIT_READ(set_, base_, ks_)                                                                  \
+  {                                                                                                   \
+    _Pragma("unroll") for (int m = 0; m < 2; ++m) fa[set_][m] = *(const half8*)((base_) + a_base + m * 32 * 64 + frag[ks_]); \
+    _Pragma("unroll") for (int n = 0; n < 2; ++n) {                                                   \
+      fh[set_][n] = *(const half8*)((base_) + b_base + n * 32 * 64 + frag[ks_]);                      \
+      fl[set_][n] = *(const half8*)((base_) + l_base + n * 32 * 64 + frag[ks_]);                      \
+    }                                                                                                 \
+  }
+  // 16 MFMAs of one k-step (8 hi then 8 lo: an accumulator is revisited after 8 others); the 8 fragment reads of the
+  // NEXT k-step (set nset_, from nbase_ at k-step nks_) are spread between the first 8
+#define SPLIT_KSTEP(set_, nset_, nbase_, nks_)                                                        \
+  {                                                                                                   \
+    _Pragma("unroll") for (int m = 0; m < 2; ++m) {                                                   \
+      _Pragma("unroll") for (int n = 0; n < 2; ++n) acc[m][n] = mfma32_f16(fa[set_][m], fh[set_][n], acc[m][n]); \
+      fa[nset_][m] = *(const half8*)((nbase_) + a_base + m * 32 * 64 + frag[nks_]);                   \
+      fh[nset_][m] = *(const half8*)((nbase_) + b_base + m * 32 * 64 + frag[nks_]);                   \
+      fl[nset_][m] = *(const half8*)((nbase_) + l_base + m * 32 * 64 + frag[nks_]);                   \
+      SB();                                                                                           \
+    }                                                                                                 \
+    _Pragma("unroll") for (int m = 0; m < 2; ++m) {                                                   \
+      _Pragma("unroll") for (int n = 0; n < 2; ++n) acc[m][n] = mfma32_f16(fa[set_][m], fl[set_][n], acc[m][n]); \
+      SB();                                                                                           \
+    }                                                                                                 \
+  }
+  SPLIT_READ(0, smem, 0)
+  SB();
+  int cur = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    const char* base = smem + cur * STAGE;
+    int n1 = cur + 1; if (n1 >= NST) n1 -= NST;
+    int n2 = cur + 2; if (n2 >= NST) n2 -= NST;
+    SPLIT_KSTEP(0, 1, base, 1)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // slab kt + 1 (issued half a slab ago or in the prologue) landed
+    __syncthreads();                                   // ... for everyone; and everyone is past slab kt - 1
+    // -> the stage slab kt - 1 used.  The two waves of a SIMD issue their six loads at different points of the second
+    // half (right after the barrier / between its hi and lo MFMAs), so one's issue stalls sit under the other's MFMAs
+    // (+1..3 %; spreading the six loads one by one behind run-time wave-group tests was slower again)
+    if (wave < 4) SPLIT_ISSUE(min(kt + 2, nk - 1), n2)
+    SB();
+    {
+      const char* nb = smem + n1 * STAGE;              // second half: already reads slab kt + 1's first fragments
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+#pragma unroll
+        for (int n = 0; n < 2; ++n) acc[m][n] = mfma32_f16(fa[1][m], fh[1][n], acc[m][n]);
+        fa[0][m] = *(const half8*)(nb + a_base + m * 32 * 64 + frag[0]);
+        fh[0][m] = *(const half8*)(nb + b_base + m * 32 * 64 + frag[0]);
+        fl[0][m] = *(const half8*)(nb + l_base + m * 32 * 64 + frag[0]);
+        SB();
+      }
+      if (wave >= 4) SPLIT_ISSUE(min(kt + 2, nk - 1), n2)
+      SB();
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+#pragma unroll
+        for (int n = 0; n < 2; ++n) acc[m][n] = mfma32_f16(fa[1][m], fl[1][n], acc[m][n]);
+        SB();
+      }
+    }
+    cur = n1;
+  }
+#undef SPLIT_READ
+#undef SPLIT_KSTEP
+#undef SPLIT_ISSUE
+#undef SB
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the clamped tail loads: nobody may still be writing LDS
+  __syncthreads();
+
+  // ---------------- epilogue (same as gemm_nt_big_kernel) ----------------
+  float* C32 = p.C32 ? p.C32 + z * p.sC32 : nullptr;
+  _Float16* C16 = p.C16 ? p.C16 + z * p.sC16 : nullptr;
+  const float* bias = p.bias ? p.bias + z * p.sBias : nullptr;
+  const float* res = p.res ? p.res + z * p.sRes : nullptr;
+  const float* gate = p.gate ? p.gate + z * p.sGate : nullptr;
+  if (p.vec_epilogue) {
+    float* stage = (float*)smem + wave * (64 * 64);                  // 8 x 16 KiB
+    int lane_e = lane;
+    asm volatile("" : "+v"(lane_e));                                 // see gemm_nt_big_kernel
+    DVD_EPILOGUE_BLOCK64(p, stage, acc[0][0], acc[0][1], acc[1][0], acc[1][1], bm0 + 64 * wr, bn0 + 64 * wc, lane_e, C32, C16,
+                         bias, res, gate)
+  } else {
+#define BIG_EP(m_, n_)                                                                                    \
+  {                                                                                                       \
+    const int col = bn0 + 64 * wc + 32 * (n_) + r;                                                        \
+    if (col < p.N) {                                                                                      \
+      const float bcol = (bias && !p.bias_row) ? bias[col] : 0.f;                                         \
+      epilogue_tile(p, acc[m_][n_], bm0 + 64 * wr + 32 * (m_), col, h, bcol, C32, C16, bias, res, gate);  \
+    }                                                                                                     \
+  }
+  BIG_EP(0, 0) BIG_EP(0, 1) BIG_EP(1, 0) BIG_EP(1, 1)
+#undef BIG_EP
+  }
+  __syncthreads();   // staging regions read back: the next tile's loads may overwrite them
+  }  // persistent tile loop
+}
+
 }  // namespace dvd
 
 using namespace dvd;
@@ -922,6 +1095,20 @@ extern "C" int dvd_gemm_nt(const dvd_gemm_desc* d, void* stream) {
   // kernel choice depends on (dtype, N, K, split) only, never on M: a document then takes the same kernels - and the
   // same fp32 summation order - whether it is sampled alone or in a batch (bit-identical results, tested)
   const bool big = d->dtype == 0 && d->N % 256 == 0 && !getenv("DVD_GEMM_V1");
+  if (d->dtype == 0 && d->N % 128 == 0 && d->N % 256 != 0 && d->B_lo && !d->A_lo && d->lo_scale == 1.f &&
+      !getenv("DVD_GEMM_TWOPASS") && !getenv("DVD_GEMM_V1")) {
+    p.ntm = cdiv(d->M, 256); p.ntn = d->N / 128;
+    constexpr int LDS = 8 * 16384;                    // 3 stages x 32 KiB, rounded up to the epilogue's 8 x 16 KiB
+    static bool once_s1 = false;
+    if (!once_s1) {
+      (void)hipFuncSetAttribute((const void*)gemm_nt_split128_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+      once_s1 = true;
+    }
+    int nblk = p.ntm * p.ntn;
+    if (nblk > 256) nblk = 256;
+    gemm_nt_split128_kernel<<<dim3(nblk, d->batch), 512, LDS, (hipStream_t)stream>>>(p);
+    return check_launch("gemm_nt(split128)");
+  }
   if (big && d->B_lo && !d->A_lo && d->lo_scale == 1.f && d->K % 32 == 0 && !getenv("DVD_GEMM_TWOPASS")) {
     p.ntm = cdiv(d->M, 256); p.ntn = d->N / 256;
     constexpr int LDS = 3 * 3 * 256 * 64;

@@ -157,7 +157,8 @@ def test_gemm_large_tile_split_weights(ops):
     assert e_b < 2e-5 and e_a < 2e-5, (e_b, e_a)
 
 
-@pytest.mark.parametrize("M,N,K", [(2048, 1536, 1536), (1100, 512, 128), (4096, 256, 64), (1024, 2048, 1536)])
+@pytest.mark.parametrize("M,N,K", [(2048, 1536, 1536), (1100, 512, 128), (4096, 256, 64), (1024, 2048, 1536),
+                                   (1100, 384, 384), (2048, 1152, 384), (300, 128, 64)])
 def test_gemm_fused_split_kernel(ops, M, N, K):
     """lo_scale = 1 with an UNSCALED lo part (f16 subnormals) routes to the one-pass kernel (three LDS tiles, one
     accumulator set).  Result: fp32-weight grade, and equal to the two-pass kernel up to fp32 summation order;
@@ -188,6 +189,19 @@ def test_gemm_fused_split_kernel(ops, M, N, K):
     ops.gemm_nt(a.cuda(), hi.cuda(), out32=o3, b_lo=lo.cuda(), lo_scale=1.0, bias=bias.cuda(), act=2, res=o3)
     ref3 = torch.relu(ref + bias.double()) + res.double()
     assert (o3.cpu().double() - ref3).abs().max() < 5e-5
+    # gate * (acc + bias) + residual and the positional add (the DiT block's epilogues)
+    T = 100
+    gate = rnd("fgate", ((M + T - 1) // T, N))
+    pos = rnd("fpos", (T, N))
+    o4 = res.clone().cuda()
+    ops.gemm_nt(a.cuda(), hi.cuda(), out32=o4, b_lo=lo.cuda(), lo_scale=1.0, bias=bias.cuda(), gate=gate.cuda(),
+                gate_rows=T, res=o4)
+    ref4 = gate.double().repeat_interleave(T, 0)[:M] * (ref + bias.double()) + res.double()
+    assert (o4.cpu().double() - ref4).abs().max() < 5e-5
+    o5 = torch.zeros(M, N, device="cuda")
+    ops.gemm_nt(a.cuda(), hi.cuda(), out32=o5, b_lo=lo.cuda(), lo_scale=1.0, bias=bias.cuda(), pos=pos.cuda())
+    ref5 = ref + bias.double() + pos.double().repeat((M + T - 1) // T, 1)[:M]
+    assert (o5.cpu().double() - ref5).abs().max() < 5e-5
 
 
 @pytest.mark.parametrize("env", [{}, {"DVD_GEMM_TWOPASS": "1"}, {"DVD_GEMM_V1": "1"}, {"DVD_GEMM_SPREAD": "1"},
