@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
-"""Which f16 weights need the hi + 2^-11 lo split?  Zeroes the `_lo` half of one weight group at a time and measures
+"""(Checker-side experiment: lives under tests/ because it uses the oracle.)  Which f16 weights need the hi + 2^-11 lo split?  Zeroes the `_lo` half of one weight group at a time and measures
 the 50-step DDIM coordinate RMSE against the CPU oracle (same harness as tests/test_gpu_engine.py).
-usage: python benchmarks/lo_ablation.py [grid=32] [steps=50]"""
+usage: python tests/tools/lo_ablation.py [grid=32] [steps=50]"""
 import os
 import re
 import sys
 
-sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
+sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..", "..")))
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
