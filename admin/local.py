@@ -54,7 +54,8 @@ _DEFAULTS = {
     "num_synthetic_docs": 4,
     "full_res": (1024, 768), # synthetic full-resolution source size (H, W)
     "conditioning_dir": "",
-    "synthetic_weights_if_missing": True,
+    # None = only when eval_dataset_name == 'synthetic' (a missing checkpoint on a real dataset raises)
+    "synthetic_weights_if_missing": None,
 }
 
 

@@ -10,6 +10,11 @@ from . import schedule, synth
 from .engine import Engine
 
 
+def _require_gpu(dev):
+    if dev.type != "cuda":
+        raise RuntimeError("DvdDenoiser runs on the HIP engine only: move the model to a GPU (no CPU fallback)")
+
+
 class DvdDenoiser(nn.Module):
     def __init__(self, input_size=64, in_channels=2, tv=True, depth=12):
         super().__init__()
@@ -54,10 +59,31 @@ class DvdDenoiser(nn.Module):
         return res
 
     # ---- engine plumbing ------------------------------------------------------------------------------
+    def materialize_blob(self, src: int = 0):
+        """Pack the current parameters into the engine's flat weight blob on rank `src` and hand it to every rank
+        with ONE flat broadcast (RCCL over xGMI) - the sampling path's only collective.  COLLECTIVE: every rank of
+        the process group must call it, unconditionally and at the same point (val_TDiff.run does, right after
+        model.to(dev)); `engine()` itself never communicates, so a rank with an empty document shard cannot leave
+        the others waiting in a broadcast.  Ranks other than `src` never read their own (unloaded) parameters."""
+        from . import dist_util
+        from .engine import blob_layout, pack_blob
+        dev = self.device
+        _require_gpu(dev)
+        total = blob_layout(self.input_size)[1]
+        store = torch.empty(total + 256, dtype=torch.uint8, device=dev)      # the engine wants 256-byte alignment
+        off = (-store.data_ptr()) % 256
+        blob = store[off:off + total]
+        if dist_util.rank() == src:
+            sd = {k: v.detach().cpu() for k, v in self.state_dict().items()}
+            blob.copy_(pack_blob(sd, self.input_size))
+        self._blob = dist_util.broadcast_blob(blob, src=src)
+        self._blob_version = self._version
+        return self._blob
+
     def engine(self, grid: int, docs: int, n_hyp: int) -> Engine:
-        dev = next(self.parameters()).device
-        if dev.type != "cuda":
-            raise RuntimeError("DvdDenoiser runs on the HIP engine only: move the model to a GPU (no CPU fallback)")
+        """The engine for (grid, docs, hypotheses) bound to the current weights.  Issues NO collective."""
+        dev = self.device
+        _require_gpu(dev)
         key = (grid, docs, n_hyp, dev.index)
         eng = self._engines.get(key)
         if eng is None:
@@ -67,11 +93,12 @@ class DvdDenoiser(nn.Module):
             eng._bound_version = -1
         if eng._bound_version != self._version:
             if self._blob is None or self._blob_version != self._version:
-                sd = {k: v.detach().cpu() for k, v in self.state_dict().items()}
                 from . import dist_util
-                host = eng.pack_blob(sd) if dist_util.rank() == 0 else torch.empty(eng.blob_layout()[1], dtype=torch.uint8)
-                self._blob = dist_util.broadcast_blob(host.to(dev))
-                self._blob_version = self._version
+                if dist_util.world_size() > 1:
+                    raise RuntimeError("the weights changed (or were never packed) in a multi-rank run: call "
+                                       "model.materialize_blob() on EVERY rank before sampling (it is the one "
+                                       "collective of the path; engine() must not issue it lazily)")
+                self.materialize_blob()
             eng.bind_blob(self._blob)
             eng._bound_version = self._version
         return eng

@@ -18,9 +18,10 @@ def _env_int(name, default):
 
 
 def setup_dist(backend=None):
-    """Initialise torch.distributed from torchrun's environment (single process: a 1-rank group)."""
+    """Initialise torch.distributed from torchrun's environment (single process: a 1-rank group).
+    Returns True when this call created the group (the caller then owns destroying it)."""
     if dist.is_initialized():
-        return
+        return False
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29541")
     os.environ.setdefault("RANK", "0")
@@ -31,6 +32,7 @@ def setup_dist(backend=None):
     if backend == "nccl":
         th.cuda.set_device(_env_int("LOCAL_RANK", 0) % max(1, th.cuda.device_count()))
     dist.init_process_group(backend=backend, init_method="env://")
+    return True
 
 
 def rank():
@@ -42,20 +44,19 @@ def world_size():
 
 
 def dev():
+    """The device setup_dist() selected for this process (the reference maps rank % GPUS_PER_NODE,
+    idf/dist_util.py:44-50; here the mapping is made once, in setup_dist, and read back)."""
     if th.cuda.is_available():
-        return th.device(f"cuda:{_env_int('LOCAL_RANK', rank()) % GPUS_PER_NODE}")
+        return th.device("cuda", th.cuda.current_device())
     return th.device("cpu")
 
 
 def load_state_dict(path, **kwargs):
-    """Every rank gets the checkpoint's state_dict; only rank 0 touches the file system."""
-    payload = [None]
-    if rank() == 0:
-        with open(path, "rb") as f:
-            payload[0] = f.read()
-    if world_size() > 1:
-        dist.broadcast_object_list(payload, src=0)
-    return th.load(io.BytesIO(payload[0]), **kwargs)
+    """Read a checkpoint's state_dict on the CALLING rank.  The reference broadcasts the pickled file bytes to every
+    rank over MPI (idf/dist_util.py:53-63) and every rank unpickles 600 MB; here only rank 0 calls this
+    (val_TDiff.run) and the ranks receive the packed engine blob instead (DvdDenoiser.materialize_blob)."""
+    with open(path, "rb") as f:
+        return th.load(io.BytesIO(f.read()), **kwargs)
 
 
 def broadcast_blob(blob: th.Tensor, src: int = 0) -> th.Tensor:

@@ -13,6 +13,57 @@ from . import lib, weights
 from .lib import ptr, stream_ptr
 
 
+_SPECS = {}
+
+
+def _is_dev(t) -> bool:
+    """Device-residency check of every tensor handed to the library (one place, so the CPU-only multi-rank test can
+    stub it together with the compute entry points)."""
+    return t.is_cuda
+
+
+def tensor_specs(grid: int):
+    """[(name, dtype 0=f32/1=f16, nelem)] of the engine's weight set for a grid - host-only (no device memory, no
+    workspace): what every rank needs to size the flat blob before the one-shot broadcast."""
+    if grid not in _SPECS:
+        h = C.c_void_p()
+        lib.call("dvd_engine_create", grid, 1, 1, C.byref(h))
+        try:
+            specs = []
+            name, dt, ne = C.c_char_p(), C.c_int(), C.c_long()
+            for i in range(lib.raw().dvd_engine_tensor_count(h)):
+                lib.call("dvd_engine_tensor_info", h, i, C.byref(name), C.byref(dt), C.byref(ne))
+                specs.append((name.value.decode(), dt.value, ne.value))
+        finally:
+            lib.raw().dvd_engine_destroy(h)
+        _SPECS[grid] = specs
+    return _SPECS[grid]
+
+
+def blob_layout(grid: int):
+    """(name, dtype, nelem, byte offset) of every tensor inside the flat weight blob (256-B aligned), total bytes."""
+    off, lay = 0, []
+    for name, dt, ne in tensor_specs(grid):
+        lay.append((name, dt, ne, off))
+        off += (ne * (2 if dt == 1 else 4) + 255) // 256 * 256
+    return lay, off
+
+
+def pack_blob(state_dict, grid: int) -> torch.Tensor:
+    """Host blob (uint8) from a reference-named state_dict."""
+    packed = weights.pack(state_dict, grid)
+    lay, total = blob_layout(grid)
+    blob = torch.zeros(total, dtype=torch.uint8)
+    for name, dt, ne, off in lay:
+        t = packed[name]
+        want = torch.float16 if dt == 1 else torch.float32
+        if t.dtype != want or t.numel() != ne:
+            raise lib.DvdError(f"packer produced {name}: {t.dtype} x{t.numel()}, engine expects {want} x{ne}")
+        raw = t.contiguous().view(-1).view(torch.uint8)
+        blob[off:off + raw.numel()] = raw
+    return blob
+
+
 class Engine:
     def __init__(self, grid: int, docs: int, n_hyp: int, device="cuda"):
         self.grid, self.docs, self.n_hyp, self.n = grid, docs, n_hyp, docs * n_hyp
@@ -25,11 +76,7 @@ class Engine:
         off = (-self.workspace.data_ptr()) % 256
         self._ws_ptr = self.workspace.data_ptr() + off
         lib.call("dvd_engine_bind_workspace", h, C.c_void_p(self._ws_ptr), nbytes)
-        self.specs = []
-        name, dt, ne = C.c_char_p(), C.c_int(), C.c_long()
-        for i in range(lib.raw().dvd_engine_tensor_count(h)):
-            lib.call("dvd_engine_tensor_info", h, i, C.byref(name), C.byref(dt), C.byref(ne))
-            self.specs.append((name.value.decode(), dt.value, ne.value))
+        self.specs = tensor_specs(grid)
         self.blob = None
 
     def __del__(self):
@@ -42,30 +89,14 @@ class Engine:
 
     # ---- weights -------------------------------------------------------------------------
     def blob_layout(self):
-        """(name, dtype, nelem, byte offset) of every tensor inside the flat weight blob (256-B aligned)."""
-        off, lay = 0, []
-        for name, dt, ne in self.specs:
-            lay.append((name, dt, ne, off))
-            off += (ne * (2 if dt == 1 else 4) + 255) // 256 * 256
-        return lay, off
+        return blob_layout(self.grid)
 
     def pack_blob(self, state_dict) -> torch.Tensor:
-        """Host blob (uint8) from a reference-named state_dict."""
-        packed = weights.pack(state_dict, self.grid)
-        lay, total = self.blob_layout()
-        blob = torch.zeros(total, dtype=torch.uint8)
-        for name, dt, ne, off in lay:
-            t = packed[name]
-            want = torch.float16 if dt == 1 else torch.float32
-            if t.dtype != want or t.numel() != ne:
-                raise lib.DvdError(f"packer produced {name}: {t.dtype} x{t.numel()}, engine expects {want} x{ne}")
-            raw = t.contiguous().view(-1).view(torch.uint8)
-            blob[off:off + raw.numel()] = raw
-        return blob
+        return pack_blob(state_dict, self.grid)
 
     def bind_blob(self, blob_dev: torch.Tensor):
         """Bind a device-resident blob (e.g. after the one-shot RCCL broadcast)."""
-        assert blob_dev.is_cuda and blob_dev.dtype == torch.uint8
+        assert blob_dev.device == self.workspace.device and blob_dev.dtype == torch.uint8
         lay, total = self.blob_layout()
         assert blob_dev.numel() >= total and blob_dev.data_ptr() % 256 == 0
         self.blob = blob_dev
@@ -80,7 +111,7 @@ class Engine:
         for t, shp in ((y512, (self.docs, 3, 512, 512)), (mask_cat, (self.docs, 1, 512, 512)),
                        (mask_y512, (self.docs, 384, self.grid, self.grid)),
                        (line_msk, (self.docs, 64, self.grid, self.grid))):
-            if tuple(t.shape) != shp or t.dtype != torch.float32 or not t.is_cuda or not t.is_contiguous():
+            if tuple(t.shape) != shp or t.dtype != torch.float32 or not _is_dev(t) or not t.is_contiguous():
                 raise lib.DvdError(f"prepare: expected contiguous f32 device tensor of shape {shp}, got {tuple(t.shape)}")
         lib.call("dvd_engine_prepare_docs", self._h, ptr(y512), ptr(mask_cat), ptr(mask_y512), ptr(line_msk),
                  stream_ptr())
@@ -93,14 +124,14 @@ class Engine:
     def denoise(self, x_t, t_embed: float, feat_mode: int, init_flow, out=None, init_feat=None):
         shp = (self.n, 2, self.grid, self.grid)
         for t in (x_t, init_flow):
-            if tuple(t.shape) != shp or t.dtype != torch.float32 or not t.is_cuda or not t.is_contiguous():
+            if tuple(t.shape) != shp or t.dtype != torch.float32 or not _is_dev(t) or not t.is_contiguous():
                 raise lib.DvdError(f"denoise: expected contiguous f32 device tensor of shape {shp}")
         if out is None:
             out = torch.empty(shp, dtype=torch.float32, device=self.device)
         if feat_mode == 3:
             fs = (self.n, 256, self.grid, self.grid)
             if init_feat is None or tuple(init_feat.shape) != fs or init_feat.dtype != torch.float32 \
-                    or not init_feat.is_cuda or not init_feat.is_contiguous():
+                    or not _is_dev(init_feat) or not init_feat.is_contiguous():
                 raise lib.DvdError(f"denoise: feat_mode 3 needs a contiguous f32 device init_feat of shape {fs}")
         lib.call("dvd_engine_denoise_step", self._h, ptr(x_t), C.c_float(t_embed), feat_mode, ptr(init_flow),
                  ptr(init_feat if feat_mode == 3 else None), ptr(out), stream_ptr())

@@ -79,9 +79,22 @@ class GaussianDiffusion:
         noise_fn = None
         if sampler_kind == "ddpm" or eta != 0.0:
             noise_fn = lambda i: th.randn((B * n_batch, 2, G, G), device=dev)  # noqa: E731
-        sample = sampler.sample(eng, self.tables, x_T, sampler=sampler_kind, eta=eta, noise_fn=noise_fn)
+        sample = sampler.sample(eng, self.tables, x_T, sampler=sampler_kind, eta=eta, noise_fn=noise_fn,
+                                **self._first_step_kwargs(kw, n_batch))
         final = {"sample": sample, "pred_xstart": sample, "feat_dict": eng.feat_nchw()}
         return sample, final
+
+    def _first_step_kwargs(self, kw, n_batch):
+        """model_kwargs['init_flow'] / ['init_feat'] reach the denoiser at the first step only, tiled over the
+        hypotheses like every model_kwarg (idf/gaussian_diffusion.py:574,578; sample index = doc * n_batch + h).
+        init_feat is dead while the first step's model time is > 600 (the model overwrites it, idf/cross_model.py:597-598:
+        every schedule with >= 3 steps), so it is only tiled when it can be read."""
+        out = {}
+        if kw.get("init_flow") is not None:
+            out["init_flow"] = kw["init_flow"].repeat_interleave(n_batch, dim=0)
+        if kw.get("init_feat") is not None and self.tables.model_time(self.num_timesteps - 1) <= 600:
+            out["init_feat"] = kw["init_feat"].repeat_interleave(n_batch, dim=0)
+        return out
 
     def p_sample_loop(self, model, shape, **kw):
         """DDPM ancestral sampling (absent from the reference): BASELINE config 4."""
@@ -99,7 +112,8 @@ class GaussianDiffusion:
                                       pyramid=None):
         """Training-time roll-out (idf/gaussian_diffusion.py:647-782): steps S-1 ... timestep+1, NO hypothesis mean,
         clamp only; returns (sample [B*n_batch,2,G,G], feat [B,256,G,G]).  mode=None applies the denoiser's timestep
-        override like sampling does; any other mode feeds the raw model time (idf/cross_model.py:574-580)."""
+        override like sampling does; any other mode - 'train' is what training_losses_time_variant passes (:921-946,
+        one document, n_batch=1, per-sample start `timestep`) - feeds the raw model time (idf/cross_model.py:574-580)."""
         final = None
         for final in self.ddim_sample_for_training(model, shape, noise=noise, clip_denoised=clip_denoised,
                                                    denoised_fn=denoised_fn, model_kwargs=model_kwargs, device=device,
@@ -115,9 +129,6 @@ class GaussianDiffusion:
             raise NotImplementedError("clip_denoised / denoised_fn are off on the DvD path")
         if not time_variant or not iter:
             raise NotImplementedError("only the live time_variant=True / iter=True configuration is mirrored")
-        if mode is not None:
-            raise NotImplementedError("mode != None (no timestep override) is the training forward; the engine mirrors "
-                                      "the sampling configuration mode=None")
         if timestep is None or not -1 <= int(timestep) < self.num_timesteps - 1:
             raise ValueError(f"timestep must be in [-1, {self.num_timesteps - 2}]")
         B, C, G, G2 = shape
@@ -134,7 +145,8 @@ class GaussianDiffusion:
             x_T = th.randn((B * n_batch, 2, G, G), device=dev)
         noise_fn = (lambda i: th.randn((B * n_batch, 2, G, G), device=dev)) if eta != 0.0 else None   # noqa: E731
         sample = sampler.sample(eng, self.tables, x_T, eta=eta, noise_fn=noise_fn, mean_hyp=False,
-                                last_step=int(timestep) + 1)
+                                last_step=int(timestep) + 1, t_override=mode is None,
+                                **self._first_step_kwargs(kw, n_batch))
         yield {"sample": sample, "pred_xstart": sample, "feat_dict": eng.feat_nchw()}
 
     # ---- single-step pieces with the reference's signatures -------------------------------------
@@ -161,7 +173,7 @@ class GaussianDiffusion:
 
     def p_mean_variance(self, model, x, t, clip_denoised=True, denoised_fn=None, model_kwargs=None):
         """idf/gaussian_diffusion.py:294-415 for the live configuration (START_X, FIXED_LARGE/SMALL, no clipping):
-        {'mean','variance','log_variance','pred_xstart','feat'}; the denoiser runs on the HIP engine, the posterior
+        {'mean','variance','log_variance','pred_xstart','feat_dict'}; the denoiser runs on the HIP engine, the posterior
         mean on the fused scheduler kernel."""
         if clip_denoised or denoised_fn is not None:
             raise NotImplementedError("clip_denoised / denoised_fn are off on the DvD path")
@@ -176,7 +188,7 @@ class GaussianDiffusion:
         else:
             logvar = float(self.posterior_log_variance_clipped[i])
         lv = th.full_like(x0, np.float32(logvar))
-        return {"mean": mean, "variance": th.exp(lv), "log_variance": lv, "pred_xstart": x0, "feat": feat}
+        return {"mean": mean, "variance": th.exp(lv), "log_variance": lv, "pred_xstart": x0, "feat_dict": feat}
 
     def ddim_sample(self, model, x, t, clip_denoised=True, denoised_fn=None, model_kwargs=None, eta=0.0):
         """One DDIM step with the reference's signature (idf/gaussian_diffusion.py:445-491):

@@ -18,16 +18,22 @@ def feat_mode_for(t_model: float, n: int, first_step: bool) -> int:
 
 
 def sample(engine: Engine, tables: schedule.Tables, x_T: torch.Tensor, sampler: str = "ddim", eta: float = 0.0,
-           noise_fn=None, mean_hyp: bool = True, trace=None, last_step: int = 0):
+           noise_fn=None, mean_hyp: bool = True, trace=None, last_step: int = 0, init_flow=None, init_feat=None,
+           t_override: bool = True):
     """x_T [docs*H, 2, G, G] on the engine's device (sample index = doc*H + h).  The engine must have been
     prepared for its documents.  noise_fn(step) -> [N,2,G,G] supplies the per-step noise (DDPM, or DDIM with
     eta > 0).  Returns [docs,2,G,G] (hypothesis mean + clamp, :639-640) or the clamped per-sample maps.
     last_step > 0 stops the roll-out early (the training-time variant starts at S-1 and ends at `timestep + 1`,
-    idf/gaussian_diffusion.py:720)."""
+    idf/gaussian_diffusion.py:720).  init_flow [N,2,G,G] / init_feat [N,256,G,G] are the caller's model_kwargs of
+    the FIRST step (:578,:729: later steps use the previous x0 and the features warped by it; the model itself
+    replaces init_feat by the pyramid features while t_model > 600, idf/cross_model.py:597-598).  t_override=False is
+    the denoiser's `mode != None` (training) call: the raw model time is embedded, no 2/1 override (:575-580)."""
     n = engine.n
     S = tables.num_timesteps
     img = x_T.contiguous()
-    zeros = torch.zeros_like(img)
+    first_flow = torch.zeros_like(img) if init_flow is None else init_flow.to(img.device, torch.float32).contiguous()
+    if tuple(first_flow.shape) != tuple(img.shape):
+        raise ValueError(f"init_flow must be {tuple(img.shape)}, got {tuple(first_flow.shape)}")
     x0_bufs = [torch.empty_like(img), torch.empty_like(img)]
     x0 = None
     if not 0 <= last_step < S:
@@ -35,9 +41,14 @@ def sample(engine: Engine, tables: schedule.Tables, x_T: torch.Tensor, sampler: 
     for k, i in enumerate(range(S - 1, last_step - 1, -1)):
         t_model = tables.model_time(i)
         first = i == S - 1
-        flow = zeros if first else x0
+        flow = first_flow if first else x0
         out = x0_bufs[k & 1]
-        x0 = engine.denoise(img, schedule.embedded_time(t_model), feat_mode_for(t_model, n, first), flow, out=out)
+        mode = feat_mode_for(t_model, n, first)
+        feat_in = None
+        if first and mode == 0 and init_feat is not None:      # a first step at t_model <= 600 sees the caller's init_feat
+            mode, feat_in = 3, init_feat.to(img.device, torch.float32).contiguous()
+        t_embed = schedule.embedded_time(t_model) if t_override else float(t_model)
+        x0 = engine.denoise(img, t_embed, mode, flow, out=out, init_feat=feat_in)
         if trace is not None:
             trace.append(x0.clone())
         if sampler == "ddim":

@@ -20,8 +20,15 @@ def get_parameter_number(net):
     return {"Total": total, "Trainable": sum(p.numel() for p in net.parameters() if p.requires_grad)}
 
 
+def _want_synthetic_weights(env):
+    """Synthetic stand-in weights are for the synthetic benchmark only: a mistyped checkpoint path on a real dataset
+    must fail, not write plausible-looking garbage where the reference writes its results."""
+    flag = getattr(env, "synthetic_weights_if_missing", None)
+    return env.eval_dataset_name == "synthetic" if flag is None else bool(flag)
+
+
 def run(settings):
-    dist_util.setup_dist()
+    own_group = dist_util.setup_dist()
     env = settings.env
     logger.configure(dir=f"SAMPLING_{env.eval_dataset_name}_{settings.name}")
     logger.log("Loading model and diffusion...")
@@ -29,20 +36,25 @@ def run(settings):
         device=dist_util.dev(), train_mode=env.train_mode, tv=env.time_variant, grid_size=env.grid_size,
         **args_to_dict(settings, model_and_diffusion_defaults().keys()))
     setattr(diffusion, "settings", settings)
-    if os.path.exists(env.model_path):
-        model.cpu().load_state_dict(dist_util.load_state_dict(env.model_path, map_location="cpu"), strict=False)
-        logger.log(f"Model loaded with {env.model_path}")
-    elif env.synthetic_weights_if_missing:
-        sd = synth.synth_state_dict(env.grid_size, seed=7)
-        model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
-        logger.log(f"{env.model_path} not found: using deterministic synthetic weights (seed 7)")
-    else:
-        raise FileNotFoundError(env.model_path)
-    if not torch.cuda.is_available():
-        raise RuntimeError("the DvD engine needs an MI355X (no CPU fallback)")
+    # rank 0 alone reads the checkpoint (val_TDiff.py:79); the other ranks receive the packed blob below
+    if dist_util.rank() == 0:
+        if os.path.exists(env.model_path):
+            model.cpu().load_state_dict(dist_util.load_state_dict(env.model_path, map_location="cpu"), strict=False)
+            logger.log(f"Model loaded with {env.model_path}")
+        elif _want_synthetic_weights(env):
+            sd = synth.synth_state_dict(env.grid_size, seed=7)
+            model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+            logger.log(f"{env.model_path} not found: using deterministic synthetic weights (seed 7)")
+        else:
+            raise FileNotFoundError(f"{env.model_path} (set env.synthetic_weights_if_missing=True to sample with "
+                                    "synthetic stand-in weights)")
+    _require_gpu()
     model.to(dist_util.dev())
     print(get_parameter_number(model))
     model.eval()
+    # the path's ONE collective, issued eagerly and unconditionally by every rank BEFORE the documents are sharded:
+    # rank 0 packs, one flat broadcast (a rank whose shard is empty still takes part, then goes to the barrier)
+    model.materialize_blob()
 
     if env.eval_dataset_name == "synthetic" or not env.conditioning_dir:
         n_docs = env.num_synthetic_docs
@@ -57,5 +69,12 @@ def run(settings):
     results = run_evaluation_docunet(settings, logger, documents, diffusion, model, dist_util.dev())
     if dist.is_initialized():
         dist.barrier()
+        if own_group:
+            dist.destroy_process_group()
     logger.log("sampling complete")
     return results
+
+
+def _require_gpu():
+    if not torch.cuda.is_available():
+        raise RuntimeError("the DvD engine needs an MI355X (no CPU fallback)")

@@ -348,12 +348,13 @@ class Oracle:
                 "msk6": self.embed("m_embedder", mask_y512), "line": self.embed("l_embedder", line_msk)}
 
     # --- one denoiser evaluation (idf/cross_model.py:568-647) -----------------------------
-    def forward(self, x, t_model, inv, init_flow, init_feat, ck=None):
+    def forward(self, x, t_model, inv, init_flow, init_feat, ck=None, mode=None):
         """x [N,2,G,G]; t_model python float (identical for the whole batch, as in sampling);
-        inv = prepare(...) tensors already tiled to N.  Returns (x0_pred, feat)."""
+        inv = prepare(...) tensors already tiled to N.  Returns (x0_pred, feat).  mode=None is the sampling call;
+        any other value (training passes 'train') skips the timestep override (idf/cross_model.py:575)."""
         n = x.shape[0]
         xt = self.embed("obs_embedder", x)
-        tt = t_rule(float(t_model))
+        tt = t_rule(float(t_model)) if mode is None else float(t_model)
         c = self.t_embed(torch.full((n,), tt, dtype=torch.float32))
         feat = inv["feat"]
         if float(t_model) > 600 or (n > 1 and float(t_model) == 2.0):   # :597-601
@@ -383,25 +384,28 @@ class Oracle:
         return self.unpatchify(o) + init_flow, feat               # :644-647
 
     # --- the sampling loop (idf/gaussian_diffusion.py:537-644) ----------------------------
-    def sample_loop(self, sch: Schedule, x_T, doc, sampler="ddim", noises=None, mean_hyp=True, trace=None):
+    def sample_loop(self, sch: Schedule, x_T, doc, sampler="ddim", noises=None, mean_hyp=True, trace=None,
+                    init_flow=None, last_step=0, mode=None):
         """x_T [H,2,G,G]; doc = dict(y512 [1,3,512,512], mask_cat, mask_y512, line_msk).
         Returns the final map [1,2,G,G] (mean over hypotheses + clamp, :639-640) or, with
-        mean_hyp=False, the clamped per-hypothesis maps (training-variant loop, :776-777)."""
+        mean_hyp=False, the clamped per-hypothesis maps (training-variant loop, :776-777).
+        init_flow [H,2,G,G]: the caller's model_kwargs['init_flow'], seen by the first step (:578,:729);
+        last_step: the training roll-out stops at timestep+1 (:720); mode: see forward."""
         H = x_T.shape[0]
         inv1 = self.prepare(doc["y512"], doc["mask_cat"], doc["mask_y512"], doc["line_msk"])
         inv = {k: v.repeat(H, *([1] * (v.dim() - 1))) for k, v in inv1.items()}
         G = self.G
         base = base_grid(G, G)
         img = x_T
-        init_flow = torch.zeros(H, 2, G, G)
+        init_flow = torch.zeros(H, 2, G, G) if init_flow is None else init_flow
         init_feat = torch.zeros(H, 256, G, G)
         x0 = None
         S = sch.num_timesteps
-        for i in range(S - 1, -1, -1):
+        for i in range(S - 1, last_step - 1, -1):
             if i != S - 1:                                        # :618-624
                 init_flow = x0.clone()
                 init_feat = grid_sample_ref(inv["feat"], (x0 + base) * 2 - 1)
-            x0, _ = self.forward(img, float(sch.t_model(i)), inv, init_flow, init_feat)
+            x0, _ = self.forward(img, float(sch.t_model(i)), inv, init_flow, init_feat, mode=mode)
             if trace is not None:
                 trace.append(x0.clone())
             if sampler == "ddim":

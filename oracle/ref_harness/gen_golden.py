@@ -19,6 +19,8 @@ Fixtures:
   G4 ddim_step.npz     ddim_sample on random (x_t,x0) for every t of S=50; p_mean_variance S=250
   G5 unwarp.npz        upsample+affine+grid_sample+uint8 tail on a small ragged image
   G6 grid_sample.npz   register_model2 on the per-step feature-warp shape
+  G7 rollout_train_g{G}_s{S}.npz  ddim_sample_loop_for_training(mode='train', n_batch=1, timestep=k) with a
+                       non-zero init_flow: the call training_losses_time_variant makes (gaussian_diffusion.py:921-946)
 """
 import argparse
 import os
@@ -264,6 +266,50 @@ def gen_loop(mods, grid, steps, full_blocks):
           f"sample mean {sample.mean():+.5f} std {sample.std():.5f}")
 
 
+# ------------------------------------------------------------------------------- G7
+def gen_train_rollout(mods, grid, steps, timestep):
+    """The training-time roll-out exactly as training_losses_time_variant calls it (gaussian_diffusion.py:921-946):
+    ONE document, n_batch=1, mode='train' (the denoiser embeds the RAW model time: no 2/1 override,
+    cross_model.py:575-580), roll-out from S-1 down to timestep+1, the caller's init_flow seen by the first step."""
+    cross_model, gd, respace, script_util, dist_util, warping = mods
+    model = build_model(cross_model, grid, script_util, dist_util)
+    model.blocks = torch.nn.ModuleList([model.blocks[-1]])       # F2: bit-identical, 10x cheaper
+    diff = make_diffusion(script_util, steps)
+    inp = doc_inputs(grid)
+    rec = {"t": [], "x0": [], "x_in": []}
+
+    def pre(mod, args, kwargs):
+        rec["x_in"].append(args[0].detach().clone().numpy())
+        rec["t"].append(float(args[1][0]))
+
+    def post(mod, args, kwargs, res):
+        rec["x0"].append(res[0].detach().clone().numpy())
+    h1 = model.register_forward_pre_hook(pre, with_kwargs=True)
+    h2 = model.register_forward_hook(post, with_kwargs=True)
+    init_flow = torch.from_numpy(synth.uniform("g7/init_flow", (1, 2, grid, grid), -0.3, 0.3, SEED_IN))
+    kw = {"init_flow": init_flow.clone(), "y512": inp["y512"], "mask_cat": inp["mask_cat"],
+          "init_feat": torch.zeros(1, 256, grid, grid), "mask_y512": inp["mask_y512"], "line_msk": inp["line_msk"]}
+    seed = 977 + grid + steps
+    torch.manual_seed(seed)
+    _ = torch.randn(1, 2, grid, grid)
+    x_T = torch.randn(1, 2, grid, grid)
+    torch.manual_seed(seed)
+    sample, feat = diff.ddim_sample_loop_for_training(
+        model, (1, 2, grid, grid), noise=None, clip_denoised=False, model_kwargs=kw, eta=0.0,
+        n_batch=1, time_variant=True, iter=True, mode="train", timestep=timestep)
+    h1.remove()
+    h2.remove()
+    assert np.array_equal(rec["x_in"][0], x_T.numpy()), "x_T replication failed"
+    assert len(rec["t"]) == steps - 1 - timestep
+    out = {"grid": np.int64(grid), "steps": np.int64(steps), "timestep": np.int64(timestep),
+           "x_T": x_T.numpy(), "init_flow": init_flow.numpy(), "t_model": np.asarray(rec["t"], dtype=np.float32),
+           "x0_steps": np.stack(rec["x0"]), "x_in_steps": np.stack(rec["x_in"]), "sample": sample.numpy(),
+           "feat_stats": summ(feat)}
+    np.savez_compressed(os.path.join(GOLD, f"rollout_train_g{grid}_s{steps}.npz"), **out)
+    print(f"G7 rollout_train_g{grid}_s{steps}.npz  timestep={timestep}  t_model={rec['t']}  "
+          f"sample mean {sample.mean():+.5f} std {sample.std():.5f}")
+
+
 # ------------------------------------------------------------------------------- G4
 def gen_ddim_step(mods):
     _, gd, respace, script_util, _, _ = mods
@@ -346,7 +392,7 @@ def gen_grid_sample(mods):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="G1,G2,G3,G4,G5,G6")
+    ap.add_argument("--only", default="G1,G2,G3,G4,G5,G6,G7")
     args = ap.parse_args()
     want = set(args.only.split(","))
     os.makedirs(GOLD, exist_ok=True)
@@ -369,6 +415,9 @@ def main():
         gen_loop(mods, 32, 3, True)
         gen_loop(mods, 64, 3, True)
         gen_loop(mods, 64, 10, False)
+    if "G7" in want:
+        gen_train_rollout(mods, 16, 10, 2)      # t_model 900 .. 300 raw: crosses both override thresholds
+        gen_train_rollout(mods, 32, 3, -1)
 
 
 if __name__ == "__main__":

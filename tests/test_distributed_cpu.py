@@ -5,6 +5,7 @@ import os
 import socket
 import sys
 
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -60,3 +61,86 @@ def test_two_rank_broadcast_and_sharding():
         assert p.exitcode == 0
     assert res[0][1] == res[1][1], "ranks disagree on the broadcast weight blob"
     assert res[0][2] == [0, 2, 4, 6] and res[1][2] == [1, 3, 5]
+
+
+# ------------------------------------------------------------------------------------------------
+# The product's own multi-rank path: val_TDiff.run(settings) under 2 gloo ranks, with the engine's
+# COMPUTE entry points stubbed at the lib.call boundary (there is no GPU here; the host-only entry
+# points - create / tensor_info / bind_workspace / set_tensor - run for real).
+# ------------------------------------------------------------------------------------------------
+COMPUTE = {"dvd_engine_prepare_docs", "dvd_engine_denoise_step", "dvd_engine_feat_nchw", "dvd_sched_step",
+           "dvd_hyp_mean_clamp", "dvd_unwarp_u8"}
+
+
+def _stub_compute(calls):
+    """Patch the GPU-only pieces; returns nothing, records (name) of every stubbed compute call."""
+    import torch as th
+    from dvd_amd import cross_model, engine, lib, ops, val_TDiff
+    real_call = lib.call
+
+    def call(name, *args):
+        if name in COMPUTE:
+            calls.append(name)
+            return
+        return real_call(name, *args)
+    lib.call = call
+    for mod in (engine, ops):
+        mod.stream_ptr = lambda: None
+    ops._chk = lambda *a, **k: None
+    engine._is_dev = lambda t: True
+    cross_model._require_gpu = lambda dev: None
+    val_TDiff._require_gpu = lambda: None
+    th.cuda.synchronize = lambda *a, **k: None
+
+
+def _run_worker(rank, world, port, n_docs, q, tmp):
+    sys.path.insert(0, ROOT)
+    os.chdir(tmp)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    calls = []
+    _stub_compute(calls)
+    import admin.settings as ws
+    from dvd_amd import dist_util, val_TDiff
+    dist_util.setup_dist(backend="gloo")           # run() finds the group initialised and leaves it to us
+    s = ws.Settings()
+    s.env.grid_size, s.env.diffusion_steps, s.env.n_batch = 16, 3, 2
+    s.env.num_synthetic_docs, s.env.batch_docs, s.env.full_res, s.env.visualize = n_docs, 2, (32, 24), False
+    s.name, s.seed, s.severity, s.corruption_number = f"gloo{rank}", 0, 0, 0
+    seen = {}
+    orig = val_TDiff.run_evaluation_docunet
+
+    def spy(settings, logger, documents, diffusion, model, device):
+        seen["digest"] = hashlib.sha256(model._blob.cpu().numpy().tobytes()).hexdigest()
+        return orig(settings, logger, documents, diffusion, model, device)
+    val_TDiff.run_evaluation_docunet = spy
+    results = val_TDiff.run(s)
+    q.put((rank, seen["digest"], [p for p, _ in results], calls.count("dvd_engine_denoise_step"),
+           calls.count("dvd_engine_prepare_docs"), calls.count("dvd_unwarp_u8")))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_docs", [1, 5])
+def test_val_tdiff_run_two_ranks(tmp_path, n_docs):
+    """n_docs = 1 < world: rank 1 owns NO document - it must still take part in the one weight broadcast (issued
+    eagerly by run(), never lazily by engine()) and reach the final barrier (this used to hang).
+    n_docs = 5: disjoint shards [0,2,4] / [1,3], batches of 2, 3 DDIM steps per batch."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_run_worker, args=(r, 2, port, n_docs, q, str(tmp_path))) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=240) for _ in range(2))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    (r0, d0, docs0, den0, prep0, unw0), (r1, d1, docs1, den1, prep1, unw1) = res
+    assert d0 == d1, "ranks disagree on the broadcast weight blob"
+    want0 = [f"synthetic_{i:05d}" for i in range(0, n_docs, 2)]
+    want1 = [f"synthetic_{i:05d}" for i in range(1, n_docs, 2)]
+    assert docs0 == want0 and docs1 == want1
+    for docs, den, prep, unw in ((want0, den0, prep0, unw0), (want1, den1, prep1, unw1)):
+        batches = (len(docs) + 1) // 2
+        assert den == 3 * batches and prep == batches and unw == len(docs)

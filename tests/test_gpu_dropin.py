@@ -43,7 +43,7 @@ def test_ddim_sample_loop_contract_vs_reference_golden():
     assert tuple(sample.shape) == (1, 2, 64, 64) and set(final) == {"sample", "pred_xstart", "feat_dict"}
     assert tuple(final["feat_dict"].shape) == (1, 256, 64, 64)
     err = float(np.sqrt(((sample.cpu().numpy() - g["sample"]) ** 2).mean()))
-    assert err < 1e-3, err
+    assert err < 2.7e-4, err              # measured 6.5e-5 (x3 + margin); north_star's bar is 1e-3
 
 
 @pytest.mark.parametrize("tag", ["t2", "t1", "raw0", "raw600", "raw200"])
@@ -60,7 +60,7 @@ def test_model_call_all_t_classes_vs_reference_golden(tag):
                      init_flow=torch.from_numpy(g["init_flow"]).cuda(), tv=True, tmode="stage_1_dit_cross",
                      line_msk=doc["line_msk"], mask_cat=doc["mask_cat"], init_feat=init_feat, iter=True, mode=None)
     err = float(np.sqrt(((x0.cpu().numpy() - g[f"{tag}/x0"]) ** 2).mean()))
-    assert err < 1e-3, (tag, err)
+    assert err < 1.6e-4, (tag, err)       # one denoiser call: measured 5.3e-5 (x3)
     np.testing.assert_allclose(feat[0].cpu().numpy(), g["feat/full"], rtol=0, atol=2e-4)
 
 
@@ -98,13 +98,34 @@ def test_training_rollout_contract_vs_reference_golden(grid):
                                                            time_variant=True, iter=True, mode=None, timestep=-1)
     assert tuple(sample.shape) == (2, 2, grid, grid) and tuple(feat.shape) == (1, 256, grid, grid)
     err = float(np.sqrt(((sample.cpu().numpy() - g["sample"]) ** 2).mean()))
-    assert err < 1e-3, err
+    assert err < 2.7e-4, err
     # stopping early (timestep = 0) returns the clamped x0 prediction of step 1
     early, _ = diffusion.ddim_sample_loop_for_training(model, (1, 2, grid, grid), noise=torch.from_numpy(g["x_T"]),
                                                        clip_denoised=False, model_kwargs=kw, eta=0.0, n_batch=2,
                                                        time_variant=True, iter=True, mode=None, timestep=0)
     ref_early = np.clip(g["x0_steps"][1], -1, 1)
-    assert float(np.sqrt(((early.cpu().numpy() - ref_early) ** 2).mean())) < 1e-3
+    assert float(np.sqrt(((early.cpu().numpy() - ref_early) ** 2).mean())) < 2.7e-4
+
+
+@pytest.mark.parametrize("grid,steps", [(16, 10), (32, 3)])
+def test_training_rollout_mode_train_vs_reference_golden(grid, steps):
+    """The call training_losses_time_variant makes (idf/gaussian_diffusion.py:921-946): ONE document, n_batch=1,
+    mode='train' (raw model time embedded: no 2/1 override), per-sample start `timestep`, the caller's init_flow
+    seen by the first step - against the real reference's roll-out (golden G7)."""
+    g = np.load(os.path.join(GOLD, f"rollout_train_g{grid}_s{steps}.npz"))
+    s, model, diffusion = build(grid, steps)
+    doc = {k: torch.from_numpy(v)[None].cuda() for k, v in synth.synth_document(0, grid, 1234).items()}
+    kw = {"init_flow": torch.from_numpy(g["init_flow"]).cuda(), "y512": doc["y512"], "mask_cat": doc["mask_cat"],
+          "init_feat": torch.zeros(1, 256, grid, grid, device="cuda"), "mask_y512": doc["mask_y512"],
+          "line_msk": doc["line_msk"]}
+    sample, feat = diffusion.ddim_sample_loop_for_training(model, (1, 2, grid, grid), noise=torch.from_numpy(g["x_T"]),
+                                                           clip_denoised=False, model_kwargs=kw, eta=0.0, n_batch=1,
+                                                           time_variant=True, iter=True, mode="train",
+                                                           timestep=int(g["timestep"]))
+    assert tuple(sample.shape) == (1, 2, grid, grid) and tuple(feat.shape) == (1, 256, grid, grid)
+    err = float(np.sqrt(((sample.cpu().numpy() - g["sample"]) ** 2).mean()))
+    print("training roll-out (mode='train') rmse", grid, steps, err)
+    assert err < 3e-4, err
 
 
 def test_single_step_signatures_vs_reference_golden():
@@ -122,8 +143,10 @@ def test_single_step_signatures_vs_reference_golden():
     t = torch.tensor([2, 2], device="cuda")
     out = diffusion.ddim_sample(model, x_in, t, clip_denoised=False, model_kwargs=kw, eta=0.0)
     assert set(out) == {"sample", "pred_xstart", "feat_dict"}
-    assert float(np.sqrt(((out["pred_xstart"].cpu().numpy() - g["x0_steps"][0]) ** 2).mean())) < 1e-3
-    assert float(np.sqrt(((out["sample"].cpu().numpy() - g["x_in_steps"][1]) ** 2).mean())) < 1e-3
+    assert float(np.sqrt(((out["pred_xstart"].cpu().numpy() - g["x0_steps"][0]) ** 2).mean())) < 1.6e-4
+    assert float(np.sqrt(((out["sample"].cpu().numpy() - g["x_in_steps"][1]) ** 2).mean())) < 2.7e-4
+    assert set(diffusion.p_mean_variance(model, x_in, t, clip_denoised=False, model_kwargs=kw)) == \
+        {"mean", "variance", "log_variance", "pred_xstart", "feat_dict"}          # reference keys (:409-415)
     pmv = diffusion.p_mean_variance(model, x_in, t, clip_denoised=False, model_kwargs=kw)
     x0 = pmv["pred_xstart"]
     c1, c2 = np.float32(sch["s3/posterior_mean_coef1"][2]), np.float32(sch["s3/posterior_mean_coef2"][2])

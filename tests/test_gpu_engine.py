@@ -89,8 +89,10 @@ def test_forward_stages_vs_oracle(grid, tcase):
     errs["x0_max"] = (x0 - x0_ref).abs().max().item()
     errs["x0_rmse"] = (x0 - x0_ref).pow(2).mean().sqrt().item()
     print("stage errors", grid, tcase, errs)
-    assert errs["blk"] < 5e-3 and errs["dec_pos"] < 5e-3 and errs["dec5"] < 1e-2, errs
-    assert errs["x0_rmse"] < 1e-3, errs
+    # bars = 3x the values measured on MI355X (blk 1.3e-4, dec_pos 1.2e-4, dec5 2.7e-4, x0 rmse 5.4e-5): a precision
+    # regression of more than that fails here long before north_star's 1e-3 coordinate bar is in danger
+    assert errs["blk"] < 4e-4 and errs["dec_pos"] < 4e-4 and errs["dec5"] < 8e-4, errs
+    assert errs["x0_rmse"] < 1.6e-4, errs
 
 
 @pytest.mark.parametrize("grid", [16, 32, 64])
@@ -104,7 +106,7 @@ def test_forward_vs_reference_golden(grid):
     x0 = eng.denoise(x, schedule.embedded_time(float(g["t2/t_in"])), 1, flow).cpu().numpy()
     err = np.sqrt(((x0 - g["t2/x0"]) ** 2).mean())
     print("golden forward rmse", grid, err, np.abs(x0 - g["t2/x0"]).max())
-    assert err < 1e-3, err
+    assert err < 1.6e-4, err          # measured 5.3e-5 (x3); north_star's bar is 1e-3
 
 
 @pytest.mark.parametrize("grid,steps", [(16, 3), (32, 3), (64, 3), (64, 10)])
@@ -119,12 +121,15 @@ def test_sampling_loop_vs_reference_golden(grid, steps):
     per_step = [float(np.sqrt(((t.cpu().numpy() - g["x0_steps"][k]) ** 2).mean())) for k, t in enumerate(trace)]
     err = float(np.sqrt(((out.cpu().numpy() - g["sample"]) ** 2).mean()))
     print("loop rmse", grid, steps, err, "per-step", per_step)
-    assert err < 1e-3, (err, per_step)
+    assert err < 2.7e-4, (err, per_step)   # measured 6.5e-5 .. 9.0e-5 (x3); north_star's bar is 1e-3
 
 
-@pytest.mark.parametrize("grid,steps", [(16, 50), (32, 50)])
+@pytest.mark.parametrize("grid,steps", [(16, 50), (32, 50), (96, 50), (72, 50)])
 def test_long_loop_vs_oracle(grid, steps):
-    """BASELINE's 50-step DDIM (not reference-runnable natively: local.py has 3 steps) against the CPU oracle."""
+    """BASELINE's 50-step DDIM (not reference-runnable natively: local.py has 3 steps) against the CPU oracle.
+    G = 96 is an UP-sampling, non-native grid like BASELINE's 288 (feat 64 -> G, T % 64 == 0: the LDS-DMA attention
+    kernels, warped-feat branch live from step 2); G = 72 is ragged (T = 1296, T % 64 = 16: the register-staged
+    attention fallback and the GEMM edge tiles)."""
     from dvd_amd import sampler, schedule
     from oracle import dvd_oracle as O
     eng, orc, doc_t, inv1 = setup(grid)
@@ -136,7 +141,8 @@ def test_long_loop_vs_oracle(grid, steps):
     per = [float((a.cpu() - b).pow(2).mean().sqrt()) for a, b in zip(tr, tr_ref)]
     err = float((out.cpu() - ref).pow(2).mean().sqrt())
     print("long loop rmse", grid, steps, err, "per-step[::7]", per[::7], "last", per[-1])
-    assert err < 1e-3, (err, per[-1])
+    assert err < 3.8e-4, (err, per[-1])    # measured 1.2e-4 .. 1.3e-4 at G = 16 / 32 (x3); north_star's bar is 1e-3
+    assert per[-1] < 1e-3, per[-1]          # un-clamped, un-averaged x0 of the last step (measured 5.6e-4 .. 6.0e-4)
 
 
 def test_ddpm_loop_vs_oracle():
@@ -152,7 +158,27 @@ def test_ddpm_loop_vs_oracle():
     out = sampler.sample(eng, tab, xT.cuda(), sampler="ddpm", noise_fn=lambda i: noises[i].cuda())
     err = float((out.cpu() - ref).pow(2).mean().sqrt())
     print("ddpm loop rmse", err)
-    assert err < 1e-3, err
+    assert err < 2.8e-4, err               # measured 9.3e-5 (x3)
+
+
+def test_ddpm_250_steps_vs_oracle():
+    """BASELINE configs[3]'s sampler at full length: 250 ancestral steps (FIXED_LARGE variance, fixed noise table) at
+    G = 16 against the oracle - the stochastic path accumulates the denoiser's error through 250 noise-driven steps."""
+    from dvd_amd import sampler, schedule
+    from oracle import dvd_oracle as O
+    grid, steps = 16, 250
+    eng, orc, doc_t, inv1 = setup(grid)
+    tab = schedule.Tables(schedule.named_betas("cosine", steps))
+    xT = torch.from_numpy(synth.synth_noise(0, 2, grid, SEED_IN))
+    noises = {i: torch.from_numpy(synth.synth_noise(0, 2, grid, SEED_IN, step=i)) for i in range(steps)}
+    tr_ref, tr = [], []
+    ref = orc.sample_loop(O.Schedule(steps), xT, {k: v[:1] for k, v in doc_t.items()}, sampler="ddpm", noises=noises,
+                          trace=tr_ref)
+    out = sampler.sample(eng, tab, xT.cuda(), sampler="ddpm", noise_fn=lambda i: noises[i].cuda(), trace=tr)
+    per = [float((a.cpu() - b).pow(2).mean().sqrt()) for a, b in zip(tr, tr_ref)]
+    err = float((out.cpu() - ref).pow(2).mean().sqrt())
+    print("ddpm 250 loop rmse", err, "per-step[::25]", per[::25], "last", per[-1])
+    assert err < 1e-3, (err, per[-1])
 
 
 def test_batched_documents_match_single():

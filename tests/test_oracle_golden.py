@@ -138,6 +138,27 @@ def test_loop_vs_reference(grid, steps):
     np.testing.assert_allclose(out.numpy(), g["sample"], rtol=0, atol=5e-5)
 
 
+# ----------------------------------------------------------------------------- G7
+@pytest.mark.parametrize("grid,steps", [(16, 10), (32, 3)])
+def test_training_rollout_mode_train_vs_reference(grid, steps):
+    """ddim_sample_loop_for_training(mode='train', n_batch=1, timestep=k) of the real reference
+    (gaussian_diffusion.py:694-782,921-946): raw model time embedded (no override), the caller's init_flow at the
+    first step, roll-out stops at timestep+1, clamp only."""
+    g = load(f"rollout_train_g{grid}_s{steps}.npz")
+    sd = synth.synth_state_dict(grid, 7, blocks=[11])
+    orc = O.Oracle(sd, grid)
+    sch = O.Schedule(steps)
+    assert [float(sch.t_model(i)) for i in range(steps - 1, int(g["timestep"]), -1)] == [float(t) for t in g["t_model"]]
+    trace = []
+    out = orc.sample_loop(sch, torch.from_numpy(g["x_T"]), _doc(grid), mean_hyp=False, trace=trace,
+                          init_flow=torch.from_numpy(g["init_flow"]), last_step=int(g["timestep"]) + 1, mode="train")
+    assert len(trace) == len(g["x0_steps"])
+    for k, x0 in enumerate(trace):
+        err = np.abs(x0.numpy() - g["x0_steps"][k]).max()
+        assert err < 5e-5, (k, err)
+    np.testing.assert_allclose(out.numpy(), g["sample"], rtol=0, atol=5e-5)
+
+
 @pytest.mark.slow
 def test_loop_s10_vs_reference():
     g = load("loop_g64_s10.npz")
