@@ -33,6 +33,8 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 PEAK_F16_TFLOPS = 2500.0      # dense f16/bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0         # HBM3E, same guide
+PROFILE_ROUND = "r2"          # which profiles/<round>_pmc_*.json this bench.py's kernels were measured for
 HID, DEC, FFN = 384, 1536, 2048
 
 
@@ -45,6 +47,64 @@ def step_flops(grid):
         + (4 * 6 * T * D * D + 4 * 4 * T * T * D + 4 * 2 * T * D * D) + 4 * 16 * T * D * D
     dec = 6 * (6 * T * E * E + 4 * T * T * E + 2 * T * E * E + 4 * T * E * F + 18 * T * F) + 16 * T * E
     return block + dec, 4 * T * T * E          # (total per sample-step, one decoder-attention launch per sample)
+
+
+def faithful_step_flops(grid):
+    """FLOPs of ONE denoiser evaluation for ONE sample the way the reference EXECUTES it (idf/cross_model.py:584-616):
+    all 12 DiT blocks (11 of them dead compute), the conv pyramid, the c/m/l embeddings and their K/V projections
+    recomputed at every step (708.8 GFLOP at G=64)."""
+    T = (grid // 2) ** 2
+    D, E, F = HID, DEC, FFN
+    embeds = 2 * T * 8 * D + 2 * T * 1032 * D + 2 * T * 4 * (256 + 384 + 64) * D
+    blk = (2 * T * D * D + 4 * 4 * T * D * D + 4 * 4 * T * T * D + 4 * 2 * T * D * D) \
+        + (4 * 6 * T * D * D + 4 * 4 * T * T * D + 4 * 2 * T * D * D) + 4 * 16 * T * D * D
+    dec = 6 * (6 * T * E * E + 4 * T * T * E + 2 * T * E * E + 4 * T * E * F + 18 * T * F) + 16 * T * E
+    return 97.84e9 + embeds + 12 * blk + dec
+
+
+def workload_name(B, H, S, sampler, G, FH, FW, world):
+    """Which BASELINE.json configuration (if any) this run is."""
+    key = (B, S, sampler, G)
+    tag = {(8, 50, "ddim", 288): "BASELINE configs[1]" if world == 1 else "BASELINE configs[2] shape (8 documents/GPU)",
+           (32, 250, "ddpm", 288): "BASELINE configs[3]", (16, 50, "ddim", 288): "BASELINE configs[4]"}.get(key)
+    if tag == "BASELINE configs[2] shape (8 documents/GPU)" and world == 8:
+        tag = "BASELINE configs[2]"
+    desc = (f"batch={B} documents/GPU x {H} hypotheses, {S}-step {sampler.upper()}, {G}x{G} coordinate grid, "
+            f"+ {FH}x{FW} u8 unwarp")
+    return f"{tag}: {desc}" if tag else f"custom (not a BASELINE.json configuration): {desc}"
+
+
+def init_dist(world, local, backend=None):
+    """One process per GPU under torch.distributed.run (env:// rendezvous); backend 'nccl' IS RCCL on ROCm."""
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend is None:
+            backend = "nccl"
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend=backend)
+
+
+def broadcast_weights(blob, world, sync=None):
+    """The path's only collective: ONE flat broadcast of the packed weight blob from rank 0.  Returns ms (None at 1 rank)."""
+    if world == 1:
+        return None
+    sync = sync or (lambda: None)
+    sync()
+    dist.barrier()
+    t0 = time.perf_counter()
+    dist.broadcast(blob, src=0)
+    sync()
+    return (time.perf_counter() - t0) * 1e3
+
+
+def max_over_ranks(elapsed, world, dev):
+    if world == 1:
+        return elapsed
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
 
 
 def main():
@@ -69,11 +129,9 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", device_id=dev)
+    init_dist(world, local)
 
-    from dvd_amd import ops, sampler, schedule, synth
+    from dvd_amd import lib, ops, sampler, schedule, synth
     from dvd_amd.engine import Engine
 
     G, B, H, S = args.grid, args.docs, args.hyp, args.ddim_steps
@@ -90,14 +148,7 @@ def main():
         del sd
     else:
         blob = torch.empty(blob_bytes, dtype=torch.uint8, device=dev)
-    bcast_ms = None
-    if world > 1:
-        torch.cuda.synchronize()
-        dist.barrier()
-        t0 = time.perf_counter()
-        dist.broadcast(blob, src=0)
-        torch.cuda.synchronize()
-        bcast_ms = (time.perf_counter() - t0) * 1e3
+    bcast_ms = broadcast_weights(blob, world, torch.cuda.synchronize)
     eng.bind_blob(blob)
 
     # ---- synthetic per-rank documents, resident in HBM (value ranges as SURVEY 8(d)) ----
@@ -114,10 +165,18 @@ def main():
     if args.sampler == "ddpm":
         noise_fn = lambda i: torch.randn(B * H, 2, G, G, device=dev, generator=gen)  # noqa: E731
 
-    def one_step():
+    unwarp_events = []          # (start, end) HIP events around the unwarp launches, on the stream they are launched on
+
+    def one_step(timed=False):
         eng.prepare(y512, mask_cat, mask_y512, line_msk)
         flow = sampler.sample(eng, tab, x_T, sampler=args.sampler, noise_fn=noise_fn)     # [B,2,G,G]
-        outs = [ops.unwarp_u8(flow[d:d + 1], src_u8[d]) for d in range(B)]
+        if timed:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+        outs = ops.unwarp_u8_batch(flow, src_u8)                                          # ONE launch for the batch
+        if timed:
+            ev[1].record()
+            unwarp_events.append(ev)
         return flow, outs
 
     for _ in range(args.warmup):
@@ -128,15 +187,11 @@ def main():
         dist.barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        flow, outs = one_step()
+        flow, outs = one_step(timed=True)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = max_over_ranks(time.perf_counter() - t0, world, dev)
     launches, attn_ms = eng.profile_read()
     eng.profile(False)
     assert bool(torch.isfinite(flow).all()), "non-finite coordinates"
@@ -147,33 +202,52 @@ def main():
         per_sample_step, attn_launch_per_sample = step_flops(G)
         n = B * H
         roof = None
+        T = (G // 2) ** 2
+        attn_kernel = lib.flash_attn_kernel_name(256, T, T)
+        launches_issued = 6 * S * args.steps            # 6 decoder layers x S evaluations x steps
         if launches:
             avg_s = attn_ms / launches * 1e-3
             achieved = attn_launch_per_sample * n / avg_s / 1e12
-            roof = {"kernel": "flash_attn_r64_kernel<0> (decoder self-attention, 6 heads x 256)", "bound": "mfma",
+            roof = {"kernel": f"{attn_kernel} (decoder self-attention, 6 heads x 256)", "bound": "mfma",
                     "achieved": round(achieved, 1), "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved / PEAK_F16_TFLOPS, 4), "traffic": None,
-                    "algorithmic_bytes_per_launch": 4 * n * (G // 2) ** 2 * 1536 * 2,   # Q, K, V^T read + O written, f16
-                    "launches_timed": launches, "avg_launch_ms": round(avg_s * 1e3, 3),
-                    "flops_per_launch": attn_launch_per_sample * n,
+                    "algorithmic_bytes_per_launch": 4 * n * T * 1536 * 2,   # Q, K, V^T read + O written, f16
+                    "launches_timed": launches, "launches_issued": launches_issued,
+                    "avg_launch_ms": round(avg_s * 1e3, 3), "flops_per_launch": attn_launch_per_sample * n,
                     "share_of_step_time": round(attn_ms * 1e-3 / elapsed, 3)}
             # HBM bytes per launch of this kernel come from PMC counters, which need their own rocprofv3 passes
-            # (benchmarks/pmc_traffic.sh); bench.py reports the committed measurement when the launch shape matches.
-            tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_pmc_traffic.json")
-            if os.path.exists(tpath) and (n, G) == (16, 288):
-                tj = json.load(open(tpath))
-                key = [k for k in tj if "flash_attn_r64_kernel" in k] or [k for k in tj if "flash_attn_glds_kernel<256" in k]
-                if key:
-                    roof["traffic"] = int(tj[key[0]]["hbm_bytes_per_launch"])
+            # (benchmarks/pmc_traffic.sh).  The committed measurement is attached ONLY when it was taken on the very
+            # kernel this run launched, at this launch shape - a renamed or re-tiled kernel gets traffic: null.
+            here = os.path.dirname(os.path.abspath(__file__))
+            for name, field in (("pmc_traffic", "traffic"), ("pmc_mfma", "mfma")):
+                path = os.path.join(here, "profiles", f"{PROFILE_ROUND}_{name}.json")
+                if not os.path.exists(path):
+                    continue
+                rec = json.load(open(path)).get(attn_kernel)
+                if not rec or rec.get("launch_shape") != {"samples": n, "grid": G}:
+                    continue
+                if field == "traffic":
+                    roof["traffic"] = int(rec["hbm_bytes_per_launch"])
                     roof["traffic_unit"] = "bytes/launch"
-                    roof["traffic_source"] = "profiles/r1_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE; 2*FETCH+WRITE)"
-            mpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_pmc_mfma.json")
-            if os.path.exists(mpath) and (n, G) == (16, 288):
-                mj = json.load(open(mpath)).get("flash_attn_r64_kernel")
-                if mj:   # hardware-side view of the same kernel at the same launch shape (separate PMC pass)
-                    roof["mfma_busy_pmc"] = mj["mfma_busy"]
-                    roof["sustained_clock_ghz_pmc"] = mj["sustained_clock_ghz"]
-                    roof["pmc_source"] = "profiles/r1_pmc_mfma.json"
+                    roof["traffic_source"] = (f"profiles/{PROFILE_ROUND}_{name}.json (rocprofv3 --pmc FETCH_SIZE, "
+                                              "WRITE_SIZE in separate passes; 2*FETCH+WRITE, gfx950 correction)")
+                else:
+                    roof["mfma_busy_pmc"] = rec["mfma_busy"]
+                    roof["sustained_clock_ghz_pmc"] = rec["sustained_clock_ghz"]
+                    roof["pmc_source"] = f"profiles/{PROFILE_ROUND}_{name}.json"
+        # second roofline object: the HBM-bound full-resolution gather (fused u8 tail, one launch per batch)
+        roof_unwarp = None
+        if unwarp_events:
+            ms = sum(a.elapsed_time(b) for a, b in unwarp_events) / len(unwarp_events)
+            bytes_alg = 6 * FH * FW * B                  # fused u8 tail = 3 B/px read + 3 B/px written
+            roof_unwarp = {"kernel": "unwarp_u8_rows_kernel (upsample + affine + grid_sample + uint8, fused; "
+                                     f"{B} documents per launch)", "bound": "hbm",
+                           "achieved": round(bytes_alg / (ms * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                           "frac": round(bytes_alg / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), "traffic": None,
+                           "algorithmic_bytes_per_launch": bytes_alg, "launches_timed": len(unwarp_events),
+                           "avg_launch_ms": round(ms, 4),
+                           "note": "6 B/px algorithmic (u8 in, u8 out); the drop-in f32 grid_sample contract is 32 B/px "
+                                   "(profiles/, benchmarks/op_bench.py)"}
         flops_total = per_sample_step * n * S * world * args.steps
         if not args.no_split_weights:
             pass   # split weights double the GEMM MFMAs; algorithmic FLOPs are unchanged by definition
@@ -183,26 +257,32 @@ def main():
             t_first = tab.model_time(S - 1)
             eng.prepare(y512, mask_cat, mask_y512, line_msk)
             x0_first = eng.denoise(x_T, schedule.embedded_time(t_first), sampler.feat_mode_for(t_first, B * H, True),
-                                   torch.zeros_like(x_T))
+                                   torch.zeros_like(x_T)).clone()
+            # a second evaluation on the WARPED-feature branch (feat_mode 2: t_model <= 600, init_flow = previous x0,
+            # init_feat = grid_sample(feat, (x0 + base) * 2 - 1)) - the branch every step but the first few takes
+            i_mid = max(i for i in range(S) if tab.model_time(i) <= 600.0)
+            t_mid = tab.model_time(i_mid)
+            x0_mid = eng.denoise(x_T, schedule.embedded_time(t_mid), 2, x0_first).clone()
             check = {"doc": [a[:1].float().cpu() for a in (y512, mask_cat, mask_y512, line_msk)], "x": x_T[:1].cpu(),
-                     "t_model": float(t_first), "x0_gpu": x0_first[:1].cpu()}
+                     "t_model": float(t_first), "x0_gpu": x0_first[:1].cpu(),
+                     "t_model_warp": float(t_mid), "x0_gpu_warp": x0_mid[:1].cpu()}
             cpu = cpu_baseline(G, H, S, check)
-            if cpu.get("parity") and not cpu["parity"]["ok"]:
-                raise SystemExit(f"PARITY FAILURE at G={G}: {cpu['parity']}")
+            for par in cpu.get("parity") or []:
+                if not par["ok"]:
+                    raise SystemExit(f"PARITY FAILURE at G={G}: {par}")
         line = {
             "metric": "documents/sec (50-step DDIM, 288x288 grid)" if (G, S, args.sampler) == (288, 50, "ddim")
             else f"documents/sec ({S}-step {args.sampler.upper()}, {G}x{G} grid)",
             "value": round(value, 5), "unit": "documents/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[1]: batch={B} documents/GPU x {H} hypotheses, {S}-step "
-                                   f"{args.sampler.upper()}, {G}x{G} coordinate grid, + {FH}x{FW} u8 unwarp",
+            "config": {"workload": workload_name(B, H, S, args.sampler, G, FH, FW, world),
                        "docs_per_gpu": B, "hypotheses": H, "sampler_steps": S, "grid": G,
                        "weights": "synthetic (seed 7), f16 hi/lo split" if not args.no_split_weights else "synthetic, f16",
                        "parallelism": f"dp{world} (documents sharded, one weight broadcast)"},
             "algorithmic_tflops": round(flops_total / elapsed / 1e12, 1),
             "weight_broadcast_ms": None if bcast_ms is None else round(bcast_ms, 2),
-            "roofline": roof, "cpu_baseline": cpu,
+            "roofline": roof, "roofline_unwarp": roof_unwarp, "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)
     if world > 1:
@@ -240,18 +320,43 @@ def cpu_baseline(grid, hyp, steps, check=None):
     def time_and_check(g):
         """The timed evaluation doubles as a FULL-SIZE parity check: it is the first loop step of document 0 /
         hypothesis 0 of this very run (same synthetic weights, conditioning and x_T), compared with what the engine
-        produced for that sample."""
+        produced for that sample; a second (untimed) evaluation checks the warped-feature branch."""
         sd = synth.synth_state_dict(g, seed=7, blocks=[11])
         orc = O.Oracle(sd, g)
+        res = []
         with torch.no_grad():
             inv = orc.prepare(*check["doc"])                      # once-per-document work: not part of the timed step
             t0 = time.perf_counter()
             x0_ref, _ = orc.forward(check["x"], check["t_model"], inv, torch.zeros_like(check["x"]), inv["feat"])
             dt = time.perf_counter() - t0
-        rmse = float((x0_ref - check["x0_gpu"]).pow(2).mean().sqrt())
-        return dt, {"what": f"x0 prediction of the first loop step (t_model = {check['t_model']:.1f}) of document 0 / "
-                            f"hypothesis 0 at G={g}: HIP engine vs CPU oracle", "coord_rmse": rmse, "bar": 1e-3,
-                    "ok": bool(rmse < 1e-3)}
+            rmse = float((x0_ref - check["x0_gpu"]).pow(2).mean().sqrt())
+            res.append({"what": f"x0 prediction of the first loop step (t_model = {check['t_model']:.1f}, init_feat = "
+                                f"feat) of document 0 / hypothesis 0 at G={g}: HIP engine vs CPU oracle",
+                        "coord_rmse": rmse, "bar": 1e-3, "ok": bool(rmse < 1e-3)})
+            if "x0_gpu_warp" in check:
+                flow = check["x0_gpu"]                            # the engine's own first-step x0 is the init_flow
+                init_feat = O.grid_sample_ref(inv["feat"], (flow + O.base_grid(g, g)) * 2 - 1)
+                x0w, _ = orc.forward(check["x"], check["t_model_warp"], inv, flow, init_feat)
+                rmse = float((x0w - check["x0_gpu_warp"]).pow(2).mean().sqrt())
+                res.append({"what": f"x0 prediction on the warped-feature branch (feat_mode 2, t_model = "
+                                    f"{check['t_model_warp']:.1f}, init_flow = first-step x0) at G={g}: HIP engine vs "
+                                    "CPU oracle", "coord_rmse": rmse, "bar": 1e-3, "ok": bool(rmse < 1e-3)})
+        return dt, res
+
+    def time_faithful(g=64):
+        """What the reference EXECUTES per sample-step (all 12 blocks, pyramid + c/m/l embeddings every step):
+        one sample-step at G=64, scaled by the faithful FLOP ratio to the benchmark grid (stated in `sample`)."""
+        sd = synth.synth_state_dict(g, seed=7)
+        orc = O.Oracle(sd, g, live_blocks_only=False)
+        gen = torch.Generator().manual_seed(5)
+        doc = [torch.rand(1, 3, 512, 512, generator=gen), torch.rand(1, 1, 512, 512, generator=gen),
+               torch.randn(1, 384, g, g, generator=gen).clamp_min_(0), torch.randn(1, 64, g, g, generator=gen).clamp_min_(0)]
+        x = torch.randn(1, 2, g, g, generator=gen)
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            inv = orc.prepare(*doc)                               # per-step in the reference: inside the timed region
+            orc.forward(x, 666.7, inv, torch.zeros(1, 2, g, g), inv["feat"])
+        return time.perf_counter() - t0
 
     t64 = time_one(64)
     f64, _ = step_flops(64)
@@ -270,7 +375,17 @@ def cpu_baseline(grid, hyp, steps, check=None):
                   f"(of {hyp * steps} per document), hoisted algebra")
     docs_per_s = 1.0 / (hyp * steps * t_step)
     out = {"value": round(docs_per_s, 7), "unit": "documents/s", "cores": cores, "kind": "port", "sample": sample,
+           "mode": "hoisted (the GPU engine's algebra: live block only, per-document invariants outside the step)",
            "seconds_per_sample_step": round(t_step, 3)}
+    tf64 = time_faithful(64)
+    tf = tf64 * faithful_step_flops(grid) / faithful_step_flops(64)
+    out["faithful"] = {"value": round(1.0 / (hyp * steps * tf), 8), "unit": "documents/s", "cores": cores,
+                       "mode": "faithful (what the reference executes: 12 DiT blocks, conv pyramid and c/m/l "
+                               "embeddings at every step; idf/cross_model.py:584-616)",
+                       "sample": f"1 sample x 1 denoiser evaluation at G=64 ({tf64:.2f} s, "
+                                 f"{faithful_step_flops(64) / 1e9:.1f} GFLOP), scaled by the faithful FLOP ratio "
+                                 f"{faithful_step_flops(grid) / faithful_step_flops(64):.1f} to G={grid}",
+                       "seconds_per_sample_step": round(tf, 3)}
     if parity is not None:
         out["parity"] = parity
     return out

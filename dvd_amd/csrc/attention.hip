@@ -840,645 +840,36 @@ __global__ void __launch_bounds__(256, 1) flash_attn_r64_kernel(AttnArgs p) {
 }
 
 
-// ================================================================================================
-// head_dim 64, TWO 32-row query blocks per wave (a workgroup = 4 waves = 256 query rows).  flash_attn_glds_kernel<64>
-// runs two waves per SIMD, and every MFMA of every wave needs its own 1-KiB fragment from LDS: 8 waves x 1 KiB per
-// 32-cycle MFMA slot = 256 B/clk, twice what the CU's LDS port delivers - that, not the softmax VALU, held the kernel at
-// ~37 % of the matrix peak.  Here each K / V^T fragment read feeds TWO MFMAs (query rows r and 32 + r), halving the
-// LDS traffic per FLOP; O^T (64 registers), S^T (64) and Q (32) for 64 rows still fit the 256 registers that two
-// waves per SIMD allow.  Same LDS image, swizzle, fragment maps, deferred-rescale softmax (one running max / sum per
-// row block) and per-element arithmetic as flash_attn_glds_kernel<64>.
-// MEASURED: no gain (872 vs 895 TF/s) - halving the LDS traffic and the barriers per FLOP changes nothing, so head_dim
-// 64 is bound by VALU ISSUE (per MFMA gap: 2 v_exp at 8 cycles + ~7 other VALU at 4 + the MFMA's own 8 = 54 cycles
-// against the 32 the matrix pipe needs), which two waves on one SIMD share.  Opt-in (DVD_ATTN_64X2=1).
-// ================================================================================================
-__global__ void __launch_bounds__(256, 2) flash_attn_glds64x2_kernel(AttnArgs p) {
-  constexpr int D = 64, KB = 64, KROWB = 128, KBYTES = KB * KROWB, VBYTES = D * 128, BUF = KBYTES + VBYTES;
-  constexpr int KINST = 2, VINST = 2, KS = 4, DT = 2, RB = 2;
-  constexpr float RESCALE_THR = 10.f;
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][BUF]
-  typedef __attribute__((address_space(3))) void* lptr_t;
-
-  const int nwg = gridDim.x;
-  int id = blockIdx.x;
-  {
-    const int q = nwg / 8, rr = nwg % 8, xcd = id % 8, k = id / 8;
-    id = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + k;
-  }
-  const int qb = id % p.nqb;          // 256-row query blocks here
-  const int bh = id / p.nqb;
-  const int head = bh % p.heads, b = bh / p.heads;
-  const int kvb = b / p.kv_div;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int r = lane & 31, h = lane >> 5;
-
-  const _Float16* Qg = p.Q + b * p.sQ + (size_t)head * D;
-  const char* Kg = (const char*)(p.K + kvb * p.sK + (size_t)head * D);
-  const char* Vg = (const char*)(p.Vt + kvb * p.sVt + (size_t)head * D * p.ldvt);
-
-  half8 qf[RB][KS];
-#pragma unroll
-  for (int rb = 0; rb < RB; ++rb) {
-    const int qrow = min(qb * 256 + wave * 64 + rb * 32 + r, p.tq - 1);
-    const _Float16* qp = Qg + (size_t)qrow * p.ldq + 8 * h;
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) qf[rb][ks] = *(const half8*)(qp + 16 * ks);
-  }
-  __builtin_amdgcn_s_waitcnt(0x0F70);   // retire the Q loads with a wait the compiler tracks (see flash_attn_glds_kernel)
-
-  unsigned koff[KINST], voff[VINST];
-#pragma unroll
-  for (int i = 0; i < KINST; ++i) {
-    const int q = (KINST * wave + i) * 64 + lane;
-    const int row = q / 8, pos = q % 8;
-    koff[i] = (unsigned)row * (unsigned)(p.ldk * 2) + (unsigned)((pos ^ ((row >> 1) & 7)) * 16);
-  }
-#pragma unroll
-  for (int i = 0; i < VINST; ++i) {
-    const int q = (VINST * wave + i) * 64 + lane;
-    const int row = q / 8, pos = q % 8;
-    voff[i] = (unsigned)row * (unsigned)(p.ldvt * 2) + (unsigned)((pos ^ ((row >> 1) & 7)) * 16);
-  }
-  const int kr = kappa(r);
-  const int fk = (kr >> 1) & 7;
-  int kfrag[KS];
-#pragma unroll
-  for (int ks = 0; ks < KS; ++ks) kfrag[ks] = kr * KROWB + (((2 * ks + h) ^ fk) * 16);
-  const int fv = (r >> 1) & 7;
-  int vfrag[4];
-#pragma unroll
-  for (int c = 0; c < 4; ++c) vfrag[c] = KBYTES + r * 128 + (((2 * c + h) ^ fv) * 16);
-
-  floatx16 o[RB][DT];
-#pragma unroll
-  for (int rb = 0; rb < RB; ++rb)
-#pragma unroll
-    for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) o[rb][dt][i] = 0.f;
-  float m_run[RB] = {-1e30f, -1e30f}, l_run[RB] = {0.f, 0.f};
-  const int nt = p.tk / KB;
-  const size_t ktile = (size_t)KB * p.ldk * 2;
-  const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t)smem;
-
-  glds_group<KINST>(Kg, koff, lds0 + (KINST * wave) * 1024);
-  glds_group<VINST>(Vg, voff, lds0 + KBYTES + (VINST * wave) * 1024);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-
-#define SB() __builtin_amdgcn_sched_barrier(0)
-  // fragment f of the first product: k-step f >> 1, key block f & 1; of the second: chunk f >> 1, d block f & 1
-#define KLOAD2(f_) fr[(f_) & 7] = *(const half8*)(base + kfrag[(f_) >> 1] + ((f_) & 1) * 32 * KROWB)
-#define VLOAD2(f_) fr[(f_) & 7] = *(const half8*)(base + vfrag[(f_) >> 1] + ((f_) & 1) * 32 * 128)
-  int cur = 0;
-  for (int t = 0; t < nt; ++t) {
-    const int tn = min(t + 1, nt - 1);
-    const char* kg_next = Kg + (size_t)tn * ktile;
-    const char* vg_next = Vg + (size_t)tn * (KB * 2);
-    const unsigned lds_next = lds0 + (cur ^ 1) * BUF;
-    const char* base = smem + cur * BUF;
-    half8 fr[8];
-    floatx16 s[RB][2];
-#pragma unroll
-    for (int rb = 0; rb < RB; ++rb)
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) s[rb][kb][i] = 0.f;
-    KLOAD2(0); KLOAD2(1); KLOAD2(2); KLOAD2(3);
-    SB();
-#pragma unroll
-    for (int f = 0; f < 8; ++f) {          // 8 K fragments, 2 MFMAs each
-      const int ks = f >> 1, kb = f & 1;
-      s[0][kb] = mfma32_f16(fr[f & 7], qf[0][ks], s[0][kb]);
-      s[1][kb] = mfma32_f16(fr[f & 7], qf[1][ks], s[1][kb]);
-      if (f + 4 < 8) { KLOAD2(f + 4); } else { VLOAD2(f + 4 - 8); }
-      if (f == 3) glds_one(kg_next, koff[0], lds_next + (KINST * wave) * 1024);
-      if (f == 7) glds_one(kg_next, koff[1], lds_next + (KINST * wave + 1) * 1024);
-      SB();
-    }
-
-    float mx[RB];
-#pragma unroll
-    for (int rb = 0; rb < RB; ++rb) {
-      float m = -1e30f;
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) m = fmaxf(m, s[rb][kb][i]);
-      mx[rb] = half_swap_max(m * p.c);
-    }
-    if (__any(fmaxf(mx[0] - m_run[0], mx[1] - m_run[1]) > RESCALE_THR)) {     // deferred rescale (both row blocks)
-#pragma unroll
-      for (int rb = 0; rb < RB; ++rb) {
-        const float m_new = fmaxf(m_run[rb], mx[rb]);
-        const float alpha = __builtin_amdgcn_exp2f(m_run[rb] - m_new);
-        m_run[rb] = m_new;
-        l_run[rb] *= alpha;
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-          for (int i = 0; i < 16; ++i) o[rb][dt][i] *= alpha;
-      }
-    }
-    float rs[RB] = {0.f, 0.f};
-    half8 pf[RB][4];
-    // chunk c of P = registers 8 (c & 1) .. +7 of s[rb][c >> 1]
-#define PEXP2(rb_, c_, e_)                                                                                  \
-  {                                                                                                         \
-    const float pv_ = __builtin_amdgcn_exp2f(fmaf(s[rb_][(c_) >> 1][8 * ((c_) & 1) + (e_)], p.c, -m_run[rb_])); \
-    rs[rb_] += pv_;                                                                                         \
-    pf[rb_][c_][e_] = (_Float16)pv_;                                                                        \
-  }
-#pragma unroll
-    for (int e = 0; e < 8; ++e) { PEXP2(0, 0, e) PEXP2(1, 0, e) }
-    SB();
-#pragma unroll
-    for (int f = 0; f < 8; ++f) {          // 8 V^T fragments (chunk c, d block dt), 2 MFMAs each
-      const int c = f >> 1, dt = f & 1;
-      o[0][dt] = mfma32_f16(fr[f & 7], pf[0][c], o[0][dt]);
-      o[1][dt] = mfma32_f16(fr[f & 7], pf[1][c], o[1][dt]);
-      if (f + 4 < 8) VLOAD2(f + 4);
-      if (c < 3) {                         // P chunk c+1 of both row blocks in the gaps of chunk c's 4 MFMAs
-#pragma unroll
-        for (int e = dt * 4; e < dt * 4 + 4; ++e) { PEXP2(0, c + 1, e) PEXP2(1, c + 1, e) }
-      }
-      if (f == 3) glds_one(vg_next, voff[0], lds_next + KBYTES + (VINST * wave) * 1024);
-      if (f == 6) glds_one(vg_next, voff[1], lds_next + KBYTES + (VINST * wave + 1) * 1024);
-      SB();
-    }
-    l_run[0] += rs[0];
-    l_run[1] += rs[1];
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    cur ^= 1;
-  }
-#undef SB
-#undef KLOAD2
-#undef VLOAD2
-#undef PEXP2
-
-#pragma unroll
-  for (int rb = 0; rb < RB; ++rb) {
-    const float l_tot = l_run[rb] + __shfl_xor(l_run[rb], 32);
-    const float inv = 1.f / l_tot;
-    const int qglob = qb * 256 + wave * 64 + rb * 32 + r;
-    if (qglob < p.tq) {
-      _Float16* op = p.O + b * p.sO + (size_t)qglob * p.ldo + (size_t)head * D;
-#pragma unroll
-      for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-          half4 v;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] = (_Float16)(o[rb][dt][4 * g4 + j] * inv);
-          *(half4*)(op + 32 * dt + 8 * g4 + 4 * h) = v;
-        }
-    }
-  }
-}
-
-
-// ================================================================================================
-// head_dim 256, SOFTWARE-PIPELINED over 32-key half tiles ("blocks").  Same data movement, LDS image, fragment maps and
-// arithmetic per element as flash_attn_glds_kernel<256>; what changes is the order of work inside a wave.  There the
-// softmax of a 64-key tile (max, rescale test, first exps: ~500 cycles) runs with the matrix pipe idle.  Here block u's
-// softmax VALU is interleaved with the 16 MFMAs of S^T(u+1), and its PV product with the combine of the next
-// accumulators:
-//     iteration u:   (a) S^T(u+1) = K(u+1).Q^T  [16 MFMA]  ||  softmax(u): max, rescale test, 13 of 16 exps
-//                    (b) O^T += V^T(u).P(u)      [16 MFMA]  ||  last 3 exps, s(u+1) = sa + sb
-//                    wait for the loads issued one block ago, barrier
-// The online softmax therefore steps per 32 keys (deferred rescale as before).  S^T(u+1) accumulates into two
-// registers sets (even / odd k-steps) because one dependent chain of MFMAs issues at ~58 instead of 32 cycles each.
-// LDS-DMA loads: V^T(t+1) during the first block of tile t, K(t+2) during the second (each has a whole block of slack
-// before its first use, so the end-of-block wait is vmcnt(8), not vmcnt(0)).
-// MEASURED (MI355X, DVD_ATTN_PIPE=1): correct (parity tests pass) but SLOWER, 830 vs 975 TF/s.  Stamps per 64-key tile:
-// block heads 860 cycles, MFMA phases 1678 + 1607, waiting for the LDS-DMA loads 1018, barriers 141 = 5303 against
-// 3751 for flash_attn_glds_kernel.  The CU's LDS port is the real limit (fragment reads alone are 4 waves x 1 KiB per
-// 32-cycle MFMA = 128 B/clk = its peak); with the softmax window filled by MFMAs + fragment reads the LDS-DMA WRITES
-// find no free port cycles and pile up to the end of the block, where every wave then waits for them.  In the
-// non-pipelined kernel the ~450-cycle softmax head is exactly the window in which those writes drain.  Not the default.
-// ================================================================================================
-template <int DBG>
-__global__ void __launch_bounds__(256, 1) flash_attn_pipe_kernel(AttnArgs p) {
-  constexpr int D = 256, KB = 64, KROWB = 512, KCPR = 32, KBYTES = KB * KROWB, VBYTES = D * 128, BUF = KBYTES + VBYTES;
-  constexpr int KINST = 8, VINST = 8, KS = 16, DT = 8;
-  constexpr float RESCALE_THR = 10.f;
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][BUF]
-  typedef __attribute__((address_space(3))) void* lptr_t;
-
-  const int nwg = gridDim.x;
-  int id = blockIdx.x;
-  {
-    const int q = nwg / 8, rr = nwg % 8, xcd = id % 8, k = id / 8;
-    id = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + k;
-  }
-  const int qb = id % p.nqb;
-  const int bh = id / p.nqb;
-  const int head = bh % p.heads, b = bh / p.heads;
-  const int kvb = b / p.kv_div;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int r = lane & 31, h = lane >> 5;
-
-  const _Float16* Qg = p.Q + b * p.sQ + (size_t)head * D;
-  const char* Kg = (const char*)(p.K + kvb * p.sK + (size_t)head * D);
-  const char* Vg = (const char*)(p.Vt + kvb * p.sVt + (size_t)head * D * p.ldvt);
-
-  const int qrow = min(qb * 128 + wave * 32 + r, p.tq - 1);
-  half8 qf[KS];
-  {
-    const _Float16* qp = Qg + (size_t)qrow * p.ldq + 8 * h;
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const half8*)(qp + 16 * ks);
-  }
-  __builtin_amdgcn_s_waitcnt(0x0F70);   // retire the Q loads with a wait the compiler tracks (see flash_attn_glds_kernel)
-
-  unsigned koff[KINST], voff[VINST];
-#pragma unroll
-  for (int i = 0; i < KINST; ++i) {
-    const int q = (KINST * wave + i) * 64 + lane;
-    const int row = q / KCPR, pos = q % KCPR;
-    koff[i] = (unsigned)row * (unsigned)(p.ldk * 2) + (unsigned)((pos ^ (row & 15)) * 16);
-  }
-#pragma unroll
-  for (int i = 0; i < VINST; ++i) {
-    const int q = (VINST * wave + i) * 64 + lane;
-    const int row = q / 8, pos = q % 8;
-    voff[i] = (unsigned)row * (unsigned)(p.ldvt * 2) + (unsigned)((pos ^ ((row >> 1) & 7)) * 16);
-  }
-  const int kr = kappa(r);
-  int kfrag[KS];
-#pragma unroll
-  for (int ks = 0; ks < KS; ++ks) kfrag[ks] = kr * KROWB + (((2 * ks + h) ^ (kr & 15)) * 16);
-  const int fv = (r >> 1) & 7;
-  int vfrag[4];
-#pragma unroll
-  for (int c = 0; c < 4; ++c) vfrag[c] = KBYTES + r * 128 + (((2 * c + h) ^ fv) * 16);
-
-  floatx16 o[DT];
-#pragma unroll
-  for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) o[dt][i] = 0.f;
-  float m_run = -1e30f, l_run = 0.f;
-  const int nt = p.tk / KB;
-  const size_t ktile = (size_t)KB * p.ldk * 2;
-  const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t)smem;
-
-  // prologue: K(0), V^T(0) -> buffer 0, K(1) -> buffer 1
-  glds_group<KINST>(Kg, koff, lds0 + (KINST * wave) * 1024);
-  glds_group<VINST>(Vg, voff, lds0 + KBYTES + (VINST * wave) * 1024);
-  if (nt > 1) glds_group<KINST>(Kg + ktile, koff, lds0 + BUF + (KINST * wave) * 1024);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-
-#define SB() __builtin_amdgcn_sched_barrier(0)
-  unsigned long long acc_t[5] = {0, 0, 0, 0, 0};
-  unsigned long long tprev = 0;
-#define STAMP(k_)                                                              \
-  if constexpr (DBG & 1) {                                                     \
-    __builtin_amdgcn_sched_barrier(0);                                         \
-    const unsigned long long now_ = __builtin_amdgcn_s_memtime();              \
-    __builtin_amdgcn_s_waitcnt(0xC07F);                                        \
-    acc_t[k_] += now_ - tprev;                                                 \
-    tprev = now_;                                                              \
-    __builtin_amdgcn_sched_barrier(0);                                         \
-  }
-  half8 fr[8];
-  floatx16 sa, sb, sc;
-  // ---- S^T(0), not overlapped
-  {
-    const char* kbase = smem;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) { sa[i] = 0.f; sb[i] = 0.f; }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) fr[i] = *(const half8*)(kbase + kfrag[i]);
-    SB();
-#pragma unroll
-    for (int i = 0; i < KS; ++i) {
-      if (i & 1) sb = mfma32_f16(fr[i & 7], qf[i], sb); else sa = mfma32_f16(fr[i & 7], qf[i], sa);
-      if (i + 4 < KS) fr[(i + 4) & 7] = *(const half8*)(kbase + kfrag[i + 4]);
-      SB();
-    }
-#pragma unroll
-    for (int i = 0; i < 16; ++i) sc[i] = sa[i] + sb[i];
-  }
-  if constexpr (DBG & 1) tprev = __builtin_amdgcn_s_memtime();
-
-  // One block.  HB_: which half of tile t holds block u (compile-time).  kbase_/kb_: where S^T(u+1) reads K;
-  // ISSUE_: the 8 loads of this block (macro taking the load index 0..7).
-#define PEXPB(e_)                                                                              \
-  {                                                                                            \
-    const float pv_ = __builtin_amdgcn_exp2f(fmaf(sc[e_], p.c, -m_run));                       \
-    rs += pv_;                                                                                 \
-    pf[(e_) >> 3][(e_) & 7] = (_Float16)pv_;                                                   \
-  }
-#define ATTN_BLOCK(HB_, kbase_, kbofs_, ISSUE_, nloads_)                                        \
-  {                                                                                            \
-    const char* kb_ = (kbase_) + (kbofs_);                                                     \
-    _Pragma("unroll") for (int i = 0; i < 16; ++i) { sa[i] = 0.f; sb[i] = 0.f; }                \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) fr[i] = *(const half8*)(kb_ + kfrag[i]);     \
-    /* max tree of block u while the first fragments arrive */                                 \
-    float mx = fmaxf(fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3])), fmaxf(fmaxf(sc[4], sc[5]), fmaxf(sc[6], sc[7]))); \
-    mx = fmaxf(mx, fmaxf(fmaxf(fmaxf(sc[8], sc[9]), fmaxf(sc[10], sc[11])), fmaxf(fmaxf(sc[12], sc[13]), fmaxf(sc[14], sc[15])))); \
-    mx *= p.c;                                                                                 \
-    mx = half_swap_max(mx);                                                        \
-    if (__any(mx - m_run > RESCALE_THR)) {                                                     \
-      const float m_new = fmaxf(m_run, mx);                                                    \
-      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);                               \
-      m_run = m_new;                                                                           \
-      l_run *= alpha;                                                                          \
-      /* the PV MFMAs of the previous block were issued > 200 cycles ago; be explicit anyway */ \
-      asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");               \
-      _Pragma("unroll") for (int dt = 0; dt < DT; ++dt) scale_acc_in_agpr(o[dt], alpha);       \
-    }                                                                                          \
-    float rs = 0.f;                                                                            \
-    half8 pf[2];                                                                               \
-    STAMP(0)                                                                                   \
-    SB();                                                                                      \
-    _Pragma("unroll") for (int i = 0; i < KS; ++i) {                                           \
-      if (i & 1) sb = mfma32_f16(fr[i & 7], qf[i], sb); else sa = mfma32_f16(fr[i & 7], qf[i], sa); \
-      if (i + 4 < KS) fr[(i + 4) & 7] = *(const half8*)(kb_ + kfrag[i + 4]);                   \
-      else fr[(i + 4) & 7] = *(const half8*)(vb_ + vfrag[2 * (HB_)] + (i + 4 - KS) * 32 * 128); \
-      if (i >= 3) PEXPB(i - 3)                                                                 \
-      if ((i & 3) == 3 && (nloads_)) { ISSUE_(i >> 2) }                                        \
-      SB();                                                                                    \
-    }                                                                                          \
-    STAMP(1)                                                                                   \
-    _Pragma("unroll") for (int j = 0; j < 16; ++j) {                                           \
-      const int cl = j >> 3, dt = j & 7;                                                       \
-      o[dt] = mfma32_f16(fr[(j + 16) & 7], pf[cl], o[dt]);                                     \
-      if (j + 4 < 16) fr[(j + 20) & 7] = *(const half8*)(vb_ + vfrag[2 * (HB_) + ((j + 4) >> 3)] + ((j + 4) & 7) * 32 * 128); \
-      if (j < 3) PEXPB(13 + j)                                                                 \
-      if (j >= 4 && j < 12) { sc[2 * (j - 4)] = sa[2 * (j - 4)] + sb[2 * (j - 4)]; sc[2 * (j - 4) + 1] = sa[2 * (j - 4) + 1] + sb[2 * (j - 4) + 1]; } \
-      if ((j & 3) == 3 && (nloads_)) { ISSUE_(4 + (j >> 2)) }                                   \
-      SB();                                                                                    \
-    }                                                                                          \
-    l_run += rs;                                                                               \
-    STAMP(2)                                                                                   \
-  }
-
-  for (int t = 0; t < nt; ++t) {
-    const char* cbase = smem + (t & 1) * BUF;
-    const char* vb_ = cbase;
-    // ---- block 2t: S^T of the second half of tile t; loads V^T(t+1) -> buffer (t+1)&1
-    {
-      const bool ld = t + 1 < nt;
-      const char* vg_n = Vg + (size_t)(t + 1) * (KB * 2);
-      const unsigned lds_n = lds0 + ((t + 1) & 1) * BUF + KBYTES + (VINST * wave) * 1024;
-#define ISSUE_V(i_) glds_one(vg_n, voff[i_], lds_n + (i_) * 1024);
-      ATTN_BLOCK(0, cbase, 32 * KROWB, ISSUE_V, ld)
-#undef ISSUE_V
-      if (ld) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      STAMP(3)
-      __syncthreads();
-      STAMP(4)
-    }
-    // ---- block 2t+1: S^T of the first half of tile t+1 (at the very end: recomputed on tile t, unused);
-    //      loads K(t+2) -> buffer t&1 (K(t) was last read in the block above)
-    {
-      const bool ld = t + 2 < nt;
-      const char* kg_n = Kg + (size_t)(t + 2) * ktile;
-      const unsigned lds_n = lds0 + (t & 1) * BUF + (KINST * wave) * 1024;
-      const char* nbase = (t + 1 < nt) ? smem + ((t + 1) & 1) * BUF : cbase + 32 * KROWB;
-#define ISSUE_K(i_) glds_one(kg_n, koff[i_], lds_n + (i_) * 1024);
-      ATTN_BLOCK(1, nbase, 0, ISSUE_K, ld)
-#undef ISSUE_K
-      if (ld) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      STAMP(3)
-      __syncthreads();
-      STAMP(4)
-    }
-  }
-  if constexpr (DBG & 1) {
-    if (lane == 0 && p.stamps) {
-      unsigned long long* o_ = p.stamps + ((size_t)blockIdx.x * 4 + wave) * 5;
-      for (int k = 0; k < 5; ++k) o_[k] = acc_t[k];
-    }
-  }
-#undef ATTN_BLOCK
-#undef PEXPB
-#undef STAMP
-#undef SB
-
-  const float l_tot = l_run + __shfl_xor(l_run, 32);
-  const float inv = 1.f / l_tot;
-  const int qglob = qb * 128 + wave * 32 + r;
-  if (qglob < p.tq) {
-    _Float16* op = p.O + b * p.sO + (size_t)qglob * p.ldo + (size_t)head * D;
-#pragma unroll
-    for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        half4 v;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = (_Float16)(o[dt][4 * g4 + j] * inv);
-        *(half4*)(op + 32 * dt + 8 * g4 + 4 * h) = v;
-      }
-  }
-}
-
-
-// ================================================================================================
-// head_dim 256, TWO waves per SIMD ("d-split"): a workgroup is 8 waves = 4 query blocks x 2 halves of the
-// head dimension.  The two waves of a pair own the same 32 query rows; BOTH compute the full S^T = K.Q^T and the
-// softmax (no communication), each accumulates only its 128 of the 256 output columns (O^T: 64 registers
-// instead of 128).  EXPERIMENT, NOT THE DEFAULT: correct (parity tests pass with DVD_ATTN_DSPLIT=1) but 10 % slower
-// than the one-wave-per-SIMD kernel - the CU's L2->LDS load path (~34 B/clk, 64 KiB per tile) is the common
-// limit and the duplicated QK^T product is not paid back.  That wastes MFMA work (48 instead of 32 useful-equivalent MFMAs per wave and tile: the QK^T
-// product is done twice) but brings the wave under 256 registers, so two waves share every SIMD and one wave's
-// LDS-DMA issue (8 x ~120 cycles per tile), softmax VALU and LDS latency overlap the other's MFMAs - at one wave
-// per SIMD those were 64 % of a tile (s_memtime stamps: 5335 cycles per 2048 cycles of MFMA).
-// ================================================================================================
-template <int N>
-__device__ __forceinline__ void glds_group4(const char* gbase, const unsigned (&voff)[N], unsigned lds) {
-  static_assert(N == 4, "unsupported group size");
-  unsigned keep;
-  asm volatile(
-      "s_mov_b32 %0, m0\n\t"
-      "s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %1\n\t"
-      "s_add_u32 m0, %2, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %1\n\t"
-      "s_add_u32 m0, %2, 0x800\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %5, %1\n\t"
-      "s_add_u32 m0, %2, 0xc00\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %6, %1\n\t"
-      "s_mov_b32 m0, %0"
-      : "=&s"(keep)
-      : "s"(gbase), "s"(lds), "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "v"(voff[3])
-      : "memory", "scc");
-}
-
-__global__ void __launch_bounds__(512, 2) flash_attn_dsplit_kernel(AttnArgs p) {
-  constexpr int D = 256, KB = 64, KROWB = 512, KBYTES = KB * KROWB, VBYTES = D * 128, BUF = KBYTES + VBYTES;
-  constexpr int KS = 16, NS = 32, NP = 16;
-  constexpr float RESCALE_THR = 10.f;
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][BUF]
-  typedef __attribute__((address_space(3))) void* lptr_t;
-
-  const int nwg = gridDim.x;
-  int id = blockIdx.x;
-  {
-    const int q = nwg / 8, rr = nwg % 8, xcd = id % 8, k = id / 8;
-    id = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + k;
-  }
-  const int qb = id % p.nqb;
-  const int bh = id / p.nqb;
-  const int head = bh % p.heads, b = bh / p.heads;
-  const int kvb = b / p.kv_div;
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int qw = wave >> 1, dh = wave & 1;
-  const int r = lane & 31, h = lane >> 5;
-
-  const _Float16* Qg = p.Q + b * p.sQ + (size_t)head * D;
-  const char* Kg = (const char*)(p.K + kvb * p.sK + (size_t)head * D);
-  const char* Vg = (const char*)(p.Vt + kvb * p.sVt + (size_t)head * D * p.ldvt);
-
-  const int qrow = min(qb * 128 + qw * 32 + r, p.tq - 1);
-  half8 qf[KS];
-  {
-    const _Float16* qp = Qg + (size_t)qrow * p.ldq + 8 * h;
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const half8*)(qp + 16 * ks);
-  }
-
-  unsigned koff[4], voff[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int q = (4 * wave + i) * 64 + lane;
-    const int krow = q / 32, kpos = q % 32;
-    koff[i] = (unsigned)krow * (unsigned)(p.ldk * 2) + (unsigned)((kpos ^ (krow & 15)) * 16);
-    const int vrow = q / 8, vpos = q % 8;
-    voff[i] = (unsigned)vrow * (unsigned)(p.ldvt * 2) + (unsigned)((vpos ^ ((vrow >> 1) & 7)) * 16);
-  }
-  // fragment read offsets: K chunk (2 ks + h) ^ fk = 2 (ks ^ (fk >> 1)) + (h ^ (fk & 1)); ks ^ xs = 8 (ks >> 3) + ((ks & 7) ^ xs)
-  const int kr = kappa(r), fk = kr & 15, xs = fk >> 1;
-  int kfrag8[8];
-#pragma unroll
-  for (int k = 0; k < 8; ++k) kfrag8[k] = kr * KROWB + 16 * (h ^ (fk & 1)) + 32 * (k ^ xs);
-  const int fv = (r >> 1) & 7;
-  int vfrag[4];
-#pragma unroll
-  for (int c = 0; c < 4; ++c) vfrag[c] = KBYTES + (dh * 128 + r) * 128 + (((2 * c + h) ^ fv) * 16);   // (128 dh + r) >> 1 & 7 == fv
-
-  floatx16 o[4];
-#pragma unroll
-  for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) o[dt][i] = 0.f;
-  float m_run = -1e30f, l_run = 0.f;
-  const int nt = p.tk / KB;
-  const size_t ktile = (size_t)KB * p.ldk * 2;
-  const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t)smem;
-
-#define DS_ISSUE(t_, buf_)                                                                                   \
-  {                                                                                                          \
-    glds_group4<4>(Kg + (size_t)(t_) * ktile, koff, lds0 + (buf_) * BUF + (4 * wave) * 1024);                 \
-    glds_group4<4>(Vg + (size_t)(t_) * (KB * 2), voff, lds0 + (buf_) * BUF + KBYTES + (4 * wave) * 1024);     \
-  }
-#define SB() __builtin_amdgcn_sched_barrier(0)
-#define KLOAD(i_) fr[(i_) & 7] = *(const half8*)(base + kfrag8[((i_) >> 1) & 7] + ((i_) >> 4) * 256 + ((i_) & 1) * 32 * KROWB)
-#define VLOAD(j_) fr[(j_) & 7] = *(const half8*)(base + vfrag[(j_) >> 2] + ((j_) & 3) * 32 * 128)
-
-  DS_ISSUE(0, 0)
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-
-  int cur = 0;
-  for (int t = 0; t < nt; ++t) {
-    if (t + 1 < nt) DS_ISSUE(t + 1, cur ^ 1)
-    const char* base = smem + cur * BUF;
-    half8 fr[8];
-    floatx16 s[2];
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) s[kb][i] = 0.f;
-    KLOAD(0); KLOAD(1); KLOAD(2); KLOAD(3);
-    SB();
-#pragma unroll
-    for (int i = 0; i < NS; ++i) {         // key block i & 1, k-step i >> 1 (alternating accumulation chains)
-      s[i & 1] = mfma32_f16(fr[i & 7], qf[i >> 1], s[i & 1]);
-      if (i + 4 < NS) { KLOAD(i + 4); } else { VLOAD(i + 4 - NS); }
-      SB();
-    }
-
-    float mx = -1e30f;
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) mx = fmaxf(mx, s[kb][i]);
-    mx *= p.c;
-    mx = half_swap_max(mx);
-    if (__any(mx - m_run > RESCALE_THR)) {
-      const float m_new = fmaxf(m_run, mx);
-      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-      m_run = m_new;
-      l_run *= alpha;
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) o[dt][i] *= alpha;
-    }
-    float rs = 0.f;
-    half8 pf[4];
-#define PEXP(c_, e_)                                                                             \
-  {                                                                                              \
-    const float pv_ = __builtin_amdgcn_exp2f(fmaf(s[(c_) >> 1][8 * ((c_) & 1) + (e_)], p.c, -m_run)); \
-    rs += pv_;                                                                                   \
-    pf[c_][e_] = (_Float16)pv_;                                                                  \
-  }
-#pragma unroll
-    for (int e = 0; e < 8; ++e) PEXP(0, e)
-    SB();
-#pragma unroll
-    for (int j = 0; j < NP; ++j) {         // key chunk c = j >> 2 outer, this wave's 4 d-tiles inner
-      const int c = j >> 2, dt = j & 3;
-      o[dt] = mfma32_f16(fr[j & 7], pf[c], o[dt]);
-      if (j + 4 < NP) VLOAD(j + 4);
-      if (c < 3) {
-        PEXP(c + 1, 2 * dt)
-        PEXP(c + 1, 2 * dt + 1)
-      }
-      SB();
-    }
-    l_run += rs;
-
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    cur ^= 1;
-  }
-#undef DS_ISSUE
-#undef SB
-#undef KLOAD
-#undef VLOAD
-#undef PEXP
-
-  const float l_tot = l_run + __shfl_xor(l_run, 32);
-  const float inv = 1.f / l_tot;
-  const int qglob = qb * 128 + qw * 32 + r;
-  if (qglob < p.tq) {
-    _Float16* op = p.O + b * p.sO + (size_t)qglob * p.ldo + (size_t)head * D + 128 * dh;
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-      for (int g4 = 0; g4 < 4; ++g4) {
-        half4 v;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = (_Float16)(o[dt][4 * g4 + j] * inv);
-        *(half4*)(op + 32 * dt + 8 * g4 + 4 * h) = v;
-      }
-  }
-}
+#ifdef DVD_LAB
+#include "../../benchmarks/lab/csrc/attention_lab.inc"
+#endif
 
 }  // namespace dvd
 
 using namespace dvd;
 
+#ifdef DVD_LAB
 static unsigned long long* g_attn_stamps = nullptr;
-// diagnostic builds only (DVD_ATTN_DEBUG=1): per-wave accumulated s_memtime deltas of the 5 phases of a KV tile
+// lab builds only (DVD_ATTN_DEBUG=1): per-wave accumulated s_memtime deltas of the 5 phases of a KV tile
 extern "C" int dvd_attn_debug_stamps(void* dev_u64) { g_attn_stamps = (unsigned long long*)dev_u64; return DVD_OK; }
+#endif
+
+// 64 query rows per wave (256 per workgroup) from this many query rows on: a (batch, head) then has >= 22 workgroups of
+// its own.  The choice depends on the problem's SHAPE only (head_dim, tq, tk) - never on the batch - so a document
+// takes the same kernel, and the same online-softmax tile order, alone or in a batch (bit-identical results).
+static constexpr int R64_MIN_TQ = 5376;
+
+extern "C" const char* dvd_flash_attn_kernel_name(int head_dim, int tq, int tk) {
+  if (head_dim != 64 && head_dim != 256) return "";
+  if (tk % 64 != 0) return head_dim == 256 ? "flash_attn_kernel<256>" : "flash_attn_kernel<64>";
+  if (head_dim == 256) return tq >= R64_MIN_TQ ? "flash_attn_r64_kernel<0>" : "flash_attn_glds_kernel<256, 0>";
+  return "flash_attn_glds_kernel<64, 0>";
+}
+
+template <typename KernelT>
+static void allow_lds(KernelT kernel, int bytes) {
+  (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}
 
 extern "C" int dvd_flash_attn(const dvd_attn_desc* d, void* stream) {
   DVD_REQUIRE(d && d->Q && d->K && d->Vt && d->O, "flash_attn: null pointer");
@@ -1498,84 +889,87 @@ extern "C" int dvd_flash_attn(const dvd_attn_desc* d, void* stream) {
   p.kv_div = d->kv_batch_div;
   p.nqb = cdiv(d->tq, 128);
   p.c = d->scale * 1.4426950408889634f;
-  p.stamps = g_attn_stamps;
+  p.stamps = nullptr;
   const long nwg = (long)p.nqb * d->heads * d->batch;
   DVD_REQUIRE(nwg < (1l << 31), "flash_attn: grid too large");
-  const bool fast = (d->tk % 64 == 0) && !getenv("DVD_ATTN_V1");
-  if (fast && d->head_dim == 256 && getenv("DVD_ATTN_DSPLIT")) {   // measured slower (732 vs 812 TF/s): opt-in only
+  hipStream_t st = (hipStream_t)stream;
+  bool fast = d->tk % 64 == 0;      // the LDS-DMA kernels stream whole 64-key tiles; ragged key counts take the
+                                    // register-staged kernel (masked tail)
+  bool r64 = d->head_dim == 256 && d->tq >= R64_MIN_TQ;
+  static bool attr_done = false;
+  if (!attr_done) {
+    allow_lds(flash_attn_glds_kernel<256, 0>, 2 * (64 * 512 + 256 * 128));
+    allow_lds(flash_attn_r64_kernel<0>, 2 * (32 * 512 + 256 * 64));
+    allow_lds(flash_attn_kernel<256>, 2 * (64 * (2 * 256 + 16) + 256 * (2 * 64 + 16)));
+    attr_done = true;
+  }
+#ifdef DVD_LAB
+  // ---- lab build: every experiment and diagnostic variant behind its environment switch ----
+  p.stamps = g_attn_stamps;
+  const bool dbg = getenv("DVD_ATTN_DEBUG"), bulk = getenv("DVD_ATTN_BULK");
+  if (getenv("DVD_ATTN_V1")) fast = false;
+  if (getenv("DVD_ATTN_R64")) r64 = d->head_dim == 256;
+  if (getenv("DVD_ATTN_R32") || getenv("DVD_ATTN_PIPE") || bulk) r64 = false;
+  static bool lab_attr_done = false;
+  if (!lab_attr_done) {
     constexpr int LDS = 2 * (64 * 512 + 256 * 128);
-    static bool once3 = false;
-    if (!once3) {
-      (void)hipFuncSetAttribute((const void*)flash_attn_dsplit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-      once3 = true;
-    }
-    flash_attn_dsplit_kernel<<<(unsigned)nwg, 512, LDS, (hipStream_t)stream>>>(p);
-  } else if (fast && d->head_dim == 256) {
+    allow_lds(flash_attn_dsplit_kernel, LDS);
+    allow_lds(flash_attn_glds_kernel<256, 1>, LDS);
+    allow_lds(flash_attn_glds_kernel<256, 2>, LDS);
+    allow_lds(flash_attn_glds_kernel<256, 3>, LDS);
+    allow_lds(flash_attn_pipe_kernel<0>, LDS);
+    allow_lds(flash_attn_pipe_kernel<1>, LDS);
+    allow_lds(flash_attn_r64_kernel<1>, 2 * (32 * 512 + 256 * 64));
+    lab_attr_done = true;
+  }
+  if (fast && d->head_dim == 256) {
     constexpr int LDS = 2 * (64 * 512 + 256 * 128);
-    static bool once2 = false;
-    if (!once2) {
-      (void)hipFuncSetAttribute((const void*)flash_attn_glds_kernel<256, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-      (void)hipFuncSetAttribute((const void*)flash_attn_glds_kernel<256, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-      (void)hipFuncSetAttribute((const void*)flash_attn_glds_kernel<256, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-      (void)hipFuncSetAttribute((const void*)flash_attn_glds_kernel<256, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-      once2 = true;
+    if (getenv("DVD_ATTN_DSPLIT")) {   // measured slower (732 vs 812 TF/s)
+      flash_attn_dsplit_kernel<<<(unsigned)nwg, 512, LDS, st>>>(p);
+      return check_launch("flash_attn(lab dsplit)");
     }
-    // 64 query rows per wave (256 per workgroup) when that still fills the chip at least twice over; small problems
-    // keep the 128-row workgroups.  DVD_ATTN_R32=1 forces the 32-row kernel (A/B runs).
-    const long wg256 = (long)cdiv(d->tq, 256) * d->heads * d->batch;
-    if ((wg256 >= 512 || getenv("DVD_ATTN_R64")) && !getenv("DVD_ATTN_R32") && !getenv("DVD_ATTN_PIPE") &&
-        !getenv("DVD_ATTN_BULK")) {
-      constexpr int LDS64 = 2 * (32 * 512 + 256 * 64);
-      static bool once5 = false;
-      if (!once5) {
-        (void)hipFuncSetAttribute((const void*)flash_attn_r64_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS64);
-        (void)hipFuncSetAttribute((const void*)flash_attn_r64_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS64);
-        once5 = true;
-      }
-      const long nqb2 = cdiv(d->tq, 256);
-      p.nqb = (int)nqb2;
-      const unsigned g = (unsigned)(nqb2 * d->heads * d->batch);
-      if (getenv("DVD_ATTN_DEBUG")) flash_attn_r64_kernel<1><<<g, 256, LDS64, (hipStream_t)stream>>>(p);
-      else flash_attn_r64_kernel<0><<<g, 256, LDS64, (hipStream_t)stream>>>(p);
-      return check_launch("flash_attn");
+    if (r64 && dbg) {
+      p.nqb = cdiv(d->tq, 256);
+      flash_attn_r64_kernel<1><<<(unsigned)((long)p.nqb * d->heads * d->batch), 256, 2 * (32 * 512 + 256 * 64), st>>>(p);
+      return check_launch("flash_attn(lab r64 stamps)");
     }
-    static bool once4 = false;
-    if (!once4) {
-      (void)hipFuncSetAttribute((const void*)flash_attn_pipe_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-      (void)hipFuncSetAttribute((const void*)flash_attn_pipe_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-      once4 = true;
+    if (!r64 && getenv("DVD_ATTN_PIPE")) {   // slower (830 vs 975 TF/s): see the kernel's header
+      if (dbg) flash_attn_pipe_kernel<1><<<(unsigned)nwg, 256, LDS, st>>>(p);
+      else flash_attn_pipe_kernel<0><<<(unsigned)nwg, 256, LDS, st>>>(p);
+      return check_launch("flash_attn(lab pipe)");
     }
-    if (getenv("DVD_ATTN_PIPE")) {   // EXPERIMENT, slower (830 vs 975 TF/s): see the kernel's header
-      if (getenv("DVD_ATTN_DEBUG")) flash_attn_pipe_kernel<1><<<(unsigned)nwg, 256, LDS, (hipStream_t)stream>>>(p);
-      else flash_attn_pipe_kernel<0><<<(unsigned)nwg, 256, LDS, (hipStream_t)stream>>>(p);
-      return check_launch("flash_attn");
+    if (!r64 && (dbg || bulk)) {
+      if (dbg && bulk) flash_attn_glds_kernel<256, 3><<<(unsigned)nwg, 256, LDS, st>>>(p);
+      else if (bulk) flash_attn_glds_kernel<256, 2><<<(unsigned)nwg, 256, LDS, st>>>(p);
+      else flash_attn_glds_kernel<256, 1><<<(unsigned)nwg, 256, LDS, st>>>(p);
+      return check_launch("flash_attn(lab glds variant)");
     }
-    const int variant = (getenv("DVD_ATTN_DEBUG") ? 1 : 0) | (getenv("DVD_ATTN_BULK") ? 2 : 0);
-    if (variant == 3) flash_attn_glds_kernel<256, 3><<<(unsigned)nwg, 256, LDS, (hipStream_t)stream>>>(p);
-    else if (variant == 2) flash_attn_glds_kernel<256, 2><<<(unsigned)nwg, 256, LDS, (hipStream_t)stream>>>(p);
-    else if (variant == 1) flash_attn_glds_kernel<256, 1><<<(unsigned)nwg, 256, LDS, (hipStream_t)stream>>>(p);
-    else flash_attn_glds_kernel<256, 0><<<(unsigned)nwg, 256, LDS, (hipStream_t)stream>>>(p);
-  } else if (fast && getenv("DVD_ATTN_64X2")) {   // head_dim 64, two query row blocks per wave: measured = (872 vs 895 TF/s)
-    constexpr int LDS = 2 * (64 * 128 + 64 * 128);
-    const long nqb2 = cdiv(d->tq, 256);
-    p.nqb = (int)nqb2;
-    flash_attn_glds64x2_kernel<<<(unsigned)(nqb2 * d->heads * d->batch), 256, LDS, (hipStream_t)stream>>>(p);
   } else if (fast) {
     constexpr int LDS = 2 * (64 * 128 + 64 * 128);
-    if (getenv("DVD_ATTN_DEBUG")) flash_attn_glds_kernel<64, 1><<<(unsigned)nwg, 256, LDS, (hipStream_t)stream>>>(p);
-    else if (getenv("DVD_ATTN_BULK")) flash_attn_glds_kernel<64, 2><<<(unsigned)nwg, 256, LDS, (hipStream_t)stream>>>(p);
-    else flash_attn_glds_kernel<64, 0><<<(unsigned)nwg, 256, LDS, (hipStream_t)stream>>>(p);
-  } else if (d->head_dim == 256) {
-    constexpr int LDS = 2 * (64 * (2 * 256 + 16) + 256 * (2 * 64 + 16));
-    static bool once = false;
-    if (!once) {
-      (void)hipFuncSetAttribute((const void*)flash_attn_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-      once = true;
+    if (getenv("DVD_ATTN_64X2")) {   // head_dim 64, two query row blocks per wave: measured = (872 vs 895 TF/s)
+      p.nqb = cdiv(d->tq, 256);
+      flash_attn_glds64x2_kernel<<<(unsigned)((long)p.nqb * d->heads * d->batch), 256, LDS, st>>>(p);
+      return check_launch("flash_attn(lab 64x2)");
     }
-    flash_attn_kernel<256><<<(unsigned)nwg, 256, LDS, (hipStream_t)stream>>>(p);
+    if (dbg || bulk) {
+      if (dbg) flash_attn_glds_kernel<64, 1><<<(unsigned)nwg, 256, LDS, st>>>(p);
+      else flash_attn_glds_kernel<64, 2><<<(unsigned)nwg, 256, LDS, st>>>(p);
+      return check_launch("flash_attn(lab glds64 variant)");
+    }
+  }
+#endif
+  // ---- product dispatch: four kernels, chosen by (head_dim, tq, tk) ----
+  if (fast && r64) {
+    p.nqb = cdiv(d->tq, 256);
+    flash_attn_r64_kernel<0><<<(unsigned)((long)p.nqb * d->heads * d->batch), 256, 2 * (32 * 512 + 256 * 64), st>>>(p);
+  } else if (fast && d->head_dim == 256) {
+    flash_attn_glds_kernel<256, 0><<<(unsigned)nwg, 256, 2 * (64 * 512 + 256 * 128), st>>>(p);
+  } else if (fast) {
+    flash_attn_glds_kernel<64, 0><<<(unsigned)nwg, 256, 2 * (64 * 128 + 64 * 128), st>>>(p);
+  } else if (d->head_dim == 256) {
+    flash_attn_kernel<256><<<(unsigned)nwg, 256, 2 * (64 * (2 * 256 + 16) + 256 * (2 * 64 + 16)), st>>>(p);
   } else {
-    constexpr int LDS = 2 * (64 * (2 * 64 + 16) + 64 * (2 * 64 + 16));
-    flash_attn_kernel<64><<<(unsigned)nwg, 256, LDS, (hipStream_t)stream>>>(p);
+    flash_attn_kernel<64><<<(unsigned)nwg, 256, 2 * (64 * (2 * 64 + 16) + 64 * (2 * 64 + 16)), st>>>(p);
   }
   return check_launch("flash_attn");
 }

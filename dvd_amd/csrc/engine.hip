@@ -95,9 +95,50 @@ static std::vector<TensorSpec> tensor_specs(int G) {
   return v;
 }
 
+// Every weight tensor and workspace buffer the step touches is addressed by an INDEX resolved once, in
+// dvd_engine_create: no string is built, hashed or compared on the launch path.
+#define DVD_W_LIST(X)                                                                                              \
+  X(obs_w) X(obs_b) X(pos) X(r_w16) X(r_b) X(c_w) X(c_b) X(m_w) X(m_b) X(l_w) X(l_b) X(t_w0) X(t_b0) X(t_w2) X(t_b2) \
+  X(ada_w) X(ada_b) X(ca_wq16) X(ca_bq) X(ca_wk16) X(ca_bk) X(ca_wv16) X(ca_bv) X(ca_wk32) X(ca_wv32) X(ca_wo16)   \
+  X(ca_bo) X(sa_wqk16) X(sa_bqk) X(sa_wv16) X(sa_bv) X(sa_wp16) X(sa_bp) X(fc1_w16) X(fc1_b) X(fc2_w16) X(fc2_b)   \
+  X(pe_h0_w) X(pe_h0_b) X(pe_h2_w) X(pe_h2_b) X(pe_w0_w) X(pe_w0_b) X(pe_w2_w) X(pe_w2_b) X(pe_htab) X(pe_wtab)    \
+  X(dec_nw) X(dec_nb) X(fin_ada_w) X(fin_ada_b) X(fin_w) X(fin_b)
+#define DVD_WD_LIST(X) \
+  X(n1w) X(n1b) X(wqk16) X(wv16) X(wfc16) X(n2w) X(n2b) X(c1w16) X(c1b) X(dww) X(dwb) X(c2w16) X(c2b)
+#define DVD_B_LIST(X)                                                                                              \
+  X(feat) X(kc16) X(km16) X(kl16) X(vtc16) X(vtm16) X(vtl16) X(tbuf) X(th) X(cvec) X(mod) X(finmod) X(pooled)      \
+  X(petmp) X(hs) X(wsc) X(part) X(xtok32) X(xq16) X(arows16) X(rtok16) X(q16) X(kr16) X(vtr16) X(att16) X(z) X(h16) \
+  X(qk16) X(vt16) X(mlp16) X(p_cat4) X(p_col) X(p_actA) X(p_actB) X(p_rows) X(p_tok32)
+
+struct WIdx {
+#define X(n) int n = -1;
+  DVD_W_LIST(X)
+  struct Dec { DVD_WD_LIST(X) } d[6];
+#undef X
+  int pyr_w[7], pyr_b[7];
+};
+struct BIdx {
+#define X(n) int n = -1;
+  DVD_B_LIST(X)
+#undef X
+};
+
 struct Buf {
   std::string name;
   size_t off, bytes;
+};
+
+struct GraphKey {
+  int feat_mode;
+  const void *x_t, *init_flow, *init_feat, *x0_out;
+  bool operator==(const GraphKey& o) const {
+    return feat_mode == o.feat_mode && x_t == o.x_t && init_flow == o.init_flow && init_feat == o.init_feat &&
+           x0_out == o.x0_out;
+  }
+};
+struct GraphEntry {
+  GraphKey key;
+  hipGraphExec_t exec;   // nullptr: the key has been run eagerly once (lazy one-time initialisation done), not yet captured
 };
 
 struct Engine {
@@ -108,33 +149,79 @@ struct Engine {
   char* ws = nullptr;
   size_t ws_bytes = 0, need_bytes = 0;
   std::vector<Buf> bufs;
+  WIdx wi;
+  BIdx bi;
   bool prepared = false;
+  // ---- options (dvd_engine_set_option; fixed for the life of a captured graph) ----
   bool split_weights = true;   // use the lo parts (fp32-grade weights, 2x GEMM MFMAs)
-  // optional per-launch timing of the dominant kernel (decoder attention) with HIP events on the launch stream
+  bool use_graphs = false;     // replay a denoiser evaluation as one hipGraph (launch-bound small grids)
+  // optional per-launch timing of the dominant kernel (decoder attention) with HIP events on the launch stream:
+  // a ring of event pairs, drained into running totals when it wraps, so EVERY launch of the timed region counts
   bool prof_on = false;
   std::vector<hipEvent_t> prof_ev;
-  size_t prof_used = 0;
+  size_t prof_head = 0, prof_inflight = 0;   // pairs
+  double prof_total_ms = 0.0;
+  long prof_count = 0;
   int debug_stop = 0;  // parity tests: return from denoise_step after stage k (0 = run everything)
+  // hipGraph cache of denoiser evaluations, keyed by what a captured launch sequence bakes in
+  std::vector<GraphEntry> graphs;
+  hipStream_t cap_stream = nullptr;
 
-  const void* W(const char* name) const {
+  const float* F(int i) const { return (const float*)wptr[i]; }
+  const void* H(int i) const { return wptr[i]; }
+  const void* L(int i) const { return split_weights ? wptr[i + 1] : nullptr; }   // (hi, lo) pairs are adjacent
+  char* B(int i) const { return ws + bufs[i].off; }
+  int find_w(const std::string& name) const {
     for (size_t i = 0; i < specs.size(); ++i)
-      if (specs[i].name == name) return wptr[i];
-    return nullptr;
+      if (specs[i].name == name) return (int)i;
+    return -1;
   }
-  const float* Wf(const std::string& n) const { return (const float*)W(n.c_str()); }
-  const void* Wh(const std::string& n) const { return W(n.c_str()); }
-  const void* Wl(const std::string& n) const { return split_weights ? W((n + "_lo").c_str()) : nullptr; }
-  char* B(const char* name) const {
-    for (auto& b : bufs)
-      if (b.name == name) return ws + b.off;
-    return nullptr;
+  int find_b(const std::string& name) const {
+    for (size_t i = 0; i < bufs.size(); ++i)
+      if (bufs[i].name == name) return (int)i;
+    return -1;
   }
-  long Bn(const char* name) const {
-    for (auto& b : bufs)
-      if (b.name == name) return (long)b.bytes;
-    return 0;
+  void drop_graphs() {
+    for (auto& g : graphs)
+      if (g.exec) (void)hipGraphExecDestroy(g.exec);
+    graphs.clear();
   }
 };
+
+static const int PROF_PAIRS = 4096;
+
+static int prof_drain_one(Engine* e) {
+  float ms = 0.f;
+  hipEvent_t a = e->prof_ev[2 * e->prof_head], b = e->prof_ev[2 * e->prof_head + 1];
+  if (hipEventSynchronize(b) != hipSuccess || hipEventElapsedTime(&ms, a, b) != hipSuccess) {
+    set_error("engine_profile: event query failed");
+    return DVD_E_LAUNCH;
+  }
+  e->prof_total_ms += ms; e->prof_count += 1;
+  e->prof_head = (e->prof_head + 1) % PROF_PAIRS; e->prof_inflight -= 1;
+  return DVD_OK;
+}
+
+static bool resolve_indices(Engine* e) {
+  bool ok = true;
+#define X(n) ok = ok && (e->wi.n = e->find_w(#n)) >= 0;
+  DVD_W_LIST(X)
+#undef X
+  for (int j = 0; j < 6; ++j) {
+    const std::string p = "d" + std::to_string(j) + "_";
+#define X(n) ok = ok && (e->wi.d[j].n = e->find_w(p + #n)) >= 0;
+    DVD_WD_LIST(X)
+#undef X
+  }
+  for (int i = 0; i < 7; ++i) {
+    ok = ok && (e->wi.pyr_w[i] = e->find_w("pyr" + std::to_string(i) + "_w")) >= 0;
+    ok = ok && (e->wi.pyr_b[i] = e->find_w("pyr" + std::to_string(i) + "_b")) >= 0;
+  }
+#define X(n) ok = ok && (e->bi.n = e->find_b(#n)) >= 0;
+  DVD_B_LIST(X)
+#undef X
+  return ok;
+}
 
 static void plan(Engine* e) {
   size_t off = 0;
@@ -223,12 +310,22 @@ extern "C" int dvd_engine_create(int grid, int docs, int n_hyp, void** handle) {
   e->specs = tensor_specs(grid);
   e->wptr.assign(e->specs.size(), nullptr);
   plan(e);
+  if (!resolve_indices(e)) {
+    delete e;
+    set_error("engine_create: internal tensor/buffer table mismatch");
+    return DVD_E_STATE;
+  }
   *handle = e;
   return DVD_OK;
 }
 
 extern "C" int dvd_engine_destroy(void* handle) {
-  delete (Engine*)handle;
+  Engine* e = (Engine*)handle;
+  if (!e) return DVD_OK;
+  e->drop_graphs();
+  if (e->cap_stream) (void)hipStreamDestroy(e->cap_stream);
+  for (auto& ev : e->prof_ev) (void)hipEventDestroy(ev);
+  delete e;
   return DVD_OK;
 }
 
@@ -240,6 +337,7 @@ extern "C" int dvd_engine_bind_workspace(void* handle, void* ws, long bytes) {
   DVD_REQUIRE((size_t)bytes >= e->need_bytes && ((uintptr_t)ws % 256) == 0,
               "engine_bind_workspace: need %zu bytes, 256-byte aligned (got %ld)", e->need_bytes, bytes);
   e->ws = (char*)ws; e->ws_bytes = bytes; e->prepared = false;
+  e->drop_graphs();   // captured launches bake the workspace addresses in
   return DVD_OK;
 }
 
@@ -261,6 +359,7 @@ extern "C" int dvd_engine_set_tensor(void* handle, const char* name, const void*
       DVD_REQUIRE(e->specs[i].nelem == nelem, "engine_set_tensor: %s expects %ld elements, got %ld", name,
                   e->specs[i].nelem, nelem);
       DVD_REQUIRE(((uintptr_t)dev_ptr % 16) == 0, "engine_set_tensor: %s must be 16-byte aligned", name);
+      if (e->wptr[i] != dev_ptr) e->drop_graphs();   // captured launches bake the weight addresses in
       e->wptr[i] = dev_ptr;
       return DVD_OK;
     }
@@ -272,36 +371,33 @@ extern "C" int dvd_engine_profile(void* handle, int enable) {
   DVD_REQUIRE(handle, "engine_profile: null handle");
   Engine* e = (Engine*)handle;
   if (enable && e->prof_ev.empty()) {
-    e->prof_ev.resize(2 * 4096);
+    e->prof_ev.resize(2 * PROF_PAIRS);
     for (auto& ev : e->prof_ev)
       if (hipEventCreate(&ev) != hipSuccess) { set_error("engine_profile: hipEventCreate failed"); return DVD_E_LAUNCH; }
   }
   e->prof_on = enable != 0;
-  e->prof_used = 0;
+  e->prof_head = 0; e->prof_inflight = 0; e->prof_total_ms = 0.0; e->prof_count = 0;
   return DVD_OK;
 }
 
 extern "C" int dvd_engine_profile_read(void* handle, int* launches, double* total_ms) {
   DVD_REQUIRE(handle && launches && total_ms, "engine_profile_read: null pointer");
   Engine* e = (Engine*)handle;
-  *launches = 0; *total_ms = 0.0;
-  for (size_t i = 0; i + 1 < e->prof_used; i += 2) {
-    float ms = 0.f;
-    if (hipEventSynchronize(e->prof_ev[i + 1]) != hipSuccess ||
-        hipEventElapsedTime(&ms, e->prof_ev[i], e->prof_ev[i + 1]) != hipSuccess) {
-      set_error("engine_profile_read: event query failed");
-      return DVD_E_LAUNCH;
-    }
-    *total_ms += ms; *launches += 1;
-  }
-  e->prof_used = 0;
+  while (e->prof_inflight) TRY(prof_drain_one(e));
+  *launches = (int)e->prof_count; *total_ms = e->prof_total_ms;
+  e->prof_total_ms = 0.0; e->prof_count = 0;
   return DVD_OK;
 }
 
 extern "C" int dvd_engine_set_option(void* handle, const char* name, int value) {
   DVD_REQUIRE(handle && name, "engine_set_option: null pointer");
   Engine* e = (Engine*)handle;
-  if (strcmp(name, "split_weights") == 0) { e->split_weights = value != 0; return DVD_OK; }
+  if (strcmp(name, "split_weights") == 0) { e->split_weights = value != 0; e->drop_graphs(); return DVD_OK; }
+  if (strcmp(name, "graphs") == 0) {
+    e->use_graphs = value != 0;
+    if (!e->use_graphs) e->drop_graphs();
+    return DVD_OK;
+  }
   set_error("engine_set_option: unknown option '%s'", name);
   return DVD_E_ARG;
 }
@@ -316,8 +412,9 @@ extern "C" int dvd_engine_debug_buffer(void* handle, const char* name, void** pt
   DVD_REQUIRE(handle && name && ptr && bytes, "engine_debug_buffer: null pointer");
   Engine* e = (Engine*)handle;
   DVD_REQUIRE(e->ws, "engine_debug_buffer: no workspace bound");
-  *ptr = e->B(name); *bytes = e->Bn(name);
-  DVD_REQUIRE(*ptr, "engine_debug_buffer: unknown buffer '%s'", name);
+  const int i = e->find_b(name);
+  DVD_REQUIRE(i >= 0, "engine_debug_buffer: unknown buffer '%s'", name);
+  *ptr = e->B(i); *bytes = (long)e->bufs[i].bytes;
   return DVD_OK;
 }
 
@@ -341,13 +438,13 @@ extern "C" int dvd_engine_prepare_docs(void* handle, const float* y512, const fl
   hipStream_t st = (hipStream_t)stream;
   const int G = e->G;
   const long T = e->T;
-  float* cat4 = (float*)e->B("p_cat4");
-  float* col = (float*)e->B("p_col");
-  float* actA = (float*)e->B("p_actA");
-  float* actB = (float*)e->B("p_actB");
-  float* rows = (float*)e->B("p_rows");
-  float* tok32 = (float*)e->B("p_tok32");
-  const float* pos = e->Wf("pos");
+  float* cat4 = (float*)e->B(e->bi.p_cat4);
+  float* col = (float*)e->B(e->bi.p_col);
+  float* actA = (float*)e->B(e->bi.p_actA);
+  float* actB = (float*)e->B(e->bi.p_actB);
+  float* rows = (float*)e->B(e->bi.p_rows);
+  float* tok32 = (float*)e->B(e->bi.p_tok32);
+  const float* pos = e->F(e->wi.pos);
   for (int d = 0; d < e->docs; ++d) {
     // cat([y512, mask_cat], dim=1)  (:586-587)
     if (hipMemcpyAsync(cat4, y512 + (size_t)d * 3 * 512 * 512, (size_t)3 * 512 * 512 * 4, hipMemcpyDeviceToDevice, st) != hipSuccess ||
@@ -366,11 +463,10 @@ extern "C" int dvd_engine_prepare_docs(void* handle, const float* y512, const fl
     for (const L& l : layers) {
       const int cin = PYR_CIN[l.idx], cout = PYR_COUT[l.idx], kp = pyr_kpad(l.idx);
       TRY(dvd_im2col3x3(cur, sc, sy, sx, col, kp, cin, l.hw, l.hw, stream));
-      const std::string wn = "pyr" + std::to_string(l.idx);
       float* outp = act[wi];
       wi ^= 1;
-      TRY(gemm(1, l.hw * l.hw, cout, kp, 1, col, kp, 0, e->Wf(wn + "_w"), kp, 0, outp, cout, 0, nullptr, 0, 0,
-               e->Wf(wn + "_b"), 0, /*relu*/ 2, nullptr, 0, nullptr, 0, nullptr, 0, 0, stream));
+      TRY(gemm(1, l.hw * l.hw, cout, kp, 1, col, kp, 0, e->F(e->wi.pyr_w[l.idx]), kp, 0, outp, cout, 0, nullptr, 0, 0,
+               e->F(e->wi.pyr_b[l.idx]), 0, /*relu*/ 2, nullptr, 0, nullptr, 0, nullptr, 0, 0, stream));
       int hw = l.hw;
       if (l.pool) {
         TRY(dvd_maxpool2_nhwc(outp, act[wi], cout, hw, hw, stream));
@@ -382,7 +478,7 @@ extern "C" int dvd_engine_prepare_docs(void* handle, const float* y512, const fl
       sc = 1; sy = (long)hw * cout; sx = cout;
     }
     // cur = level_3 output [64,64,256]; resize to the coordinate grid (:590-593 generalised)
-    float* feat = (float*)e->B("feat") + (size_t)d * G * G * 256;
+    float* feat = (float*)e->B(e->bi.feat) + (size_t)d * G * G * 256;
     if (G == 64) {
       if (hipMemcpyAsync(feat, cur, (size_t)64 * 64 * 256 * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) {
         set_error("engine_prepare_docs: device copy failed");
@@ -392,22 +488,24 @@ extern "C" int dvd_engine_prepare_docs(void* handle, const float* y512, const fl
       TRY(dvd_resize_bilinear_nhwc(cur, feat, 256, 64, 64, G, G, stream));
     }
     // c / m / l patch embeddings (+pos) and their K / V^T projections (shared cross_attn weights)
-    struct S { const float* src; long sn, sc, sy, sx; int c; const char* w; const char* b; const char* k16; const char* vt16; };
+    struct S { const float* src; long sn, sc, sy, sx; int c; int w, b, k16, vt16; };
+    const WIdx& wx = e->wi;
+    const BIdx& bx = e->bi;
     const S streams[3] = {
-        {feat, 0, 1, (long)G * 256, 256, 256, "c_w", "c_b", "kc16", "vtc16"},
-        {mask_y512 + (size_t)d * 384 * G * G, 0, (long)G * G, G, 1, 384, "m_w", "m_b", "km16", "vtm16"},
-        {line_msk + (size_t)d * 64 * G * G, 0, (long)G * G, G, 1, 64, "l_w", "l_b", "kl16", "vtl16"}};
+        {feat, 0, 1, (long)G * 256, 256, 256, wx.c_w, wx.c_b, bx.kc16, bx.vtc16},
+        {mask_y512 + (size_t)d * 384 * G * G, 0, (long)G * G, G, 1, 384, wx.m_w, wx.m_b, bx.km16, bx.vtm16},
+        {line_msk + (size_t)d * 64 * G * G, 0, (long)G * G, G, 1, 64, wx.l_w, wx.l_b, bx.kl16, bx.vtl16}};
     for (const S& s : streams) {
       const int K4 = 4 * s.c;
       TRY(dvd_patch_rows(s.src, s.sn, s.sc, s.sy, s.sx, rows, K4, 1, s.c, G, stream));
-      TRY(gemm(1, (int)T, HID, K4, 1, rows, K4, 0, e->Wf(s.w), K4, 0, tok32, HID, 0, nullptr, 0, 0, e->Wf(s.b), 0, 0,
+      TRY(gemm(1, (int)T, HID, K4, 1, rows, K4, 0, e->F(s.w), K4, 0, tok32, HID, 0, nullptr, 0, 0, e->F(s.b), 0, 0,
                pos, (int)T, nullptr, 0, nullptr, 0, 0, stream));
       _Float16* k16 = (_Float16*)e->B(s.k16) + (size_t)d * T * HID;
       _Float16* vt16 = (_Float16*)e->B(s.vt16) + (size_t)d * T * HID;
-      TRY(gemm(1, (int)T, HID, HID, 1, tok32, HID, 0, e->Wf("ca_wk32"), HID, 0, nullptr, 0, 0, k16, HID, 0,
-               e->Wf("ca_bk"), 0, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0, stream));
-      TRY(gemm(1, HID, (int)T, HID, 1, e->Wf("ca_wv32"), HID, 0, tok32, HID, 0, nullptr, 0, 0, vt16, (int)T, 0,
-               e->Wf("ca_bv"), 1, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0, stream));
+      TRY(gemm(1, (int)T, HID, HID, 1, tok32, HID, 0, e->F(e->wi.ca_wk32), HID, 0, nullptr, 0, 0, k16, HID, 0,
+               e->F(e->wi.ca_bk), 0, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0, stream));
+      TRY(gemm(1, HID, (int)T, HID, 1, e->F(e->wi.ca_wv32), HID, 0, tok32, HID, 0, nullptr, 0, 0, vt16, (int)T, 0,
+               e->F(e->wi.ca_bv), 1, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0, stream));
     }
   }
   e->prepared = true;
@@ -419,7 +517,7 @@ extern "C" int dvd_engine_feat_nchw(void* handle, float* out, void* stream) {
   Engine* e = (Engine*)handle;
   TRY(require_ready(e, true));
   for (int d = 0; d < e->docs; ++d)
-    TRY(dvd_nhwc_to_nchw((const float*)e->B("feat") + (size_t)d * e->G * e->G * 256,
+    TRY(dvd_nhwc_to_nchw((const float*)e->B(e->bi.feat) + (size_t)d * e->G * e->G * 256,
                          out + (size_t)d * 256 * e->G * e->G, 256, e->G, e->G, stream));
   return DVD_OK;
 }
@@ -431,6 +529,143 @@ extern "C" int dvd_engine_feat_nchw(void* handle, float* out, void* stream) {
 //   (t_model > 600, :597-598), 2 -> init_feat = grid_sample(feat, (init_flow + base)*2-1)
 //   (idf/gaussian_diffusion.py:618-624), 0 -> init_feat = 0, 3 -> init_feat_nchw [N,256,G,G] given explicitly.
 // ------------------------------------------------------------------------------------------------
+// The launch sequence of one evaluation.  The embedded timestep is read from `tbuf` (written by the caller before this
+// sequence), so the sequence depends on (feat_mode, the four I/O pointers) only and can be captured into a hipGraph.
+static int enqueue_step(Engine* e, const float* x_t, int feat_mode, const float* init_flow,
+                        const float* init_feat_nchw, float* x0_out, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  const int G = e->G, N = e->N, side = e->side, hyp = e->hyp;
+  const int T = (int)e->T;
+  const long NT = e->NT;
+
+  float* tbuf = (float*)e->B(e->bi.tbuf);
+  float* th = (float*)e->B(e->bi.th);
+  float* cvec = (float*)e->B(e->bi.cvec);
+  float* mod = (float*)e->B(e->bi.mod);
+  float* finmod = (float*)e->B(e->bi.finmod);
+  float* xtok32 = (float*)e->B(e->bi.xtok32);
+  _Float16* xq16 = (_Float16*)e->B(e->bi.xq16);
+  _Float16* arows16 = (_Float16*)e->B(e->bi.arows16);
+  _Float16* rtok16 = (_Float16*)e->B(e->bi.rtok16);
+  _Float16* q16 = (_Float16*)e->B(e->bi.q16);
+  _Float16* kr16 = (_Float16*)e->B(e->bi.kr16);
+  _Float16* vtr16 = (_Float16*)e->B(e->bi.vtr16);
+  _Float16* att16 = (_Float16*)e->B(e->bi.att16);
+  float* z = (float*)e->B(e->bi.z);
+  _Float16* h16 = (_Float16*)e->B(e->bi.h16);
+  _Float16* qk16 = (_Float16*)e->B(e->bi.qk16);
+  _Float16* vt16 = (_Float16*)e->B(e->bi.vt16);
+  _Float16* mlp16 = (_Float16*)e->B(e->bi.mlp16);
+
+  // --- timestep embedding and the two adaLN tables (one row: t is batch-global in sampling) ---
+  TRY(dvd_small_linear(tbuf, 1, e->F(e->wi.t_w0), e->F(e->wi.t_b0), th, HID, 1, 256, HID, 256, 2, 1, stream));
+  TRY(dvd_small_linear(th, HID, e->F(e->wi.t_w2), e->F(e->wi.t_b2), cvec, HID, 1, HID, HID, HID, 0, 0, stream));
+  TRY(dvd_small_linear(cvec, HID, e->F(e->wi.ada_w), e->F(e->wi.ada_b), mod, 6 * HID, 1, HID, 6 * HID, HID, 1, 0, stream));
+  TRY(dvd_small_linear(cvec, HID, e->F(e->wi.fin_ada_w), e->F(e->wi.fin_ada_b), finmod, 2 * DEC, 1, DEC, 2 * DEC, HID, 1, 0,
+                       stream));
+  const float *sh_a = mod, *sc_a = mod + HID, *g_a = mod + 2 * HID, *sh_m = mod + 3 * HID, *sc_m = mod + 4 * HID,
+              *g_m = mod + 5 * HID;
+
+  // --- tokens ---
+  TRY(dvd_embed_obs_ln(x_t, e->F(e->wi.obs_w), e->F(e->wi.obs_b), e->F(e->wi.pos), xtok32, xq16, N, G, stream));
+  TRY(dvd_build_r_rows((const float*)e->B(e->bi.feat), init_feat_nchw, init_flow, arows16, RK, N, G, hyp, feat_mode,
+                       stream));
+  TRY(gemm(0, (int)NT, HID, RK, 1, arows16, RK, 0, e->H(e->wi.r_w16), RK, 0, nullptr, 0, 0, rtok16, HID, 0, e->F(e->wi.r_b), 0,
+           0, e->F(e->wi.pos), T, nullptr, 0, nullptr, 0, 0, stream, nullptr, e->L(e->wi.r_w16)));
+
+  // --- parallel cross-attention of the shared query against the 4 streams (:237-265) ---
+  TRY(gemm(0, (int)NT, HID, HID, 1, xq16, HID, 0, e->H(e->wi.ca_wq16), HID, 0, nullptr, 0, 0, q16, HID, 0, e->F(e->wi.ca_bq),
+           0, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0, stream, nullptr, e->L(e->wi.ca_wq16)));
+  TRY(gemm(0, (int)NT, HID, HID, 1, rtok16, HID, 0, e->H(e->wi.ca_wk16), HID, 0, nullptr, 0, 0, kr16, HID, 0,
+           e->F(e->wi.ca_bk), 0, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0, stream, nullptr, e->L(e->wi.ca_wk16)));
+  TRY(gemm(0, HID, T, HID, N, e->H(e->wi.ca_wv16), HID, 0, rtok16, HID, (long)T * HID, nullptr, 0, 0, vtr16, T,
+           (long)HID * T, e->F(e->wi.ca_bv), 1, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0, stream, e->L(e->wi.ca_wv16), nullptr));
+  {
+    const int kn[3] = {e->bi.kc16, e->bi.km16, e->bi.kl16};
+    const int vn[3] = {e->bi.vtc16, e->bi.vtm16, e->bi.vtl16};
+    for (int s = 0; s < 3; ++s)
+      TRY(attn(64, 6, N, T, T, hyp, q16, HID, (long)T * HID, e->B(kn[s]), HID, (long)T * HID, e->B(vn[s]), T,
+               (long)HID * T, att16 + (size_t)s * NT * HID, HID, (long)T * HID, 0.125f, stream));
+    TRY(attn(64, 6, N, T, T, 1, q16, HID, (long)T * HID, kr16, HID, (long)T * HID, vtr16, T, (long)HID * T,
+             att16 + (size_t)3 * NT * HID, HID, (long)T * HID, 0.125f, stream));
+  }
+  // x_s = x + out_proj(attn_s)  -> z[:, 384 s : 384 (s+1)]   (stream order cond, msk6, line, r == cat order :623)
+  TRY(gemm(0, (int)NT, HID, HID, 4, att16, HID, NT * HID, e->H(e->wi.ca_wo16), HID, 0, z, DEC, HID, nullptr, 0, 0,
+           e->F(e->wi.ca_bo), 0, 0, nullptr, 0, nullptr, 0, xtok32, HID, 0, stream, nullptr, e->L(e->wi.ca_wo16)));
+
+  if (e->debug_stop == 1) return check_launch("engine_denoise_step(stop 1)");
+  // --- per stream: gated self-attention (:268-289) ---
+  TRY(dvd_layernorm_rows(z, DEC, HID, h16, HID, NT * HID, 4, NT, HID, nullptr, nullptr, sh_a, sc_a, 0, (int)NT, 1e-6f,
+                         stream));
+  TRY(gemm(0, (int)(4 * NT), 2 * HID, HID, 1, h16, HID, 0, e->H(e->wi.sa_wqk16), HID, 0, nullptr, 0, 0, qk16, 2 * HID, 0,
+           e->F(e->wi.sa_bqk), 0, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0, stream, nullptr, e->L(e->wi.sa_wqk16)));
+  TRY(gemm(0, HID, T, HID, 4 * N, e->H(e->wi.sa_wv16), HID, 0, h16, HID, (long)T * HID, nullptr, 0, 0, vt16, T,
+           (long)HID * T, e->F(e->wi.sa_bv), 1, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0, stream, e->L(e->wi.sa_wv16), nullptr));
+  TRY(attn(64, 6, 4 * N, T, T, 1, qk16, 2 * HID, (long)T * 2 * HID, qk16 + HID, 2 * HID, (long)T * 2 * HID, vt16, T,
+           (long)HID * T, att16, HID, (long)T * HID, 0.125f, stream));
+  TRY(gemm(0, (int)NT, HID, HID, 4, att16, HID, NT * HID, e->H(e->wi.sa_wp16), HID, 0, z, DEC, HID, nullptr, 0, 0,
+           e->F(e->wi.sa_bp), 0, 0, nullptr, 0, g_a, (int)NT, z, DEC, HID, stream, nullptr, e->L(e->wi.sa_wp16)));
+  // --- per stream: gated MLP (:271-292) ---
+  TRY(dvd_layernorm_rows(z, DEC, HID, h16, HID, NT * HID, 4, NT, HID, nullptr, nullptr, sh_m, sc_m, 0, (int)NT, 1e-6f,
+                         stream));
+  TRY(gemm(0, (int)(4 * NT), 4 * HID, HID, 1, h16, HID, 0, e->H(e->wi.fc1_w16), HID, 0, nullptr, 0, 0, mlp16, 4 * HID, 0,
+           e->F(e->wi.fc1_b), 0, /*gelu*/ 1, nullptr, 0, nullptr, 0, nullptr, 0, 0, stream, nullptr, e->L(e->wi.fc1_w16)));
+  TRY(gemm(0, (int)NT, HID, 4 * HID, 4, mlp16, 4 * HID, NT * 4 * HID, e->H(e->wi.fc2_w16), 4 * HID, 0, z, DEC, HID,
+           nullptr, 0, 0, e->F(e->wi.fc2_b), 0, 0, nullptr, 0, g_m, (int)NT, z, DEC, HID, stream, nullptr, e->L(e->wi.fc2_w16)));
+
+  if (e->debug_stop == 2) return check_launch("engine_denoise_step(stop 2)");
+  // --- decoder: adaptive 2-D positional encoding (idf/cross_attn.py:143-157) ---
+  float* pooled = (float*)e->B(e->bi.pooled);
+  float* petmp = (float*)e->B(e->bi.petmp);
+  float* hs = (float*)e->B(e->bi.hs);
+  float* wsc = (float*)e->B(e->bi.wsc);
+  TRY(dvd_colmean(z, (float*)e->B(e->bi.part), pooled, N, T, DEC, COLCHUNKS, stream));
+  TRY(dvd_small_linear(pooled, DEC, e->F(e->wi.pe_h0_w), e->F(e->wi.pe_h0_b), petmp, DEC, N, DEC, DEC, DEC, 0, 2, stream));
+  TRY(dvd_small_linear(petmp, DEC, e->F(e->wi.pe_h2_w), e->F(e->wi.pe_h2_b), hs, DEC, N, DEC, DEC, DEC, 0, 3, stream));
+  TRY(dvd_small_linear(pooled, DEC, e->F(e->wi.pe_w0_w), e->F(e->wi.pe_w0_b), petmp, DEC, N, DEC, DEC, DEC, 0, 2, stream));
+  TRY(dvd_small_linear(petmp, DEC, e->F(e->wi.pe_w2_w), e->F(e->wi.pe_w2_b), wsc, DEC, N, DEC, DEC, DEC, 0, 3, stream));
+  TRY(dvd_posenc_add(z, hs, wsc, e->F(e->wi.pe_htab), e->F(e->wi.pe_wtab), N, side, DEC, stream));
+
+  if (e->debug_stop == 3) return check_launch("engine_denoise_step(stop 3)");
+  // --- decoder layers (idf/cross_attn.py:377-396) ---
+  _Float16* f1 = mlp16;
+  _Float16* f2 = mlp16 + (size_t)NT * FFN;
+  for (int j = 0; j < 6; ++j) {
+    const WIdx::Dec& dw = e->wi.d[j];
+    TRY(dvd_layernorm_rows(z, DEC, 0, h16, DEC, 0, 1, NT, DEC, e->F(dw.n1w), e->F(dw.n1b), nullptr, nullptr, 0,
+                           1, 1e-5f, stream));
+    TRY(gemm(0, (int)NT, 2 * DEC, DEC, 1, h16, DEC, 0, e->H(dw.wqk16), DEC, 0, nullptr, 0, 0, qk16, 2 * DEC, 0,
+             nullptr, 0, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0, stream, nullptr, e->L(dw.wqk16)));
+    TRY(gemm(0, DEC, T, DEC, N, e->H(dw.wv16), DEC, 0, h16, DEC, (long)T * DEC, nullptr, 0, 0, vt16, T,
+             (long)DEC * T, nullptr, 0, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0, stream, e->L(dw.wv16), nullptr));
+    const bool timed = e->prof_on;
+    size_t slot = 0;
+    if (timed) {
+      if (e->prof_inflight == (size_t)PROF_PAIRS) TRY(prof_drain_one(e));   // ring full: fold the oldest pair into the totals
+      slot = (e->prof_head + e->prof_inflight) % PROF_PAIRS;
+      (void)hipEventRecord(e->prof_ev[2 * slot], st);
+    }
+    TRY(attn(256, 6, N, T, T, 1, qk16, 2 * DEC, (long)T * 2 * DEC, qk16 + DEC, 2 * DEC, (long)T * 2 * DEC, vt16, T,
+             (long)DEC * T, att16, DEC, (long)T * DEC, 0.0625f, stream));
+    if (timed) { (void)hipEventRecord(e->prof_ev[2 * slot + 1], st); e->prof_inflight += 1; }
+    TRY(gemm(0, (int)NT, DEC, DEC, 1, att16, DEC, 0, e->H(dw.wfc16), DEC, 0, z, DEC, 0, nullptr, 0, 0, nullptr, 0,
+             0, nullptr, 0, nullptr, 0, z, DEC, 0, stream, nullptr, e->L(dw.wfc16)));
+    TRY(dvd_layernorm_rows(z, DEC, 0, h16, DEC, 0, 1, NT, DEC, e->F(dw.n2w), e->F(dw.n2b), nullptr, nullptr, 0,
+                           1, 1e-5f, stream));
+    TRY(gemm(0, (int)NT, FFN, DEC, 1, h16, DEC, 0, e->H(dw.c1w16), DEC, 0, nullptr, 0, 0, f1, FFN, 0,
+             e->F(dw.c1b), 0, 2, nullptr, 0, nullptr, 0, nullptr, 0, 0, stream, nullptr, e->L(dw.c1w16)));
+    TRY(dvd_dwconv3x3(f1, f2, e->F(dw.dww), e->F(dw.dwb), N, side, FFN, stream));
+    TRY(gemm(0, (int)NT, DEC, FFN, 1, f2, FFN, 0, e->H(dw.c2w16), FFN, 0, z, DEC, 0, nullptr, 0, 0,
+             e->F(dw.c2b), 0, 2, nullptr, 0, nullptr, 0, z, DEC, 0, stream, nullptr, e->L(dw.c2w16)));
+    if (e->debug_stop == 4 + j) return check_launch("engine_denoise_step(stop 4+j)");
+  }
+
+  // --- final LayerNorm + FinalLayer2 + unpatchify + init_flow (:457; idf/cross_model.py:329-336,553-566,645-646) ---
+  TRY(dvd_final_tokens(z, e->F(e->wi.dec_nw), e->F(e->wi.dec_nb), finmod, finmod + DEC, 0, (int)NT, e->F(e->wi.fin_w),
+                       e->F(e->wi.fin_b), init_flow, x0_out, nullptr, N, G, stream));
+  return check_launch("engine_denoise_step");
+}
+
 extern "C" int dvd_engine_denoise_step(void* handle, const float* x_t, float t_embed, int feat_mode,
                                        const float* init_flow, const float* init_feat_nchw, float* x0_out,
                                        void* stream) {
@@ -439,132 +674,47 @@ extern "C" int dvd_engine_denoise_step(void* handle, const float* x_t, float t_e
               "engine_denoise_step: feat_mode %d (3 needs init_feat)", feat_mode);
   Engine* e = (Engine*)handle;
   TRY(require_ready(e, true));
+  DVD_REQUIRE(4 * e->NT < (1L << 31), "engine_denoise_step: batch too large for 32-bit row indices (NT=%ld)", e->NT);
   hipStream_t st = (hipStream_t)stream;
-  const int G = e->G, N = e->N, side = e->side, hyp = e->hyp;
-  const int T = (int)e->T;
-  const long NT = e->NT;
-  DVD_REQUIRE(4 * NT < (1L << 31), "engine_denoise_step: batch too large for 32-bit row indices (NT=%ld)", NT);
+  set_scalar_kernel<<<1, 1, 0, st>>>((float*)e->B(e->bi.tbuf), t_embed);
+  if (!e->use_graphs || e->prof_on || e->debug_stop)
+    return enqueue_step(e, x_t, feat_mode, init_flow, init_feat_nchw, x0_out, stream);
 
-  float* tbuf = (float*)e->B("tbuf");
-  float* th = (float*)e->B("th");
-  float* cvec = (float*)e->B("cvec");
-  float* mod = (float*)e->B("mod");
-  float* finmod = (float*)e->B("finmod");
-  float* xtok32 = (float*)e->B("xtok32");
-  _Float16* xq16 = (_Float16*)e->B("xq16");
-  _Float16* arows16 = (_Float16*)e->B("arows16");
-  _Float16* rtok16 = (_Float16*)e->B("rtok16");
-  _Float16* q16 = (_Float16*)e->B("q16");
-  _Float16* kr16 = (_Float16*)e->B("kr16");
-  _Float16* vtr16 = (_Float16*)e->B("vtr16");
-  _Float16* att16 = (_Float16*)e->B("att16");
-  float* z = (float*)e->B("z");
-  _Float16* h16 = (_Float16*)e->B("h16");
-  _Float16* qk16 = (_Float16*)e->B("qk16");
-  _Float16* vt16 = (_Float16*)e->B("vt16");
-  _Float16* mlp16 = (_Float16*)e->B("mlp16");
-
-  // --- timestep embedding and the two adaLN tables (one row: t is batch-global in sampling) ---
-  set_scalar_kernel<<<1, 1, 0, st>>>(tbuf, t_embed);
-  TRY(dvd_small_linear(tbuf, 1, e->Wf("t_w0"), e->Wf("t_b0"), th, HID, 1, 256, HID, 256, 2, 1, stream));
-  TRY(dvd_small_linear(th, HID, e->Wf("t_w2"), e->Wf("t_b2"), cvec, HID, 1, HID, HID, HID, 0, 0, stream));
-  TRY(dvd_small_linear(cvec, HID, e->Wf("ada_w"), e->Wf("ada_b"), mod, 6 * HID, 1, HID, 6 * HID, HID, 1, 0, stream));
-  TRY(dvd_small_linear(cvec, HID, e->Wf("fin_ada_w"), e->Wf("fin_ada_b"), finmod, 2 * DEC, 1, DEC, 2 * DEC, HID, 1, 0,
-                       stream));
-  const float *sh_a = mod, *sc_a = mod + HID, *g_a = mod + 2 * HID, *sh_m = mod + 3 * HID, *sc_m = mod + 4 * HID,
-              *g_m = mod + 5 * HID;
-
-  // --- tokens ---
-  TRY(dvd_embed_obs_ln(x_t, e->Wf("obs_w"), e->Wf("obs_b"), e->Wf("pos"), xtok32, xq16, N, G, stream));
-  TRY(dvd_build_r_rows((const float*)e->B("feat"), init_feat_nchw, init_flow, arows16, RK, N, G, hyp, feat_mode,
-                       stream));
-  TRY(gemm(0, (int)NT, HID, RK, 1, arows16, RK, 0, e->Wh("r_w16"), RK, 0, nullptr, 0, 0, rtok16, HID, 0, e->Wf("r_b"), 0,
-           0, e->Wf("pos"), T, nullptr, 0, nullptr, 0, 0, stream, nullptr, e->Wl("r_w16")));
-
-  // --- parallel cross-attention of the shared query against the 4 streams (:237-265) ---
-  TRY(gemm(0, (int)NT, HID, HID, 1, xq16, HID, 0, e->Wh("ca_wq16"), HID, 0, nullptr, 0, 0, q16, HID, 0, e->Wf("ca_bq"),
-           0, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0, stream, nullptr, e->Wl("ca_wq16")));
-  TRY(gemm(0, (int)NT, HID, HID, 1, rtok16, HID, 0, e->Wh("ca_wk16"), HID, 0, nullptr, 0, 0, kr16, HID, 0,
-           e->Wf("ca_bk"), 0, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0, stream, nullptr, e->Wl("ca_wk16")));
-  TRY(gemm(0, HID, T, HID, N, e->Wh("ca_wv16"), HID, 0, rtok16, HID, (long)T * HID, nullptr, 0, 0, vtr16, T,
-           (long)HID * T, e->Wf("ca_bv"), 1, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0, stream, e->Wl("ca_wv16"), nullptr));
-  {
-    const char* kn[3] = {"kc16", "km16", "kl16"};
-    const char* vn[3] = {"vtc16", "vtm16", "vtl16"};
-    for (int s = 0; s < 3; ++s)
-      TRY(attn(64, 6, N, T, T, hyp, q16, HID, (long)T * HID, e->B(kn[s]), HID, (long)T * HID, e->B(vn[s]), T,
-               (long)HID * T, att16 + (size_t)s * NT * HID, HID, (long)T * HID, 0.125f, stream));
-    TRY(attn(64, 6, N, T, T, 1, q16, HID, (long)T * HID, kr16, HID, (long)T * HID, vtr16, T, (long)HID * T,
-             att16 + (size_t)3 * NT * HID, HID, (long)T * HID, 0.125f, stream));
+  // ---- hipGraph replay: ~110 launches of a small-grid evaluation become one graph launch.  A key's first use runs
+  // eagerly (every lazy one-time initialisation happens outside capture), its second use captures, later uses replay.
+  const GraphKey key{feat_mode, x_t, init_flow, feat_mode == 3 ? init_feat_nchw : nullptr, x0_out};
+  GraphEntry* ge = nullptr;
+  for (auto& g : e->graphs)
+    if (g.key == key) { ge = &g; break; }
+  if (!ge) {
+    if (e->graphs.size() >= 32) e->drop_graphs();
+    e->graphs.push_back({key, nullptr});
+    return enqueue_step(e, x_t, feat_mode, init_flow, init_feat_nchw, x0_out, stream);
   }
-  // x_s = x + out_proj(attn_s)  -> z[:, 384 s : 384 (s+1)]   (stream order cond, msk6, line, r == cat order :623)
-  TRY(gemm(0, (int)NT, HID, HID, 4, att16, HID, NT * HID, e->Wh("ca_wo16"), HID, 0, z, DEC, HID, nullptr, 0, 0,
-           e->Wf("ca_bo"), 0, 0, nullptr, 0, nullptr, 0, xtok32, HID, 0, stream, nullptr, e->Wl("ca_wo16")));
-
-  if (e->debug_stop == 1) return check_launch("engine_denoise_step(stop 1)");
-  // --- per stream: gated self-attention (:268-289) ---
-  TRY(dvd_layernorm_rows(z, DEC, HID, h16, HID, NT * HID, 4, NT, HID, nullptr, nullptr, sh_a, sc_a, 0, (int)NT, 1e-6f,
-                         stream));
-  TRY(gemm(0, (int)(4 * NT), 2 * HID, HID, 1, h16, HID, 0, e->Wh("sa_wqk16"), HID, 0, nullptr, 0, 0, qk16, 2 * HID, 0,
-           e->Wf("sa_bqk"), 0, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0, stream, nullptr, e->Wl("sa_wqk16")));
-  TRY(gemm(0, HID, T, HID, 4 * N, e->Wh("sa_wv16"), HID, 0, h16, HID, (long)T * HID, nullptr, 0, 0, vt16, T,
-           (long)HID * T, e->Wf("sa_bv"), 1, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0, stream, e->Wl("sa_wv16"), nullptr));
-  TRY(attn(64, 6, 4 * N, T, T, 1, qk16, 2 * HID, (long)T * 2 * HID, qk16 + HID, 2 * HID, (long)T * 2 * HID, vt16, T,
-           (long)HID * T, att16, HID, (long)T * HID, 0.125f, stream));
-  TRY(gemm(0, (int)NT, HID, HID, 4, att16, HID, NT * HID, e->Wh("sa_wp16"), HID, 0, z, DEC, HID, nullptr, 0, 0,
-           e->Wf("sa_bp"), 0, 0, nullptr, 0, g_a, (int)NT, z, DEC, HID, stream, nullptr, e->Wl("sa_wp16")));
-  // --- per stream: gated MLP (:271-292) ---
-  TRY(dvd_layernorm_rows(z, DEC, HID, h16, HID, NT * HID, 4, NT, HID, nullptr, nullptr, sh_m, sc_m, 0, (int)NT, 1e-6f,
-                         stream));
-  TRY(gemm(0, (int)(4 * NT), 4 * HID, HID, 1, h16, HID, 0, e->Wh("fc1_w16"), HID, 0, nullptr, 0, 0, mlp16, 4 * HID, 0,
-           e->Wf("fc1_b"), 0, /*gelu*/ 1, nullptr, 0, nullptr, 0, nullptr, 0, 0, stream, nullptr, e->Wl("fc1_w16")));
-  TRY(gemm(0, (int)NT, HID, 4 * HID, 4, mlp16, 4 * HID, NT * 4 * HID, e->Wh("fc2_w16"), 4 * HID, 0, z, DEC, HID,
-           nullptr, 0, 0, e->Wf("fc2_b"), 0, 0, nullptr, 0, g_m, (int)NT, z, DEC, HID, stream, nullptr, e->Wl("fc2_w16")));
-
-  if (e->debug_stop == 2) return check_launch("engine_denoise_step(stop 2)");
-  // --- decoder: adaptive 2-D positional encoding (idf/cross_attn.py:143-157) ---
-  float* pooled = (float*)e->B("pooled");
-  float* petmp = (float*)e->B("petmp");
-  float* hs = (float*)e->B("hs");
-  float* wsc = (float*)e->B("wsc");
-  TRY(dvd_colmean(z, (float*)e->B("part"), pooled, N, T, DEC, COLCHUNKS, stream));
-  TRY(dvd_small_linear(pooled, DEC, e->Wf("pe_h0_w"), e->Wf("pe_h0_b"), petmp, DEC, N, DEC, DEC, DEC, 0, 2, stream));
-  TRY(dvd_small_linear(petmp, DEC, e->Wf("pe_h2_w"), e->Wf("pe_h2_b"), hs, DEC, N, DEC, DEC, DEC, 0, 3, stream));
-  TRY(dvd_small_linear(pooled, DEC, e->Wf("pe_w0_w"), e->Wf("pe_w0_b"), petmp, DEC, N, DEC, DEC, DEC, 0, 2, stream));
-  TRY(dvd_small_linear(petmp, DEC, e->Wf("pe_w2_w"), e->Wf("pe_w2_b"), wsc, DEC, N, DEC, DEC, DEC, 0, 3, stream));
-  TRY(dvd_posenc_add(z, hs, wsc, e->Wf("pe_htab"), e->Wf("pe_wtab"), N, side, DEC, stream));
-
-  if (e->debug_stop == 3) return check_launch("engine_denoise_step(stop 3)");
-  // --- decoder layers (idf/cross_attn.py:377-396) ---
-  _Float16* f1 = mlp16;
-  _Float16* f2 = mlp16 + (size_t)NT * FFN;
-  for (int j = 0; j < 6; ++j) {
-    const std::string p = "d" + std::to_string(j) + "_";
-    TRY(dvd_layernorm_rows(z, DEC, 0, h16, DEC, 0, 1, NT, DEC, e->Wf(p + "n1w"), e->Wf(p + "n1b"), nullptr, nullptr, 0,
-                           1, 1e-5f, stream));
-    TRY(gemm(0, (int)NT, 2 * DEC, DEC, 1, h16, DEC, 0, e->Wh(p + "wqk16"), DEC, 0, nullptr, 0, 0, qk16, 2 * DEC, 0,
-             nullptr, 0, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0, stream, nullptr, e->Wl(p + "wqk16")));
-    TRY(gemm(0, DEC, T, DEC, N, e->Wh(p + "wv16"), DEC, 0, h16, DEC, (long)T * DEC, nullptr, 0, 0, vt16, T,
-             (long)DEC * T, nullptr, 0, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0, stream, e->Wl(p + "wv16"), nullptr));
-    const bool timed = e->prof_on && e->prof_used + 2 <= e->prof_ev.size();
-    if (timed) (void)hipEventRecord(e->prof_ev[e->prof_used], st);
-    TRY(attn(256, 6, N, T, T, 1, qk16, 2 * DEC, (long)T * 2 * DEC, qk16 + DEC, 2 * DEC, (long)T * 2 * DEC, vt16, T,
-             (long)DEC * T, att16, DEC, (long)T * DEC, 0.0625f, stream));
-    if (timed) { (void)hipEventRecord(e->prof_ev[e->prof_used + 1], st); e->prof_used += 2; }
-    TRY(gemm(0, (int)NT, DEC, DEC, 1, att16, DEC, 0, e->Wh(p + "wfc16"), DEC, 0, z, DEC, 0, nullptr, 0, 0, nullptr, 0,
-             0, nullptr, 0, nullptr, 0, z, DEC, 0, stream, nullptr, e->Wl(p + "wfc16")));
-    TRY(dvd_layernorm_rows(z, DEC, 0, h16, DEC, 0, 1, NT, DEC, e->Wf(p + "n2w"), e->Wf(p + "n2b"), nullptr, nullptr, 0,
-                           1, 1e-5f, stream));
-    TRY(gemm(0, (int)NT, FFN, DEC, 1, h16, DEC, 0, e->Wh(p + "c1w16"), DEC, 0, nullptr, 0, 0, f1, FFN, 0,
-             e->Wf(p + "c1b"), 0, 2, nullptr, 0, nullptr, 0, nullptr, 0, 0, stream, nullptr, e->Wl(p + "c1w16")));
-    TRY(dvd_dwconv3x3(f1, f2, e->Wf(p + "dww"), e->Wf(p + "dwb"), N, side, FFN, stream));
-    TRY(gemm(0, (int)NT, DEC, FFN, 1, f2, FFN, 0, e->Wh(p + "c2w16"), FFN, 0, z, DEC, 0, nullptr, 0, 0,
-             e->Wf(p + "c2b"), 0, 2, nullptr, 0, nullptr, 0, z, DEC, 0, stream, nullptr, e->Wl(p + "c2w16")));
-    if (e->debug_stop == 4 + j) return check_launch("engine_denoise_step(stop 4+j)");
+  if (!ge->exec) {
+    if (!e->cap_stream && hipStreamCreateWithFlags(&e->cap_stream, hipStreamNonBlocking) != hipSuccess) {
+      set_error("engine_denoise_step: cannot create the capture stream");
+      return DVD_E_LAUNCH;
+    }
+    hipGraph_t graph = nullptr;
+    if (hipStreamBeginCapture(e->cap_stream, hipStreamCaptureModeRelaxed) != hipSuccess) {
+      set_error("engine_denoise_step: hipStreamBeginCapture failed");
+      return DVD_E_LAUNCH;
+    }
+    const int rc = enqueue_step(e, x_t, feat_mode, init_flow, init_feat_nchw, x0_out, e->cap_stream);
+    const hipError_t ec = hipStreamEndCapture(e->cap_stream, &graph);
+    if (rc != DVD_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+    if (ec != hipSuccess || !graph || hipGraphInstantiate(&ge->exec, graph, nullptr, nullptr, 0) != hipSuccess) {
+      if (graph) (void)hipGraphDestroy(graph);
+      ge->exec = nullptr;
+      set_error("engine_denoise_step: graph capture/instantiate failed (%s)", hipGetErrorString(ec));
+      return DVD_E_LAUNCH;
+    }
+    (void)hipGraphDestroy(graph);
   }
-
-  // --- final LayerNorm + FinalLayer2 + unpatchify + init_flow (:457; idf/cross_model.py:329-336,553-566,645-646) ---
-  TRY(dvd_final_tokens(z, e->Wf("dec_nw"), e->Wf("dec_nb"), finmod, finmod + DEC, 0, (int)NT, e->Wf("fin_w"),
-                       e->Wf("fin_b"), init_flow, x0_out, nullptr, N, G, stream));
-  return check_launch("engine_denoise_step");
+  if (hipGraphLaunch(ge->exec, st) != hipSuccess) {
+    set_error("engine_denoise_step: hipGraphLaunch failed");
+    return DVD_E_LAUNCH;
+  }
+  return check_launch("engine_denoise_step(graph)");
 }

@@ -1044,9 +1044,11 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_split128_kernel(GemmArgs p) {
 
 using namespace dvd;
 
+#ifdef DVD_LAB
 static unsigned long long* g_gemm_stamps = nullptr;
-// diagnostic builds only (DVD_GEMM_DEBUG=3): where the per-wave s_memtime stamps of the large-tile kernel go
+// lab builds only (DVD_GEMM_DEBUG=3): where the per-wave s_memtime stamps of the large-tile kernel go
 extern "C" int dvd_gemm_debug_stamps(void* dev_u64) { g_gemm_stamps = (unsigned long long*)dev_u64; return DVD_OK; }
+#endif
 
 extern "C" int dvd_gemm_nt(const dvd_gemm_desc* d, void* stream) {
   DVD_REQUIRE(d && d->A && d->B && (d->C32 || d->C16), "gemm: null pointer");
@@ -1077,10 +1079,22 @@ extern "C" int dvd_gemm_nt(const dvd_gemm_desc* d, void* stream) {
   p.gate_rows = d->gate_rows; p.pos_rows = d->pos_rows;
   p.act = d->act; p.bias_row = d->bias_row;
 
+  // The product library has no switches: the kernel is a function of the descriptor alone.  The lab build
+  // (-DDVD_LAB, benchmarks/lab/libdvd_hip_lab.so) keeps the A/B switches of the experiments that were measured.
+#ifdef DVD_LAB
   { const char* dbg = getenv("DVD_GEMM_DEBUG"); p.debug = dbg ? atoi(dbg) : 0; }
+  { const char* sg = getenv("DVD_GEMM_STAGGER"); p.stagger = sg ? atoi(sg) : 0; }   // measured: no effect
+  p.stamps = g_gemm_stamps;
+  const bool lab_scalar_epi = getenv("DVD_GEMM_SCALAR_EPILOGUE"), lab_v1 = getenv("DVD_GEMM_V1"),
+             lab_twopass = getenv("DVD_GEMM_TWOPASS"), lab_nonpersistent = getenv("DVD_GEMM_NONPERSISTENT"),
+             lab_spread = getenv("DVD_GEMM_SPREAD");
+#else
+  p.debug = 0; p.stagger = 0; p.stamps = nullptr;
+  constexpr bool lab_scalar_epi = false, lab_v1 = false, lab_twopass = false, lab_nonpersistent = false;
+#endif
   {
     auto al = [](const void* q, size_t a) { return ((uintptr_t)q % a) == 0; };
-    bool ok = d->N % 8 == 0 && !getenv("DVD_GEMM_SCALAR_EPILOGUE");
+    bool ok = d->N % 8 == 0 && !lab_scalar_epi;
     if (d->C32) ok = ok && d->ldc % 4 == 0 && d->strideC32 % 4 == 0 && al(d->C32, 16);
     if (d->C16) ok = ok && d->ldc16 % 8 == 0 && d->strideC16 % 8 == 0 && al(d->C16, 16);
     if (d->bias && !d->bias_row) ok = ok && al(d->bias, 16) && d->strideBias % 4 == 0;
@@ -1089,14 +1103,12 @@ extern "C" int dvd_gemm_nt(const dvd_gemm_desc* d, void* stream) {
     if (d->res) ok = ok && d->ldres % 4 == 0 && d->strideRes % 4 == 0 && al(d->res, 16);
     p.vec_epilogue = ok ? 1 : 0;
   }
-  p.stamps = g_gemm_stamps;
-  { const char* sg = getenv("DVD_GEMM_STAGGER"); p.stagger = sg ? atoi(sg) : 0; }   // measured: no effect
   // large-tile kernel for the big f16 GEMMs (decoder): N a multiple of 256, at least a few row tiles
   // kernel choice depends on (dtype, N, K, split) only, never on M: a document then takes the same kernels - and the
   // same fp32 summation order - whether it is sampled alone or in a batch (bit-identical results, tested)
-  const bool big = d->dtype == 0 && d->N % 256 == 0 && !getenv("DVD_GEMM_V1");
+  const bool big = d->dtype == 0 && d->N % 256 == 0 && !lab_v1;
   if (d->dtype == 0 && d->N % 128 == 0 && d->N % 256 != 0 && d->B_lo && !d->A_lo && d->lo_scale == 1.f &&
-      !getenv("DVD_GEMM_TWOPASS") && !getenv("DVD_GEMM_V1")) {
+      !lab_twopass && !lab_v1) {
     p.ntm = cdiv(d->M, 256); p.ntn = d->N / 128;
     constexpr int LDS = 8 * 16384;                    // 3 stages x 32 KiB, rounded up to the epilogue's 8 x 16 KiB
     static bool once_s1 = false;
@@ -1109,7 +1121,7 @@ extern "C" int dvd_gemm_nt(const dvd_gemm_desc* d, void* stream) {
     gemm_nt_split128_kernel<<<dim3(nblk, d->batch), 512, LDS, (hipStream_t)stream>>>(p);
     return check_launch("gemm_nt(split128)");
   }
-  if (big && d->B_lo && !d->A_lo && d->lo_scale == 1.f && d->K % 32 == 0 && !getenv("DVD_GEMM_TWOPASS")) {
+  if (big && d->B_lo && !d->A_lo && d->lo_scale == 1.f && d->K % 32 == 0 && !lab_twopass) {
     p.ntm = cdiv(d->M, 256); p.ntn = d->N / 256;
     constexpr int LDS = 3 * 3 * 256 * 64;
     static bool once_s = false;
@@ -1128,20 +1140,25 @@ extern "C" int dvd_gemm_nt(const dvd_gemm_desc* d, void* stream) {
     static bool once = false;
     if (!once) {
       (void)hipFuncSetAttribute((const void*)gemm_nt_big_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+#ifdef DVD_LAB
       (void)hipFuncSetAttribute((const void*)gemm_nt_big_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
       (void)hipFuncSetAttribute((const void*)gemm_nt_big_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
       (void)hipFuncSetAttribute((const void*)gemm_nt_big_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
       (void)hipFuncSetAttribute((const void*)gemm_nt_big_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+#endif
       once = true;
     }
     int nblk = p.ntm * p.ntn;
-    if (nblk > 256 && !getenv("DVD_GEMM_NONPERSISTENT")) nblk = 256;
+    if (nblk > 256 && !lab_nonpersistent) nblk = 256;
     dim3 gridb(nblk, d->batch);
+#ifdef DVD_LAB
     if (p.debug == 1) gemm_nt_big_kernel<1><<<gridb, 512, LDS, (hipStream_t)stream>>>(p);
     else if (p.debug == 2) gemm_nt_big_kernel<2><<<gridb, 512, LDS, (hipStream_t)stream>>>(p);
     else if (p.debug == 3) gemm_nt_big_kernel<3><<<gridb, 512, LDS, (hipStream_t)stream>>>(p);
-    else if (getenv("DVD_GEMM_SPREAD")) gemm_nt_big_kernel<4><<<gridb, 512, LDS, (hipStream_t)stream>>>(p);
-    else gemm_nt_big_kernel<0><<<gridb, 512, LDS, (hipStream_t)stream>>>(p);
+    else if (lab_spread) gemm_nt_big_kernel<4><<<gridb, 512, LDS, (hipStream_t)stream>>>(p);
+    else
+#endif
+    gemm_nt_big_kernel<0><<<gridb, 512, LDS, (hipStream_t)stream>>>(p);
     return check_launch("gemm_nt(big)");
   }
   p.ntm = cdiv(d->M, 128); p.ntn = cdiv(d->N, 128);

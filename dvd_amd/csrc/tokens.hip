@@ -593,15 +593,17 @@ extern "C" int dvd_dwconv3x3(const void* in16, void* out16, const float* w9c, co
                              void* stream) {
   DVD_REQUIRE(in16 && out16 && w9c && b, "dwconv3x3: null pointer");
   DVD_REQUIRE(n > 0 && side > 0 && c % 8 == 0, "dwconv3x3: bad shape");
-  if (!getenv("DVD_DWCONV_V1")) {
-    const long total = (long)n * side * cdiv(side, DW_TX) * (c / 8);
-    dwconv3x3_row4_kernel<<<cdiv(total, 256), 256, 0, (hipStream_t)stream>>>((const _Float16*)in16, (_Float16*)out16, w9c,
-                                                                             b, side, c, total);
-    return check_launch("dwconv3x3");
+#ifdef DVD_LAB
+  if (getenv("DVD_DWCONV_V1")) {   // lab build: the one-token-per-thread kernel (same tap order, bit-identical, 1.5x slower)
+    const long total1 = (long)n * side * side * (c / 8);
+    dwconv3x3_kernel<<<cdiv(total1, 256), 256, 0, (hipStream_t)stream>>>((const _Float16*)in16, (_Float16*)out16, w9c, b,
+                                                                         side, c, total1);
+    return check_launch("dwconv3x3(lab v1)");
   }
-  const long total = (long)n * side * side * (c / 8);
-  dwconv3x3_kernel<<<cdiv(total, 256), 256, 0, (hipStream_t)stream>>>((const _Float16*)in16, (_Float16*)out16, w9c, b,
-                                                                      side, c, total);
+#endif
+  const long total = (long)n * side * cdiv(side, DW_TX) * (c / 8);
+  dwconv3x3_row4_kernel<<<cdiv(total, 256), 256, 0, (hipStream_t)stream>>>((const _Float16*)in16, (_Float16*)out16, w9c,
+                                                                           b, side, c, total);
   return check_launch("dwconv3x3");
 }
 

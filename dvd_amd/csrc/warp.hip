@@ -249,6 +249,9 @@ __global__ void __launch_bounds__(256) unwarp_grid_kernel(const float* __restric
 __global__ void __launch_bounds__(256) unwarp_f32_kernel(const float* __restrict__ flow,
                                                          const float* __restrict__ src, float* __restrict__ out,
                                                          UpParams p) {
+  flow += (size_t)blockIdx.z * 2 * p.g * p.g;        // one document per grid z (batched launch)
+  src += (size_t)blockIdx.z * 3 * p.h * p.w;
+  out += (size_t)blockIdx.z * 3 * p.h * p.w;
   const int i0 = blockIdx.y * PX;
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= p.w) return;
@@ -282,6 +285,9 @@ __global__ void __launch_bounds__(256) unwarp_f32_kernel(const float* __restrict
 __global__ void __launch_bounds__(256) unwarp_u8_kernel(const float* __restrict__ flow,
                                                         const uint8_t* __restrict__ src, uint8_t* __restrict__ out,
                                                         UpParams p) {
+  flow += (size_t)blockIdx.z * 2 * p.g * p.g;        // one document per grid z (batched launch)
+  src += (size_t)blockIdx.z * 3 * p.h * p.w;
+  out += (size_t)blockIdx.z * 3 * p.h * p.w;
   const int i0 = blockIdx.y * PX;
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= p.w) return;
@@ -321,6 +327,9 @@ __global__ void __launch_bounds__(256) unwarp_u8_kernel(const float* __restrict_
 __global__ void __launch_bounds__(256) unwarp_f32_rows_kernel(const float* __restrict__ flow,
                                                               const float* __restrict__ src,
                                                               float* __restrict__ out, UpParams p) {
+  flow += (size_t)blockIdx.z * 2 * p.g * p.g;        // one document per grid z (batched launch)
+  src += (size_t)blockIdx.z * 3 * p.h * p.w;
+  out += (size_t)blockIdx.z * 3 * p.h * p.w;
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int ib = (blockIdx.y * 4 + wv) * KR;
@@ -369,6 +378,9 @@ __device__ __forceinline__ void load_rgb_pair(const uint8_t* __restrict__ src, u
 __global__ void __launch_bounds__(256) unwarp_u8_rows_kernel(const float* __restrict__ flow,
                                                              const uint8_t* __restrict__ src,
                                                              uint8_t* __restrict__ out, UpParams p) {
+  flow += (size_t)blockIdx.z * 2 * p.g * p.g;        // one document per grid z (batched launch)
+  src += (size_t)blockIdx.z * 3 * p.h * p.w;
+  out += (size_t)blockIdx.z * 3 * p.h * p.w;
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int i = blockIdx.y * 4 + wv;
@@ -427,10 +439,15 @@ static UpParams make_up(int g, int h, int w, float scale) {
 
 using namespace dvd;
 
-// DVD_WARP_SCALAR=1 forces the 1-pixel-per-lane fallback kernels (A/B runs and the fallback's own tests)
+// The 1-pixel-per-lane kernels are the fallback for shapes the row kernels do not take (win < 2, w % 4 != 0 for u8,
+// planes >= 4 GiB).  Lab build only: DVD_WARP_SCALAR=1 forces them (A/B runs, fast-vs-fallback bit-identity checks).
 static bool scalar_warp() {
+#ifdef DVD_LAB
   const char* e = getenv("DVD_WARP_SCALAR");
   return e && e[0] == '1';
+#else
+  return false;
+#endif
 }
 
 extern "C" int dvd_grid_sample_bilinear_zeros_ac(const float* src, const float* grid, float* out, int n, int c,
@@ -466,28 +483,42 @@ extern "C" int dvd_unwarp_grid(const float* flow, int g, float* grid_out, int h,
   return check_launch("unwarp_grid");
 }
 
-extern "C" int dvd_unwarp_f32(const float* flow, int g, const float* src_chw, float* out_hwc, int h, int w,
-                              float scale, void* stream) {
+extern "C" int dvd_unwarp_f32_batch(const float* flow, int g, const float* src_chw, float* out_hwc, int n, int h,
+                                    int w, float scale, void* stream) {
   if (int e = unwarp_args(flow, src_chw, out_hwc, g, h, w)) return e;
+  DVD_REQUIRE(n >= 0 && n <= 65535, "unwarp: bad batch %d", n);
+  if (n == 0) return DVD_OK;
   if (w >= 2 && (size_t)h * w * 12 < (1ull << 32) && !scalar_warp()) {
-    dim3 grd(cdiv(w, 64), cdiv(h, 4 * KR));
+    dim3 grd(cdiv(w, 64), cdiv(h, 4 * KR), n);
     unwarp_f32_rows_kernel<<<grd, 256, 0, (hipStream_t)stream>>>(flow, src_chw, out_hwc, make_up(g, h, w, scale));
     return check_launch("unwarp_f32");
   }
-  dim3 grd(cdiv(w, 256), cdiv(h, 4));
+  dim3 grd(cdiv(w, 256), cdiv(h, 4), n);
   unwarp_f32_kernel<<<grd, 256, 0, (hipStream_t)stream>>>(flow, src_chw, out_hwc, make_up(g, h, w, scale));
   return check_launch("unwarp_f32");
 }
 
-extern "C" int dvd_unwarp_u8(const float* flow, int g, const uint8_t* src_hwc, uint8_t* out_hwc, int h, int w,
-                             float scale, void* stream) {
+extern "C" int dvd_unwarp_f32(const float* flow, int g, const float* src_chw, float* out_hwc, int h, int w,
+                              float scale, void* stream) {
+  return dvd_unwarp_f32_batch(flow, g, src_chw, out_hwc, 1, h, w, scale, stream);
+}
+
+extern "C" int dvd_unwarp_u8_batch(const float* flow, int g, const uint8_t* src_hwc, uint8_t* out_hwc, int n, int h,
+                                   int w, float scale, void* stream) {
   if (int e = unwarp_args(flow, src_hwc, out_hwc, g, h, w)) return e;
+  DVD_REQUIRE(n >= 0 && n <= 65535, "unwarp: bad batch %d", n);
+  if (n == 0) return DVD_OK;
   if (w % 4 == 0 && (size_t)h * w * 3 < (1ull << 32) && (size_t)h * w * 3 >= 12 && !scalar_warp()) {
-    dim3 grd(cdiv(w, 256), cdiv(h, 4));
+    dim3 grd(cdiv(w, 256), cdiv(h, 4), n);
     unwarp_u8_rows_kernel<<<grd, 256, 0, (hipStream_t)stream>>>(flow, src_hwc, out_hwc, make_up(g, h, w, scale));
     return check_launch("unwarp_u8");
   }
-  dim3 grd(cdiv(w, 256), cdiv(h, 4));
+  dim3 grd(cdiv(w, 256), cdiv(h, 4), n);
   unwarp_u8_kernel<<<grd, 256, 0, (hipStream_t)stream>>>(flow, src_hwc, out_hwc, make_up(g, h, w, scale));
   return check_launch("unwarp_u8");
+}
+
+extern "C" int dvd_unwarp_u8(const float* flow, int g, const uint8_t* src_hwc, uint8_t* out_hwc, int h, int w,
+                             float scale, void* stream) {
+  return dvd_unwarp_u8_batch(flow, g, src_hwc, out_hwc, 1, h, w, scale, stream);
 }

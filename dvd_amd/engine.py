@@ -14,6 +14,7 @@ from .lib import ptr, stream_ptr
 
 
 _SPECS = {}
+GRAPH_MAX_GRID = 128
 
 
 def _is_dev(t) -> bool:
@@ -78,6 +79,11 @@ class Engine:
         lib.call("dvd_engine_bind_workspace", h, C.c_void_p(self._ws_ptr), nbytes)
         self.specs = tensor_specs(grid)
         self.blob = None
+        self._io = None
+        # small grids are launch-bound (~110 launches of a few microseconds per evaluation): replay each evaluation as
+        # one captured hipGraph.  At the BASELINE grid an evaluation is ~0.4 s of device time and nothing is gained.
+        if grid <= GRAPH_MAX_GRID:
+            self.set_option("graphs", 1)
 
     def __del__(self):
         try:
@@ -136,6 +142,14 @@ class Engine:
         lib.call("dvd_engine_denoise_step", self._h, ptr(x_t), C.c_float(t_embed), feat_mode, ptr(init_flow),
                  ptr(init_feat if feat_mode == 3 else None), ptr(out), stream_ptr())
         return out
+
+    def io_buffers(self):
+        """Persistent I/O of the sampling loop (x_t and x0 ping-pong pairs, the first step's init_flow)."""
+        if self._io is None:
+            shp = (self.n, 2, self.grid, self.grid)
+            mk = lambda: torch.empty(shp, dtype=torch.float32, device=self.device)  # noqa: E731
+            self._io = {"img": [mk(), mk()], "x0": [mk(), mk()], "flow0": mk()}
+        return self._io
 
     def set_option(self, name: str, value: int):
         lib.call("dvd_engine_set_option", self._h, name.encode(), int(value))

@@ -72,8 +72,14 @@ def run_evaluation_docunet(settings, logger, documents, diffusion, model, device
                                        th.zeros(nb, 256, G, G, device=device))
         th.cuda.synchronize()
         times.append((time.time() - t0) / model_docs)
+        # :301-306 + viz :75-77 - one launch for the batch when its documents share a full-resolution size
+        if len({d["src_u8"].shape for d in batch}) == 1:
+            outs = ops.unwarp_u8_batch(flow.contiguous(), stack("src_u8"))
+        else:
+            outs = [ops.unwarp_u8(flow[j:j + 1].contiguous(), th.from_numpy(d["src_u8"]).to(device))
+                    for j, d in enumerate(batch)]
         for j, d in enumerate(batch):
-            out = ops.unwarp_u8(flow[j:j + 1].contiguous(), th.from_numpy(d["src_u8"]).to(device))   # :301-306 + viz :75-77
+            out = outs[j]
             results.append((d["path"], out))
             if env.visualize:
                 from PIL import Image

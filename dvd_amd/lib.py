@@ -68,18 +68,8 @@ class AttnDesc(C.Structure):
                 ("scale", C.c_float)]
 
 
-def _sig(name, argtypes, restype=C.c_int):
-    fn = getattr(_lib, name)
-    fn.argtypes = argtypes
-    fn.restype = restype
-    return fn
-
-
-_lib.dvd_last_error.restype = C.c_char_p
-_lib.dvd_version.restype = C.c_int
-_lib.dvd_engine_workspace_bytes.restype = C.c_long
-_lib.dvd_engine_workspace_bytes.argtypes = [C.c_void_p]
-NON_STATUS = {"dvd_last_error", "dvd_version", "dvd_engine_workspace_bytes", "dvd_engine_tensor_count"}
+NON_STATUS = {"dvd_last_error", "dvd_version", "dvd_engine_workspace_bytes", "dvd_engine_tensor_count",
+              "dvd_flash_attn_kernel_name"}
 
 # name -> argtypes; kept in one table so tests can check every symbol of include/dvd_hip.h
 SIGNATURES = {
@@ -87,14 +77,14 @@ SIGNATURES = {
                                           C.c_int, C.c_int, c_void],
     "dvd_unwarp_f32": [c_void, C.c_int, c_void, c_void, C.c_int, C.c_int, C.c_float, c_void],
     "dvd_unwarp_u8": [c_void, C.c_int, c_void, c_void, C.c_int, C.c_int, C.c_float, c_void],
+    "dvd_unwarp_f32_batch": [c_void, C.c_int, c_void, c_void, C.c_int, C.c_int, C.c_int, C.c_float, c_void],
+    "dvd_unwarp_u8_batch": [c_void, C.c_int, c_void, c_void, C.c_int, C.c_int, C.c_int, C.c_float, c_void],
     "dvd_unwarp_grid": [c_void, C.c_int, c_void, C.c_int, C.c_int, C.c_float, c_void],
     "dvd_sched_step": [C.POINTER(SchedCoef), c_void, c_void, c_void, c_void, c_void, C.c_int, C.c_int, c_void],
     "dvd_hyp_mean_clamp": [c_void, c_void, C.c_int, C.c_int, C.c_int, c_void],
     "dvd_selftest_mfma": [c_void, c_void, c_void, c_void, c_void],
     "dvd_gemm_nt": [C.POINTER(GemmDesc), c_void],
-    "dvd_gemm_debug_stamps": [c_void],
     "dvd_flash_attn": [C.POINTER(AttnDesc), c_void],
-    "dvd_attn_debug_stamps": [c_void],
     "dvd_embed_obs_ln": [c_void, c_void, c_void, c_void, c_void, c_void, C.c_int, C.c_int, c_void],
     "dvd_layernorm_rows": [c_void, C.c_int, C.c_long, c_void, C.c_int, C.c_long, C.c_int, C.c_long, C.c_int, c_void,
                            c_void, c_void, c_void, C.c_int, C.c_int, C.c_float, c_void],
@@ -129,12 +119,29 @@ SIGNATURES = {
 }
 
 
-def _bind_all():
+# entry points that exist only in the lab build (benchmarks/lab/dvd_hip_lab.h; DVD_HIP_LIB=benchmarks/lab/libdvd_hip_lab.so)
+LAB_SIGNATURES = {"dvd_gemm_debug_stamps": [c_void], "dvd_attn_debug_stamps": [c_void]}
+
+
+def bind(cdll):
+    """Attach argtypes / restypes to a loaded libdvd_hip.so (the product library, or the lab build in tests/benchmarks)."""
+    cdll.dvd_last_error.restype = C.c_char_p
+    cdll.dvd_version.restype = C.c_int
+    cdll.dvd_engine_workspace_bytes.restype = C.c_long
+    cdll.dvd_engine_workspace_bytes.argtypes = [C.c_void_p]
+    cdll.dvd_flash_attn_kernel_name.restype = C.c_char_p
+    cdll.dvd_flash_attn_kernel_name.argtypes = [C.c_int, C.c_int, C.c_int]
     for name, args in SIGNATURES.items():
-        _sig(name, args)
+        fn = getattr(cdll, name)
+        fn.argtypes, fn.restype = args, C.c_int
+    for name, args in LAB_SIGNATURES.items():
+        if hasattr(cdll, name):
+            fn = getattr(cdll, name)
+            fn.argtypes, fn.restype = args, C.c_int
+    return cdll
 
 
-_bind_all()
+bind(_lib)
 
 
 def call(name: str, *args):
@@ -142,6 +149,10 @@ def call(name: str, *args):
     rc = getattr(_lib, name)(*args)
     if rc != 0:
         raise DvdError(f"{name} failed ({rc}): {_lib.dvd_last_error().decode()}")
+
+
+def flash_attn_kernel_name(head_dim: int, tq: int, tk: int) -> str:
+    return _lib.dvd_flash_attn_kernel_name(head_dim, tq, tk).decode()
 
 
 def version() -> int:

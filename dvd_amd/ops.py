@@ -64,11 +64,39 @@ def unwarp_u8(flow: torch.Tensor, src_hwc: torch.Tensor, scale: float = 0.987) -
     return out
 
 
-def sched_step(coef: lib.SchedCoef, x_t, x0, noise=None, want_grid=False):
+def unwarp_u8_batch(flow: torch.Tensor, src_nhwc: torch.Tensor, scale: float = 0.987) -> torch.Tensor:
+    """flow [B,2,G,G]; src [B,H,W,3] uint8 -> [B,H,W,3] uint8: the batch's documents in ONE launch."""
+    _chk(flow, torch.float32, "flow")
+    _chk(src_nhwc, torch.uint8, "src")
+    b, h, w, three = src_nhwc.shape
+    assert three == 3 and flow.shape[0] == b and flow.shape[1] == 2
+    out = torch.empty_like(src_nhwc)
+    lib.call("dvd_unwarp_u8_batch", ptr(flow), flow.shape[-1], ptr(src_nhwc), ptr(out), b, h, w, C.c_float(scale),
+             stream_ptr())
+    return out
+
+
+def unwarp_f32_batch(flow: torch.Tensor, src_nchw: torch.Tensor, scale: float = 0.987) -> torch.Tensor:
+    """flow [B,2,G,G]; src [B,3,H,W] f32 0..255 -> [B,H,W,3] f32."""
+    _chk(flow, torch.float32, "flow")
+    _chk(src_nchw, torch.float32, "src")
+    b, three, h, w = src_nchw.shape
+    assert three == 3 and flow.shape[0] == b and flow.shape[1] == 2
+    out = torch.empty((b, h, w, 3), dtype=torch.float32, device=src_nchw.device)
+    lib.call("dvd_unwarp_f32_batch", ptr(flow), flow.shape[-1], ptr(src_nchw), ptr(out), b, h, w, C.c_float(scale),
+             stream_ptr())
+    return out
+
+
+def sched_step(coef: lib.SchedCoef, x_t, x0, noise=None, want_grid=False, out=None):
     _chk(x_t, torch.float32, "x_t")
     _chk(x0, torch.float32, "x0")
     n, _, g, _ = x_t.shape
-    out = torch.empty_like(x_t)
+    if out is None:
+        out = torch.empty_like(x_t)
+    else:
+        _chk(out, torch.float32, "out")
+        assert out.shape == x_t.shape and out.data_ptr() != x_t.data_ptr()
     ngrid = torch.empty_like(x_t) if want_grid else None
     if noise is not None:
         _chk(noise, torch.float32, "noise")

@@ -30,11 +30,22 @@ def sample(engine: Engine, tables: schedule.Tables, x_T: torch.Tensor, sampler: 
     the denoiser's `mode != None` (training) call: the raw model time is embedded, no 2/1 override (:575-580)."""
     n = engine.n
     S = tables.num_timesteps
-    img = x_T.contiguous()
-    first_flow = torch.zeros_like(img) if init_flow is None else init_flow.to(img.device, torch.float32).contiguous()
-    if tuple(first_flow.shape) != tuple(img.shape):
-        raise ValueError(f"init_flow must be {tuple(img.shape)}, got {tuple(first_flow.shape)}")
-    x0_bufs = [torch.empty_like(img), torch.empty_like(img)]
+    # The loop's I/O lives in buffers owned by the engine object and reused by every roll-out: x_t and x0 ping-pong
+    # between two buffers each, so a denoiser evaluation sees one of a handful of fixed (x_t, init_flow, x0) address
+    # triples - which is what lets the engine replay it as a captured hipGraph (dvd_engine_set_option "graphs").
+    io = engine.io_buffers()
+    if tuple(x_T.shape) != tuple(io["img"][0].shape):
+        raise ValueError(f"x_T must be {tuple(io['img'][0].shape)}, got {tuple(x_T.shape)}")
+    img_bufs, x0_bufs = io["img"], io["x0"]
+    img = img_bufs[0]
+    img.copy_(x_T)
+    first_flow = io["flow0"]
+    if init_flow is None:
+        first_flow.zero_()
+    else:
+        if tuple(init_flow.shape) != tuple(img.shape):
+            raise ValueError(f"init_flow must be {tuple(img.shape)}, got {tuple(init_flow.shape)}")
+        first_flow.copy_(init_flow)
     x0 = None
     if not 0 <= last_step < S:
         raise ValueError(f"last_step {last_step} outside [0, {S})")
@@ -60,7 +71,7 @@ def sample(engine: Engine, tables: schedule.Tables, x_T: torch.Tensor, sampler: 
         noise = noise_fn(i) if (coef.sigma != 0.0 and noise_fn is not None) else None
         if coef.sigma != 0.0 and noise is None:
             raise ValueError("this step needs noise: pass noise_fn")
-        img = ops.sched_step(coef, img, x0, noise)
+        img = ops.sched_step(coef, img, x0, noise, out=img_bufs[(k + 1) & 1])
     if mean_hyp:
         return ops.hyp_mean_clamp(x0, engine.n_hyp)
     return torch.clamp(x0, -1, 1)

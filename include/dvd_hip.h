@@ -61,6 +61,12 @@ int dvd_unwarp_f32(const float* flow, int g, const float* src_chw, float* out_hw
                    int h, int w, float scale, void* stream);
 int dvd_unwarp_u8(const float* flow, int g, const uint8_t* src_hwc, uint8_t* out_hwc,
                   int h, int w, float scale, void* stream);
+/* The same for n documents of one size in ONE launch (flow [n,2,G,G], src / out [n,...] contiguous):
+ * the per-document loop of run_evaluation_docunet (evaluation.py:245-306) for a batch of documents. */
+int dvd_unwarp_f32_batch(const float* flow, int g, const float* src_chw, float* out_hwc,
+                         int n, int h, int w, float scale, void* stream);
+int dvd_unwarp_u8_batch(const float* flow, int g, const uint8_t* src_hwc, uint8_t* out_hwc,
+                        int n, int h, int w, float scale, void* stream);
 /* Materialise the full-resolution sampling grid only ([2,H,W] f32), i.e. evaluation.py:301-306. */
 int dvd_unwarp_grid(const float* flow, int g, float* grid_out, int h, int w, float scale, void* stream);
 
@@ -123,8 +129,6 @@ typedef struct {
 } dvd_gemm_desc;
 
 int dvd_gemm_nt(const dvd_gemm_desc* desc, void* stream);
-/* diagnostics (env DVD_GEMM_DEBUG=3): device buffer [workgroups*8*4] u64 receiving per-wave s_memtime stamps */
-int dvd_gemm_debug_stamps(void* dev_u64);
 
 /* ------------------------------------------------------------------------------------------
  * Flash attention core  O = softmax(scale * Q K^T) V  per (batch, head); f16 in/out, fp32 softmax.
@@ -147,8 +151,9 @@ typedef struct {
 } dvd_attn_desc;
 
 int dvd_flash_attn(const dvd_attn_desc* desc, void* stream);
-/* diagnostics (env DVD_ATTN_DEBUG=1): device buffer [workgroups*4*5] u64 receiving per-wave phase times */
-int dvd_attn_debug_stamps(void* dev_u64);
+/* Name of the kernel dvd_flash_attn launches for a problem shape (the choice depends on head_dim, tq and tk only -
+ * never on the batch or the environment).  Measurement tooling matches rocprofv3 / PMC records against it. */
+const char* dvd_flash_attn_kernel_name(int head_dim, int tq, int tk);
 
 /* ------------------------------------------------------------------------------------------
  * Token-side kernels (each also reachable on its own for parity tests).  "rows" = tokens of all

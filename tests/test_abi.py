@@ -23,8 +23,30 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_python_binding_table_matches_header():
-    syms = set(declared_symbols()) - {"dvd_last_error", "dvd_version", "dvd_engine_workspace_bytes"}
+    syms = set(declared_symbols()) - {"dvd_last_error", "dvd_version", "dvd_engine_workspace_bytes",
+                                      "dvd_flash_attn_kernel_name"}
     assert syms == set(lib.SIGNATURES), (syms ^ set(lib.SIGNATURES))
+
+
+def test_product_library_reads_no_environment_and_ships_no_experiments():
+    """The product .so has no getenv import and none of the lab's experiment kernels / switch names; the lab build
+    (benchmarks/lab/libdvd_hip_lab.so, -DDVD_LAB) is where those live."""
+    import subprocess
+    so = os.path.join(ROOT, "dvd_amd", "libdvd_hip.so")
+    dyn = subprocess.run(["nm", "-D", so], capture_output=True, text=True, check=True).stdout
+    assert "getenv" not in dyn
+    blob = open(so, "rb").read()
+    for needle in (b"DVD_ATTN_", b"DVD_GEMM_", b"DVD_WARP_", b"flash_attn_pipe_kernel", b"flash_attn_dsplit_kernel",
+                   b"flash_attn_glds64x2_kernel"):
+        assert needle not in blob, needle
+    assert "dvd_attn_debug_stamps" not in dyn and "dvd_gemm_debug_stamps" not in dyn
+
+
+def test_attention_kernel_choice_depends_on_shape_only():
+    assert lib.flash_attn_kernel_name(256, 20736, 20736) == "flash_attn_r64_kernel<0>"
+    assert lib.flash_attn_kernel_name(256, 1024, 1024) == "flash_attn_glds_kernel<256, 0>"
+    assert lib.flash_attn_kernel_name(256, 1296, 1296) == "flash_attn_kernel<256>"
+    assert lib.flash_attn_kernel_name(64, 20736, 20736) == "flash_attn_glds_kernel<64, 0>"
 
 
 def test_version_and_error_string():

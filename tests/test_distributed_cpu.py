@@ -68,7 +68,7 @@ def test_two_rank_broadcast_and_sharding():
 # COMPUTE entry points stubbed at the lib.call boundary (there is no GPU here; the host-only entry
 # points - create / tensor_info / bind_workspace / set_tensor - run for real).
 # ------------------------------------------------------------------------------------------------
-COMPUTE = {"dvd_engine_prepare_docs", "dvd_engine_denoise_step", "dvd_engine_feat_nchw", "dvd_sched_step",
+COMPUTE = {"dvd_unwarp_u8_batch", "dvd_engine_prepare_docs", "dvd_engine_denoise_step", "dvd_engine_feat_nchw", "dvd_sched_step",
            "dvd_hyp_mean_clamp", "dvd_unwarp_u8"}
 
 
@@ -116,7 +116,7 @@ def _run_worker(rank, world, port, n_docs, q, tmp):
     val_TDiff.run_evaluation_docunet = spy
     results = val_TDiff.run(s)
     q.put((rank, seen["digest"], [p for p, _ in results], calls.count("dvd_engine_denoise_step"),
-           calls.count("dvd_engine_prepare_docs"), calls.count("dvd_unwarp_u8")))
+           calls.count("dvd_engine_prepare_docs"), calls.count("dvd_unwarp_u8_batch")))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -143,4 +143,43 @@ def test_val_tdiff_run_two_ranks(tmp_path, n_docs):
     assert docs0 == want0 and docs1 == want1
     for docs, den, prep, unw in ((want0, den0, prep0, unw0), (want1, den1, prep1, unw1)):
         batches = (len(docs) + 1) // 2
-        assert den == 3 * batches and prep == batches and unw == len(docs)
+        assert den == 3 * batches and prep == batches and unw == batches      # one batched unwarp launch per batch
+
+
+# ------------------------------------------------------------------------------------------------
+# bench.py's rank logic (the functions its N > 1 branch is made of) under 2 gloo ranks
+# ------------------------------------------------------------------------------------------------
+def _bench_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    from dvd_amd import engine, synth
+    bench.init_dist(world, rank, backend="gloo")
+    grid = 16
+    _, nbytes = engine.blob_layout(grid)
+    blob = engine.pack_blob(synth.synth_state_dict(grid, seed=7, blocks=[11]), grid) if rank == 0 \
+        else torch.empty(nbytes, dtype=torch.uint8)
+    ms = bench.broadcast_weights(blob, world)
+    slowest = bench.max_over_ranks(1.0 + rank, world, torch.device("cpu"))
+    q.put((rank, hashlib.sha256(blob.numpy().tobytes()).hexdigest(), ms is not None and ms >= 0.0, slowest))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_rank_logic_two_ranks():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bench_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=240) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][1] == res[1][1] and res[0][2] and res[1][2]
+    assert res[0][3] == res[1][3] == 2.0          # every rank reports the slowest rank's time

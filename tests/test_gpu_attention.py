@@ -81,9 +81,9 @@ VARIANTS = {
 
 @pytest.mark.parametrize("variant", list(VARIANTS))
 @pytest.mark.parametrize("hd,scale", [(64, 0.125), (256, 0.0625)])
-def test_attention_kernel_variants(ops, monkeypatch, variant, hd, scale):
-    """Every kernel behind a DVD_ATTN_* switch - the production ones selected by problem size and the documented
-    experiments alike - against the float64 reference: ragged query count, shared K/V, a forced rescale."""
+def test_attention_kernel_variants(ops, lab, monkeypatch, variant, hd, scale):
+    """LAB build: every kernel behind a DVD_ATTN_* switch - the production ones forced at a small size and the
+    documented experiments alike - against the float64 reference: ragged query count, shared K/V, a forced rescale."""
     for k, v in VARIANTS[variant].items():
         monkeypatch.setenv(k, v)
     err, mag = run(ops, 4, 2, 300, 512, 6, hd, scale)
@@ -92,7 +92,33 @@ def test_attention_kernel_variants(ops, monkeypatch, variant, hd, scale):
     assert err < 3e-3 * max(1.0, mag), (variant, err, mag)
 
 
-def test_attention_r64_large(ops):
-    """A problem large enough to take the 64-row kernel WITHOUT any switch (>= 512 workgroups of 256 rows)."""
-    err, mag = run(ops, 24, 24, 1024, 512, 6, 256, 0.0625)
-    assert err < 2e-3 * max(1.0, mag), (err, mag)
+PRODUCT_SHAPES = {
+    # the product library picks its kernel from (head_dim, tq, tk) alone - never from the batch, never from the environment
+    "hd256 r64 (tq >= 5376, ragged tq)": (256, 0.0625, 5500, 512),
+    "hd256 glds (tq < 5376)": (256, 0.0625, 1024, 512),
+    "hd256 register-staged (tk % 64 != 0)": (256, 0.0625, 300, 1000),
+    "hd64 glds": (64, 0.125, 5500, 512),
+    "hd64 register-staged (tk % 64 != 0)": (64, 0.125, 300, 1000),
+}
+
+
+@pytest.mark.parametrize("case", list(PRODUCT_SHAPES))
+def test_attention_product_kernels_by_shape(ops, case):
+    hd, scale, tq, tk = PRODUCT_SHAPES[case]
+    err, mag = run(ops, 2, 1, tq, tk, 6, hd, scale)           # shared K/V (kv_batch_div 2)
+    assert err < 2e-3 * max(1.0, mag), (case, err, mag)
+
+
+def test_attention_kernel_choice_is_batch_independent(ops):
+    """One (batch, head) problem gives the same bits alone and inside a large batch (the kernel used to be
+    chosen from the total workgroup count, so the online-softmax tile order changed with the batch size)."""
+    heads, hd, T = 6, 256, 1024
+    C = heads * hd
+    q = torch.from_numpy(synth.normalish("bi/q", (24, T, C), 5)).half().cuda()
+    k = torch.from_numpy(synth.normalish("bi/k", (24, T, C), 5)).half().cuda()
+    vt = torch.from_numpy(synth.normalish("bi/v", (24, C, T), 5)).half().cuda()
+    big = torch.zeros(24, T, C, dtype=torch.float16, device="cuda")
+    ops.flash_attn(q, k, vt, big, heads, hd, 0.0625)
+    one = torch.zeros(1, T, C, dtype=torch.float16, device="cuda")
+    ops.flash_attn(q[17:18].contiguous(), k[17:18].contiguous(), vt[17:18].contiguous(), one, heads, hd, 0.0625)
+    assert torch.equal(one[0], big[17])

@@ -201,3 +201,23 @@ def test_batched_documents_match_single():
         one.prepare(*[torch.from_numpy(ds[d][k][None]).cuda() for k in keys])
         o = sampler.sample(one, tab, xT[2 * d:2 * d + 2].contiguous()).cpu()
         assert torch.equal(o[0], out2[d]), d
+
+
+def test_graph_replay_equals_eager():
+    """A sampling loop whose denoiser evaluations are replayed as captured hipGraphs (the default for small grids) gives
+    the same bits as the eagerly enqueued launch sequence - first use of an address triple runs eagerly, the second
+    captures, later ones replay, so three roll-outs exercise all three."""
+    from dvd_amd import sampler, schedule
+    grid = 16
+    eng, orc, doc_t, inv1 = setup(grid)
+    tab = schedule.Tables(schedule.named_betas("cosine", 10))
+    xT = torch.from_numpy(synth.synth_noise(0, 2, grid, SEED_IN)).cuda()
+    try:
+        eng.set_option("graphs", 0)
+        eager = sampler.sample(eng, tab, xT).clone()
+        eng.set_option("graphs", 1)
+        runs = [sampler.sample(eng, tab, xT).clone() for _ in range(3)]
+    finally:
+        eng.set_option("graphs", 1)
+    for r in runs:
+        assert torch.equal(r, eager)

@@ -174,12 +174,9 @@ def test_gemm_fused_split_kernel(ops, M, N, K):
     e_fused = (out.cpu().double() - ref).abs().max().item()
     ops.gemm_nt(a.cuda(), hi.cuda(), out32=out)
     e_plain = (out.cpu().double() - ref).abs().max().item()
-    os.environ["DVD_GEMM_TWOPASS"] = "1"
-    try:
-        out2 = torch.zeros(M, N, device="cuda")
-        ops.gemm_nt(a.cuda(), hi.cuda(), out32=out2, b_lo=lo.cuda(), lo_scale=1.0)
-    finally:
-        os.environ.pop("DVD_GEMM_TWOPASS")
+    # the two-pass path of the product: a SCALED lo part (lo_scale != 1) sweeps K twice
+    out2 = torch.zeros(M, N, device="cuda")
+    ops.gemm_nt(a.cuda(), hi.cuda(), out32=out2, b_lo=((w - hi.float()) * 2048.0).half().cuda(), lo_scale=2.0 ** -11)
     e_two = (out2.cpu().double() - ref).abs().max().item()
     print("fused split", M, N, K, e_plain, e_fused, e_two)
     assert e_fused < 3e-5 * (K / 1536) ** 0.5 + 2e-6 and e_fused < e_plain / 10, (e_plain, e_fused, e_two)
@@ -207,8 +204,8 @@ def test_gemm_fused_split_kernel(ops, M, N, K):
 @pytest.mark.parametrize("env", [{}, {"DVD_GEMM_TWOPASS": "1"}, {"DVD_GEMM_V1": "1"}, {"DVD_GEMM_SPREAD": "1"},
                                  {"DVD_GEMM_SCALAR_EPILOGUE": "1"}, {"DVD_GEMM_NONPERSISTENT": "1"}],
                          ids=lambda e: next(iter(e), "default"))
-def test_gemm_kernel_variants(ops, monkeypatch, env):
-    """Every GEMM path behind a DVD_GEMM_* switch: split weights (scaled and unscaled lo), residual + bias + ReLU, f16
+def test_gemm_kernel_variants(ops, lab, monkeypatch, env):
+    """LAB build: every GEMM path behind a DVD_GEMM_* switch: split weights (scaled and unscaled lo), residual + bias + ReLU, f16
     output with GELU, ragged M - against float64."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)

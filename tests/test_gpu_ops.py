@@ -109,7 +109,8 @@ def test_unwarp_full_size_properties(ops):
 
 
 def _both_paths(fn):
-    """Run fn() with the row-per-wave fast kernels and again with the scalar fallback kernels (DVD_WARP_SCALAR=1)."""
+    """Run fn() with the row-per-wave fast kernels and again with the scalar fallback kernels forced
+    (DVD_WARP_SCALAR=1 - a switch of the LAB build only: callers take the `lab` fixture)."""
     os.environ.pop("DVD_WARP_SCALAR", None)
     fast = fn()
     os.environ["DVD_WARP_SCALAR"] = "1"
@@ -121,7 +122,7 @@ def _both_paths(fn):
 
 
 @pytest.mark.parametrize("shape", [(2, 3, 37, 53, 41, 129), (1, 7, 64, 2, 5, 200), (1, 2, 9, 1, 8, 8), (1, 9, 33, 65, 3, 1)])
-def test_grid_sample_fast_equals_fallback_and_oracle(ops, shape):
+def test_grid_sample_fast_equals_fallback_and_oracle(ops, lab, shape):
     """Pair-gather kernel == scalar kernel bit for bit (same products, same blend order), incl. wild / non-finite
     coordinates, borders, win = 2 (every tap pair clamped) and win = 1 (fast path not applicable)."""
     from oracle import dvd_oracle as O
@@ -145,7 +146,7 @@ def test_grid_sample_fast_equals_fallback_and_oracle(ops, shape):
 
 
 @pytest.mark.parametrize("hw", [(97, 132), (64, 4), (31, 130), (5, 8)])
-def test_unwarp_fast_equals_fallback(ops, hw):
+def test_unwarp_fast_equals_fallback(ops, lab, hw):
     """Fused tails: fast kernels == scalar kernels bit for bit, flows that push taps outside the image on all sides;
     widths that are / are not multiples of 4 (the u8 fast path needs w % 4 == 0)."""
     H, W = hw
@@ -161,7 +162,7 @@ def test_unwarp_fast_equals_fallback(ops, hw):
     assert (f_fast == 0).any() and (f_fast > 0).any()        # zero padding was exercised
 
 
-def test_unwarp_full_size_fast_equals_fallback(ops):
+def test_unwarp_full_size_fast_equals_fallback(ops, lab):
     H, W, G = 3508, 2480, 288
     ctrl = torch.from_numpy(synth.uniform("uwf/ctrl", (1, 2, 6, 6), -0.05, 0.05, 1))
     flow = torch.nn.functional.interpolate(ctrl, size=(G, G), mode="bicubic", align_corners=True).contiguous().cuda()
@@ -224,3 +225,18 @@ def test_hyp_mean_clamp(ops):
     out = ops.hyp_mean_clamp(x0.cuda(), 2).cpu()
     ref = torch.stack([torch.clamp(x0[2 * d:2 * d + 2].mean(0), -1, 1) for d in range(3)])
     assert torch.equal(out, ref)
+
+
+def test_unwarp_batch_equals_per_document(ops):
+    """One launch for the documents of a batch (grid z) == one launch per document, bit for bit (u8 and f32,
+    fast-path width and a ragged width that takes the fallback kernel)."""
+    for h, w in ((96, 128), (57, 45)):
+        flow = torch.from_numpy(synth.uniform("ub/flow", (3, 2, 16, 16), -0.2, 0.2, 9)).cuda()
+        src8 = torch.from_numpy(synth.synth_document(0, 8, 3, full_res=(3 * h, w))["src_u8"]).reshape(3, h, w, 3).cuda()
+        got = ops.unwarp_u8_batch(flow, src8)
+        for d in range(3):
+            assert torch.equal(got[d], ops.unwarp_u8(flow[d:d + 1].contiguous(), src8[d].contiguous()))
+        srcf = src8.permute(0, 3, 1, 2).float().contiguous()
+        gotf = ops.unwarp_f32_batch(flow, srcf)
+        for d in range(3):
+            assert torch.equal(gotf[d], ops.unwarp_f32(flow[d:d + 1].contiguous(), srcf[d:d + 1].contiguous()))

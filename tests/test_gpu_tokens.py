@@ -78,11 +78,19 @@ def test_dwconv_bn_relu(ops, side):
     out = ops.dwconv3x3(x16.cuda(), w9c.cuda(), b.cuda(), n, side).float().cpu()
     got = out.reshape(n, side, side, c).permute(0, 3, 1, 2)
     assert (got - ref).abs().max() < 6e-3
-    os.environ["DVD_DWCONV_V1"] = "1"        # the one-token-per-thread kernel: same tap order -> bit-identical
-    try:
-        out_v1 = ops.dwconv3x3(x16.cuda(), w9c.cuda(), b.cuda(), n, side).float().cpu()
-    finally:
-        os.environ.pop("DVD_DWCONV_V1")
+
+
+@pytest.mark.parametrize("side", [8, 7, 13])
+def test_dwconv_row4_equals_v1(ops, lab, monkeypatch, side):
+    """Lab build: the product kernel (4 tokens per thread along a grid row) against the one-token-per-thread kernel it
+    replaced (DVD_DWCONV_V1=1): same tap order -> bit-identical."""
+    n, c = 2, 2048
+    x16 = rnd("dw/x", (n * side * side, c), -1, 2).half().contiguous()
+    w9c = rnd("dw/w9", (9, c), -0.5, 0.5)
+    b = rnd("dw/b", (c,), -0.3, 0.3)
+    out = ops.dwconv3x3(x16.cuda(), w9c.cuda(), b.cuda(), n, side).float().cpu()
+    monkeypatch.setenv("DVD_DWCONV_V1", "1")
+    out_v1 = ops.dwconv3x3(x16.cuda(), w9c.cuda(), b.cuda(), n, side).float().cpu()
     assert torch.equal(out, out_v1)
 
 
