@@ -53,7 +53,10 @@ _DEFAULTS = {
     "sampler": "ddim",       # 'ddim' | 'ddpm'
     "num_synthetic_docs": 4,
     "full_res": (1024, 768), # synthetic full-resolution source size (H, W)
-    "conditioning_dir": "",
+    "conditioning_dir": "",   # directory of per-document conditioning .npz files (skips ingest + pre-stage nets)
+    # run the pre-stage conditioning nets (GeoTr_Seg_Inf.msk, Seg, line UNet; reference evaluation.py:162-216) on the
+    # document images, as the reference does; False = synthetic documents carry random conditioning tensors
+    "use_prestage_nets": True,
     # None = only when eval_dataset_name == 'synthetic' (a missing checkpoint on a real dataset raises)
     "synthetic_weights_if_missing": None,
 }

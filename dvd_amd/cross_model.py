@@ -59,25 +59,27 @@ class DvdDenoiser(nn.Module):
         return res
 
     # ---- engine plumbing ------------------------------------------------------------------------------
+    # ---- flat weight blob: dist_util.materialize_blobs([...]) packs on rank 0, ONE broadcast, every rank binds ----
+    def blob_bytes(self) -> int:
+        from .engine import blob_layout
+        return blob_layout(self.input_size)[1]
+
+    def pack_into(self, view_u8: torch.Tensor):
+        from .engine import pack_blob
+        view_u8.copy_(pack_blob({k: v.detach().cpu() for k, v in self.state_dict().items()}, self.input_size))
+
+    def bind_blob(self, view_u8: torch.Tensor):
+        self._blob, self._blob_version = view_u8, self._version
+
     def materialize_blob(self, src: int = 0):
         """Pack the current parameters into the engine's flat weight blob on rank `src` and hand it to every rank
         with ONE flat broadcast (RCCL over xGMI) - the sampling path's only collective.  COLLECTIVE: every rank of
-        the process group must call it, unconditionally and at the same point (val_TDiff.run does, right after
-        model.to(dev)); `engine()` itself never communicates, so a rank with an empty document shard cannot leave
-        the others waiting in a broadcast.  Ranks other than `src` never read their own (unloaded) parameters."""
+        the process group must call it, unconditionally and at the same point; `engine()` itself never communicates,
+        so a rank with an empty document shard cannot leave the others waiting in a broadcast.  (val_TDiff.run
+        broadcasts this model together with the pre-stage nets: dist_util.materialize_blobs.)"""
         from . import dist_util
-        from .engine import blob_layout, pack_blob
-        dev = self.device
-        _require_gpu(dev)
-        total = blob_layout(self.input_size)[1]
-        store = torch.empty(total + 256, dtype=torch.uint8, device=dev)      # the engine wants 256-byte alignment
-        off = (-store.data_ptr()) % 256
-        blob = store[off:off + total]
-        if dist_util.rank() == src:
-            sd = {k: v.detach().cpu() for k, v in self.state_dict().items()}
-            blob.copy_(pack_blob(sd, self.input_size))
-        self._blob = dist_util.broadcast_blob(blob, src=src)
-        self._blob_version = self._version
+        _require_gpu(self.device)
+        dist_util.materialize_blobs([self], src=src)
         return self._blob
 
     def engine(self, grid: int, docs: int, n_hyp: int) -> Engine:

@@ -1,0 +1,346 @@
+// A small convolutional-network executor for the PRE-STAGE conditioning nets of the sampling path
+// (SURVEY 8(f) rank 1): the two U2NETP document-mask nets and the text-line UNet that run once per
+// document before the diffusion loop (train_settings/dvd/evaluation.py:162-216;
+// train_settings/models/geotr/geotr_core.py:24-46,48-330,745-845; unet_model.py:4-37; unet_parts.py:8-77).
+//
+// The host describes a net as a flat op list over numbered activation slots (dvd_cn_op, include/dvd_hip.h);
+// this file plans the slots in one caller-provided workspace and enqueues, per op:
+//   conv (3x3 dilated or 1x1, optional channel-concat of two sources, eval-mode BatchNorm folded into the
+//         weights on the host, bias, optional ReLU) = one gather kernel (im2col with the concat and the
+//         dilation folded in) + the library's exact-f32 MFMA GEMM (v_mfma_f32_32x32x2_f32: fp32 products,
+//         fp32 accumulate - the conditioning reused by every denoising step carries no low-precision error);
+//   max-pool 2x2 / stride 2 (ceil_mode), bilinear resize (align_corners on or off), add, sigmoid.
+// Activations are channels-last f32 ([H*W, C] row-major = the GEMM's C matrix, so a conv writes its output
+// with no transpose).  Everything only enqueues on the caller's stream; nothing allocates or synchronises.
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "common.h"
+
+namespace dvd {
+
+struct CnSlot { int h = 0, w = 0, c = 0; size_t off = 0; bool set = false; };
+
+struct ConvNet {
+  std::vector<dvd_cn_op> ops;
+  std::vector<CnSlot> slots;
+  std::vector<int> kpad;       // per op (conv only): padded K
+  size_t col_off = 0, col_bytes = 0, need_bytes = 0;
+  long weight_floats = 0;
+  int in_c, in_h, in_w;
+};
+
+static inline size_t al256(size_t b) { return (b + 255) & ~(size_t)255; }
+
+// in: planar [C,H,W] -> out: [H*W, C]
+__global__ void __launch_bounds__(256) nchw_to_nhwc_kernel(const float* __restrict__ in, float* __restrict__ out, int c,
+                                                          long hw) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= hw * c) return;
+  const long p = i / c;
+  const int ch = (int)(i - p * c);
+  out[i] = in[(long)ch * hw + p];
+}
+
+// col[p, tap * (ca + cb) + ch] = src(ch)[y + (ky - r) * dil, x + (kx - r) * dil] (zero outside); columns >= ks*ks*(ca+cb)
+// are zero.  One thread per (pixel, 4 consecutive K entries): channels-last sources make the reads contiguous.
+__global__ void __launch_bounds__(256) im2col_cat_kernel(const float* __restrict__ a, int ca, const float* __restrict__ b,
+                                                         int cb, float* __restrict__ col, int kp, int ks, int dil,
+                                                         int h, int w, long total4) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total4) return;
+  const int kq = kp / 4;
+  const long p = i / kq;
+  const int k0 = (int)(i - p * kq) * 4;
+  const int y = (int)(p / w), x = (int)(p - (long)y * w);
+  const int cc = ca + cb, kreal = ks * ks * cc, r = ks / 2;
+  float v[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int k = k0 + j;
+    float val = 0.f;
+    if (k < kreal) {
+      const int tap = k / cc, ch = k - tap * cc;
+      const int yy = y + (tap / ks - r) * dil, xx = x + (tap % ks - r) * dil;
+      if (yy >= 0 && yy < h && xx >= 0 && xx < w) {
+        const long q = (long)yy * w + xx;
+        val = ch < ca ? a[q * ca + ch] : b[q * cb + (ch - ca)];
+      }
+    }
+    v[j] = val;
+  }
+  *reinterpret_cast<float4*>(col + p * kp + k0) = make_float4(v[0], v[1], v[2], v[3]);
+}
+
+// nn.MaxPool2d(2, stride=2, ceil_mode): windows are clipped at the border
+__global__ void __launch_bounds__(256) maxpool2_ceil_kernel(const float* __restrict__ in, float* __restrict__ out, int c,
+                                                            int h, int w, int ho, int wo, long total) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int ch = (int)(i % c);
+  const long p = i / c;
+  const int x = (int)(p % wo), y = (int)(p / wo);
+  const int y0 = 2 * y, x0 = 2 * x, y1 = min(y0 + 1, h - 1), x1 = min(x0 + 1, w - 1);
+  const float m0 = fmaxf(in[((long)y0 * w + x0) * c + ch], in[((long)y0 * w + x1) * c + ch]);
+  const float m1 = fmaxf(in[((long)y1 * w + x0) * c + ch], in[((long)y1 * w + x1) * c + ch]);
+  out[i] = fmaxf(m0, m1);
+}
+
+// F.interpolate(mode='bilinear') source index (ATen area_pixel_compute_source_index) and weights
+__device__ __forceinline__ void bil_index(int dst, int in_size, int out_size, int align, int& i0, int& i1, float& l1) {
+  float src;
+  if (align) {
+    const float scale = out_size > 1 ? (float)(in_size - 1) / (float)(out_size - 1) : 0.f;
+    src = scale * (float)dst;
+  } else {
+    const float scale = (float)in_size / (float)out_size;
+    src = fmaxf(scale * ((float)dst + 0.5f) - 0.5f, 0.f);
+  }
+  i0 = min((int)src, in_size - 1);
+  i1 = min(i0 + 1, in_size - 1);
+  l1 = src - (float)i0;
+}
+
+// channels-last resize; ATen's blend order: l0y * (l0x * v00 + l1x * v01) + l1y * (l0x * v10 + l1x * v11)
+__global__ void __launch_bounds__(256) resize_nhwc_kernel(const float* __restrict__ in, float* __restrict__ out, int c,
+                                                          int hin, int win, int hout, int wout, int align, long total) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int ch = (int)(i % c);
+  const long p = i / c;
+  const int x = (int)(p % wout), y = (int)(p / wout);
+  int y0, y1, x0, x1;
+  float ly, lx;
+  bil_index(y, hin, hout, align, y0, y1, ly);
+  bil_index(x, win, wout, align, x0, x1, lx);
+  const float hy = 1.f - ly, hx = 1.f - lx;
+  const float v00 = in[((long)y0 * win + x0) * c + ch], v01 = in[((long)y0 * win + x1) * c + ch];
+  const float v10 = in[((long)y1 * win + x0) * c + ch], v11 = in[((long)y1 * win + x1) * c + ch];
+  out[i] = hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11);
+}
+
+// planar resize: `planes` independent [hin, win] images
+__global__ void __launch_bounds__(256) resize_planar_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                            int hin, int win, int hout, int wout, int align, long total) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int x = (int)(i % wout);
+  const long q = i / wout;
+  const int y = (int)(q % hout);
+  const long pl = q / hout;
+  int y0, y1, x0, x1;
+  float ly, lx;
+  bil_index(y, hin, hout, align, y0, y1, ly);
+  bil_index(x, win, wout, align, x0, x1, lx);
+  const float hy = 1.f - ly, hx = 1.f - lx;
+  const float* s = in + pl * (long)hin * win;
+  out[i] = hy * (hx * s[(long)y0 * win + x0] + lx * s[(long)y0 * win + x1]) +
+           ly * (hx * s[(long)y1 * win + x0] + lx * s[(long)y1 * win + x1]);
+}
+
+__global__ void __launch_bounds__(256) add_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                  float* __restrict__ out, long n) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = a[i] + b[i];
+}
+
+__global__ void __launch_bounds__(256) sigmoid_kernel(const float* __restrict__ a, float* __restrict__ out, long n) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = 1.f / (1.f + expf(-a[i]));
+}
+
+// out[ch, p] = (d0[p] > thr ? 1 : 0) * x[ch, p]        (Seg.forward, geotr_core.py:989-990)
+__global__ void __launch_bounds__(256) mask_mul_kernel(const float* __restrict__ d0, const float* __restrict__ x,
+                                                       float* __restrict__ out, float* __restrict__ mask_out, int c,
+                                                       long hw, float thr) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= hw) return;
+  const float m = d0[i] > thr ? 1.f : 0.f;
+  if (mask_out) mask_out[i] = m;
+  for (int ch = 0; ch < c; ++ch) out[(long)ch * hw + i] = m * x[(long)ch * hw + i];
+}
+
+}  // namespace dvd
+
+using namespace dvd;
+
+extern "C" int dvd_nhwc_to_nchw(const float*, float*, int, int, int, void*);
+
+extern "C" int dvd_convnet_create(const dvd_cn_op* ops, int n_ops, int n_slots, int in_c, int in_h, int in_w,
+                                  void** handle) {
+  DVD_REQUIRE(ops && handle && n_ops > 0 && n_slots > 1, "convnet_create: bad arguments");
+  DVD_REQUIRE(in_c > 0 && in_h > 0 && in_w > 0, "convnet_create: bad input shape");
+  ConvNet* n = new ConvNet();
+  n->ops.assign(ops, ops + n_ops);
+  n->slots.resize(n_slots);
+  n->kpad.assign(n_ops, 0);
+  n->in_c = in_c; n->in_h = in_h; n->in_w = in_w;
+  n->slots[0].h = in_h; n->slots[0].w = in_w; n->slots[0].c = in_c; n->slots[0].set = true;
+  size_t off = 0, colmax = 0;
+  n->slots[0].off = 0;
+  off = al256((size_t)in_h * in_w * in_c * 4);
+  long wf = 0;
+  auto fail = [&](const char* msg, int i) {
+    set_error("convnet_create: op %d: %s", i, msg);
+    delete n;
+    return DVD_E_ARG;
+  };
+  for (int i = 0; i < n_ops; ++i) {
+    const dvd_cn_op& o = n->ops[i];
+    if (o.a < 0 || o.a >= n_slots || !n->slots[o.a].set) return fail("input slot not defined", i);
+    if (o.dst <= 0 || o.dst >= n_slots || n->slots[o.dst].set) return fail("bad or already written destination slot", i);
+    if (o.b >= n_slots || (o.b >= 0 && !n->slots[o.b].set)) return fail("second input slot not defined", i);
+    const CnSlot& a = n->slots[o.a];
+    CnSlot d;
+    d.set = true;
+    switch (o.op) {
+      case DVD_CN_CONV: {
+        if ((o.ks != 1 && o.ks != 3) || o.dil < 1 || o.cout < 1) return fail("bad conv parameters", i);
+        int cin = a.c;
+        if (o.b >= 0) {
+          const CnSlot& b = n->slots[o.b];
+          if (b.h != a.h || b.w != a.w) return fail("concat sources differ in size", i);
+          cin += b.c;
+        }
+        const int kp = (o.ks * o.ks * cin + 15) / 16 * 16;
+        n->kpad[i] = kp;
+        if (o.w_off != wf) return fail("weights must be packed in op order (w_off mismatch)", i);
+        wf += (long)o.cout * kp + o.cout;
+        colmax = std::max(colmax, (size_t)a.h * a.w * kp * 4);
+        d.h = a.h; d.w = a.w; d.c = o.cout;
+        break;
+      }
+      case DVD_CN_POOL:
+        d.h = o.flag ? (a.h + 1) / 2 : a.h / 2; d.w = o.flag ? (a.w + 1) / 2 : a.w / 2; d.c = a.c;
+        if (d.h < 1 || d.w < 1) return fail("pool of a 1-pixel map", i);
+        break;
+      case DVD_CN_RESIZE:
+        if (o.b >= 0) { d.h = n->slots[o.b].h; d.w = n->slots[o.b].w; } else { d.h = o.h; d.w = o.w; }
+        if (d.h < 1 || d.w < 1) return fail("bad resize target", i);
+        d.c = a.c;
+        break;
+      case DVD_CN_ADD: {
+        if (o.b < 0) return fail("add needs two inputs", i);
+        const CnSlot& b = n->slots[o.b];
+        if (b.h != a.h || b.w != a.w || b.c != a.c) return fail("add operands differ in shape", i);
+        d.h = a.h; d.w = a.w; d.c = a.c;
+        break;
+      }
+      case DVD_CN_SIGMOID:
+        d.h = a.h; d.w = a.w; d.c = a.c;
+        break;
+      default:
+        return fail("unknown op", i);
+    }
+    d.off = off;
+    off += al256((size_t)d.h * d.w * d.c * 4);
+    n->slots[o.dst] = d;
+  }
+  n->col_off = off; n->col_bytes = al256(colmax);
+  n->need_bytes = off + n->col_bytes;
+  n->weight_floats = wf;
+  *handle = n;
+  return DVD_OK;
+}
+
+extern "C" int dvd_convnet_destroy(void* handle) {
+  delete (ConvNet*)handle;
+  return DVD_OK;
+}
+
+extern "C" long dvd_convnet_workspace_bytes(void* handle) { return handle ? (long)((ConvNet*)handle)->need_bytes : -1; }
+extern "C" long dvd_convnet_weight_floats(void* handle) { return handle ? ((ConvNet*)handle)->weight_floats : -1; }
+
+extern "C" int dvd_convnet_slot_shape(void* handle, int slot, int* h, int* w, int* c) {
+  DVD_REQUIRE(handle && h && w && c, "convnet_slot_shape: null pointer");
+  ConvNet* n = (ConvNet*)handle;
+  DVD_REQUIRE(slot >= 0 && slot < (int)n->slots.size() && n->slots[slot].set, "convnet_slot_shape: slot %d not defined", slot);
+  *h = n->slots[slot].h; *w = n->slots[slot].w; *c = n->slots[slot].c;
+  return DVD_OK;
+}
+
+extern "C" int dvd_convnet_run(void* handle, const float* in_nchw, const float* weights, void* workspace,
+                               long workspace_bytes, int n_out, const int* out_slots, float* const* out_nchw,
+                               void* stream) {
+  DVD_REQUIRE(handle && in_nchw && weights && workspace, "convnet_run: null pointer");
+  DVD_REQUIRE(n_out >= 0 && (n_out == 0 || (out_slots && out_nchw)), "convnet_run: bad outputs");
+  ConvNet* n = (ConvNet*)handle;
+  DVD_REQUIRE((size_t)workspace_bytes >= n->need_bytes && ((uintptr_t)workspace % 256) == 0 &&
+                  ((uintptr_t)weights % 16) == 0,
+              "convnet_run: need %zu workspace bytes, 256-byte aligned (got %ld)", n->need_bytes, workspace_bytes);
+  hipStream_t st = (hipStream_t)stream;
+  char* ws = (char*)workspace;
+  auto P = [&](int slot) { return (float*)(ws + n->slots[slot].off); };
+  float* col = (float*)(ws + n->col_off);
+  {
+    const long hw = (long)n->in_h * n->in_w;
+    nchw_to_nhwc_kernel<<<cdiv(hw * n->in_c, 256), 256, 0, st>>>(in_nchw, P(0), n->in_c, hw);
+  }
+  for (size_t i = 0; i < n->ops.size(); ++i) {
+    const dvd_cn_op& o = n->ops[i];
+    const CnSlot& a = n->slots[o.a];
+    const CnSlot& d = n->slots[o.dst];
+    const long nd = (long)d.h * d.w * d.c;
+    switch (o.op) {
+      case DVD_CN_CONV: {
+        const int kp = n->kpad[i];
+        const int cb = o.b >= 0 ? n->slots[o.b].c : 0;
+        const float* A = P(o.a);
+        int lda = a.c;
+        if (!(o.ks == 1 && o.b < 0 && a.c == kp)) {   // a 1x1 conv over a 16-aligned single source reads the slot directly
+          const long total4 = (long)a.h * a.w * (kp / 4);
+          im2col_cat_kernel<<<cdiv(total4, 256), 256, 0, st>>>(P(o.a), a.c, o.b >= 0 ? P(o.b) : nullptr, cb, col, kp,
+                                                              o.ks, o.dil, a.h, a.w, total4);
+          A = col; lda = kp;
+        }
+        dvd_gemm_desc g;
+        memset(&g, 0, sizeof(g));
+        g.dtype = 1; g.M = a.h * a.w; g.N = o.cout; g.K = kp; g.batch = 1;
+        g.A = A; g.lda = lda; g.B = weights + o.w_off; g.ldb = kp;
+        g.C32 = P(o.dst); g.ldc = o.cout;
+        g.bias = weights + o.w_off + (long)o.cout * kp; g.act = o.act;
+        g.lo_scale = 1.f;
+        if (int e = dvd_gemm_nt(&g, stream)) return e;
+        break;
+      }
+      case DVD_CN_POOL:
+        maxpool2_ceil_kernel<<<cdiv(nd, 256), 256, 0, st>>>(P(o.a), P(o.dst), a.c, a.h, a.w, d.h, d.w, nd);
+        break;
+      case DVD_CN_RESIZE:
+        resize_nhwc_kernel<<<cdiv(nd, 256), 256, 0, st>>>(P(o.a), P(o.dst), a.c, a.h, a.w, d.h, d.w, o.flag, nd);
+        break;
+      case DVD_CN_ADD:
+        add_kernel<<<cdiv(nd, 256), 256, 0, st>>>(P(o.a), P(o.b), P(o.dst), nd);
+        break;
+      case DVD_CN_SIGMOID:
+        sigmoid_kernel<<<cdiv(nd, 256), 256, 0, st>>>(P(o.a), P(o.dst), nd);
+        break;
+    }
+  }
+  for (int k = 0; k < n_out; ++k) {
+    const int s = out_slots[k];
+    DVD_REQUIRE(s >= 0 && s < (int)n->slots.size() && n->slots[s].set && out_nchw[k], "convnet_run: bad output %d", k);
+    if (int e = dvd_nhwc_to_nchw(P(s), out_nchw[k], n->slots[s].c, n->slots[s].h, n->slots[s].w, stream)) return e;
+  }
+  return check_launch("convnet_run");
+}
+
+extern "C" int dvd_resize_bilinear_nchw(const float* in, float* out, long planes, int hin, int win, int hout, int wout,
+                                        int align_corners, void* stream) {
+  DVD_REQUIRE(in && out, "resize_bilinear_nchw: null pointer");
+  DVD_REQUIRE(planes >= 0 && hin > 0 && win > 0 && hout > 0 && wout > 0, "resize_bilinear_nchw: bad shape");
+  const long total = planes * hout * wout;
+  if (total == 0) return DVD_OK;
+  resize_planar_kernel<<<cdiv(total, 256), 256, 0, (hipStream_t)stream>>>(in, out, hin, win, hout, wout,
+                                                                         align_corners ? 1 : 0, total);
+  return check_launch("resize_bilinear_nchw");
+}
+
+extern "C" int dvd_threshold_mask_mul(const float* d0, const float* x_nchw, float* out_nchw, float* mask_out, int c,
+                                      long hw, float thr, void* stream) {
+  DVD_REQUIRE(d0 && x_nchw && out_nchw && c > 0 && hw > 0, "threshold_mask_mul: bad arguments");
+  mask_mul_kernel<<<cdiv(hw, 256), 256, 0, (hipStream_t)stream>>>(d0, x_nchw, out_nchw, mask_out, c, hw, thr);
+  return check_launch("threshold_mask_mul");
+}

@@ -66,6 +66,29 @@ def broadcast_blob(blob: th.Tensor, src: int = 0) -> th.Tensor:
     return blob
 
 
+def materialize_blobs(models, src: int = 0):
+    """Rank `src` packs every model's weights into ONE flat device buffer; ONE broadcast hands it to every rank; each
+    model binds its slice.  COLLECTIVE - every rank calls it at the same point, unconditionally (val_TDiff.run does,
+    before the documents are sharded).  A model provides blob_bytes() (computable without its weights), pack_into(view)
+    and bind_blob(view); the models' own compute paths never communicate."""
+    models = list(models)
+    dev = models[0].device
+    offs, total = [], 0
+    for m in models:
+        offs.append(total)
+        total += (m.blob_bytes() + 255) // 256 * 256
+    store = th.empty(total + 256, dtype=th.uint8, device=dev)
+    base = (-store.data_ptr()) % 256
+    flat = store[base:base + total]
+    if rank() == src:
+        for m, off in zip(models, offs):
+            m.pack_into(flat[off:off + m.blob_bytes()])
+    broadcast_blob(flat, src=src)
+    for m, off in zip(models, offs):
+        m.bind_blob(flat[off:off + m.blob_bytes()])
+    return flat
+
+
 def sync_params(params):
     """Reference API (one broadcast per tensor); kept for compatibility, the engine uses broadcast_blob."""
     for p in params:

@@ -1,8 +1,9 @@
 """Per-document driver of the sampling path - mirror of train_settings/dvd/evaluation.py
 (`run_sample_lr_dewarping` :80-138, the tail of `run_evaluation_docunet` :245-306) on the HIP engine.
 
-The pre-stage conditioning nets (evaluation.py:162-216) are outside this path: documents arrive
-as dicts of conditioning tensors (synthetic or loaded from .npz), i.e. exactly the tensors those nets produce."""
+Documents arrive either as decoded images (dict key "image_u8": [H,W,3] uint8 RGB) - then the ingest kernel
+(doc_benchmark.py:75-97) and the pre-stage conditioning nets (evaluation.py:162-216, dvd_amd/prestage.py) run first -
+or as dicts of ready conditioning tensors (synthetic or loaded from .npz), i.e. exactly the tensors those nets produce."""
 from __future__ import annotations
 
 import os
@@ -34,10 +35,27 @@ def run_sample_lr_dewarping(settings, logger, diffusion, model, source, feature_
 
 
 def synthetic_documents(settings, indices):
+    """Synthetic documents: with env.use_prestage_nets a page-like IMAGE (the whole pipeline runs: ingest -> pre-stage
+    nets -> sampler -> unwarp), otherwise random conditioning tensors in the value ranges of SURVEY 8(d)."""
     G = settings.env.grid_size
     for i in indices:
-        d = synth.synth_document(i, G, seed=1234, full_res=tuple(settings.env.full_res))
+        if getattr(settings.env, "use_prestage_nets", False):
+            h, w = settings.env.full_res
+            img = synth.smooth_image(f"doc{i}/image", h, w, seed=1234)
+            d = {"image_u8": np.ascontiguousarray((img.transpose(1, 2, 0) * 255.0).astype(np.uint8))}
+        else:
+            d = synth.synth_document(i, G, seed=1234, full_res=tuple(settings.env.full_res))
         d["path"] = f"synthetic_{i:05d}"
+        yield d
+
+
+def image_documents(settings, indices, files):
+    """Image files of a benchmark directory (doc_benchmark.py:60-62,80-83): decoded on the CPU (PIL -> RGB uint8);
+    everything after the decode runs on the GPU."""
+    from PIL import Image
+    for i in indices:
+        d = {"image_u8": np.ascontiguousarray(np.asarray(Image.open(files[i]).convert("RGB"), dtype=np.uint8))}
+        d["path"] = os.path.splitext(os.path.basename(files[i]))[0]
         yield d
 
 
@@ -49,9 +67,30 @@ def npz_documents(settings, indices, files):
         yield d
 
 
-def run_evaluation_docunet(settings, logger, documents, diffusion, model, device):
-    """Document loop (evaluation.py:142-327): batches `batch_docs` documents, samples, unwarps the full-resolution
-    u8 source with the fused HIP kernel and (if env.visualize) writes PNGs where the reference writes them."""
+def prepare_conditioning(batch, device, grid, prestage_models):
+    """Documents given as decoded images: ingest (cv2.resize to 512^2, / 255; doc_benchmark.py:84-88) and the pre-stage
+    nets (evaluation.py:162-216) fill in y512 / mask_cat / mask_y512 / line_msk / src_u8 as DEVICE tensors."""
+    from . import prestage
+    if prestage_models is None:
+        raise RuntimeError("documents were given as images but the pre-stage nets are not loaded (env.use_prestage_nets)")
+    for d in batch:
+        if "image_u8" not in d or "y512" in d:
+            continue
+        img = th.from_numpy(d["image_u8"]).to(device)
+        d["y512"], d["src_u8"] = ops.ingest_u8(img, swap_rb=False, out_size=512, want_rgb=True)
+    todo = [d for d in batch if "mask_cat" not in d]
+    if todo:
+        src = th.stack([d["y512"] if th.is_tensor(d["y512"]) else th.from_numpy(d["y512"]).to(device) for d in todo])
+        cond = prestage.conditioning(*prestage_models, src, grid)
+        for j, d in enumerate(todo):
+            for k in ("mask_cat", "mask_y512", "line_msk"):
+                d[k] = cond[k][j]
+
+
+def run_evaluation_docunet(settings, logger, documents, diffusion, model, device, prestage_models=None):
+    """Document loop (evaluation.py:142-327): batches `batch_docs` documents, runs ingest + the pre-stage nets for
+    documents given as images, samples, unwarps the full-resolution u8 source with the fused HIP kernel and (if
+    env.visualize) writes PNGs where the reference writes them."""
     env = settings.env
     out_dir = f"vis_hp/{env.eval_dataset_name}/{settings.name}/dewarped_pred"
     if env.visualize:
@@ -63,7 +102,9 @@ def run_evaluation_docunet(settings, logger, documents, diffusion, model, device
         if not batch:
             return
         nb = len(batch)
-        stack = lambda k: th.from_numpy(np.stack([d[k] for d in batch])).to(device)  # noqa: E731
+        dev_t = lambda v: v.to(device) if th.is_tensor(v) else th.from_numpy(v).to(device)  # noqa: E731
+        stack = lambda k: th.stack([dev_t(d[k]) for d in batch]).contiguous()  # noqa: E731
+        prepare_conditioning(batch, device, G, prestage_models)
         t0 = time.time()
         model_docs = nb
         src, msk, seg, line = stack("y512"), stack("mask_cat"), stack("mask_y512"), stack("line_msk")
@@ -73,11 +114,10 @@ def run_evaluation_docunet(settings, logger, documents, diffusion, model, device
         th.cuda.synchronize()
         times.append((time.time() - t0) / model_docs)
         # :301-306 + viz :75-77 - one launch for the batch when its documents share a full-resolution size
-        if len({d["src_u8"].shape for d in batch}) == 1:
+        if len({tuple(d["src_u8"].shape) for d in batch}) == 1:
             outs = ops.unwarp_u8_batch(flow.contiguous(), stack("src_u8"))
         else:
-            outs = [ops.unwarp_u8(flow[j:j + 1].contiguous(), th.from_numpy(d["src_u8"]).to(device))
-                    for j, d in enumerate(batch)]
+            outs = [ops.unwarp_u8(flow[j:j + 1].contiguous(), dev_t(d["src_u8"]).contiguous()) for j, d in enumerate(batch)]
         for j, d in enumerate(batch):
             out = outs[j]
             results.append((d["path"], out))

@@ -68,8 +68,15 @@ class AttnDesc(C.Structure):
                 ("scale", C.c_float)]
 
 
+class CnOp(C.Structure):
+    _fields_ = [("op", C.c_int), ("a", C.c_int), ("b", C.c_int), ("dst", C.c_int), ("ks", C.c_int), ("dil", C.c_int),
+                ("cout", C.c_int), ("act", C.c_int), ("w_off", C.c_long), ("h", C.c_int), ("w", C.c_int),
+                ("flag", C.c_int)]
+
+
 NON_STATUS = {"dvd_last_error", "dvd_version", "dvd_engine_workspace_bytes", "dvd_engine_tensor_count",
-              "dvd_flash_attn_kernel_name"}
+              "dvd_flash_attn_kernel_name", "dvd_convnet_workspace_bytes", "dvd_convnet_weight_floats",
+              "dvd_ingest_scratch_bytes"}
 
 # name -> argtypes; kept in one table so tests can check every symbol of include/dvd_hip.h
 SIGNATURES = {
@@ -102,6 +109,13 @@ SIGNATURES = {
     "dvd_maxpool2_nhwc": [c_void, c_void, C.c_int, C.c_int, C.c_int, c_void],
     "dvd_resize_bilinear_nhwc": [c_void, c_void, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_void],
     "dvd_nhwc_to_nchw": [c_void, c_void, C.c_int, C.c_int, C.c_int, c_void],
+    "dvd_convnet_create": [C.POINTER(CnOp), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(c_void)],
+    "dvd_convnet_destroy": [c_void],
+    "dvd_convnet_slot_shape": [c_void, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)],
+    "dvd_convnet_run": [c_void, c_void, c_void, c_void, C.c_long, C.c_int, C.POINTER(C.c_int), C.POINTER(c_void), c_void],
+    "dvd_resize_bilinear_nchw": [c_void, c_void, C.c_long, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_void],
+    "dvd_threshold_mask_mul": [c_void, c_void, c_void, c_void, C.c_int, C.c_long, C.c_float, c_void],
+    "dvd_ingest_u8": [c_void, C.c_int, C.c_int, C.c_int, c_void, C.c_int, c_void, c_void, c_void],
     "dvd_engine_create": [C.c_int, C.c_int, C.c_int, C.POINTER(c_void)],
     "dvd_engine_destroy": [c_void],
     "dvd_engine_bind_workspace": [c_void, c_void, C.c_long],
@@ -129,6 +143,9 @@ def bind(cdll):
     cdll.dvd_version.restype = C.c_int
     cdll.dvd_engine_workspace_bytes.restype = C.c_long
     cdll.dvd_engine_workspace_bytes.argtypes = [C.c_void_p]
+    for fn in (cdll.dvd_convnet_workspace_bytes, cdll.dvd_convnet_weight_floats):
+        fn.restype, fn.argtypes = C.c_long, [C.c_void_p]
+    cdll.dvd_ingest_scratch_bytes.restype, cdll.dvd_ingest_scratch_bytes.argtypes = C.c_long, [C.c_int]
     cdll.dvd_flash_attn_kernel_name.restype = C.c_char_p
     cdll.dvd_flash_attn_kernel_name.argtypes = [C.c_int, C.c_int, C.c_int]
     for name, args in SIGNATURES.items():

@@ -88,6 +88,19 @@ def unwarp_f32_batch(flow: torch.Tensor, src_nchw: torch.Tensor, scale: float = 
     return out
 
 
+def ingest_u8(img_hwc: torch.Tensor, swap_rb: bool = False, out_size: int = 512, want_rgb: bool = False):
+    """Decoded image [H,W,3] uint8 on the device -> source_image [3,out,out] f32 in 0..1 (cv2.resize INTER_LINEAR / 255,
+    doc_benchmark.py:84-88) and, if asked, the full-resolution RGB image (doc_benchmark.py:76)."""
+    _chk(img_hwc, torch.uint8, "img")
+    h, w, three = img_hwc.shape
+    assert three == 3
+    y = torch.empty((3, out_size, out_size), dtype=torch.float32, device=img_hwc.device)
+    rgb_out = torch.empty_like(img_hwc) if (want_rgb and swap_rb) else None
+    scratch = torch.empty(lib.raw().dvd_ingest_scratch_bytes(out_size), dtype=torch.uint8, device=img_hwc.device)
+    lib.call("dvd_ingest_u8", ptr(img_hwc), h, w, int(swap_rb), ptr(y), out_size, ptr(rgb_out), ptr(scratch), stream_ptr())
+    return (y, rgb_out if swap_rb else img_hwc) if want_rgb else y
+
+
 def sched_step(coef: lib.SchedCoef, x_t, x0, noise=None, want_grid=False, out=None):
     _chk(x_t, torch.float32, "x_t")
     _chk(x0, torch.float32, "x0")

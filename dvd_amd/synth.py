@@ -265,3 +265,107 @@ def synth_noise(doc_idx: int, n_hyp: int, grid: int, seed: int = 1234, step=None
     """x_T (step=None) or the per-step DDPM noise: [n_hyp, 2, G, G] ~ N(0,1)-ish."""
     tag = f"doc{doc_idx}/noise" + ("" if step is None else f"/s{step}")
     return normalish(tag, (n_hyp, 2, grid, grid), seed)
+
+
+# --------------------------------------------------------------------------------------
+# Pre-stage conditioning nets (SURVEY 8(f) rank 1): tensor inventories with the reference's
+# state_dict key names, so real seg.pth / seg_model.pth / line_model2.pth and the synthetic
+# weights go through the same loaders.
+#   U2NETP   train_settings/models/geotr/geotr_core.py:24-36 (REBNCONV), :48-330 (RSU7..RSU4F), :745-845
+#   UNet     train_settings/models/geotr/unet_model.py:4-37, unet_parts.py:8-77
+# --------------------------------------------------------------------------------------
+
+def _rebnconv(s, p, cin, cout):
+    s[p + "conv_s1.weight"] = ((cout, cin, 3, 3), "w")
+    s[p + "conv_s1.bias"] = ((cout,), "b")
+    s[p + "bn_s1.weight"] = ((cout,), "bn_w")
+    s[p + "bn_s1.bias"] = ((cout,), "bn_b")
+    s[p + "bn_s1.running_mean"] = ((cout,), "bn_m")
+    s[p + "bn_s1.running_var"] = ((cout,), "bn_v")
+    s[p + "bn_s1.num_batches_tracked"] = ((), "bn_n")
+
+
+def _rsu(s, p, depth, cin, mid, cout, flat=False):
+    """RSU-`depth` (depth 7/6/5/4) or the dilated RSU-4F: registration order of the reference's __init__."""
+    _rebnconv(s, p + "rebnconvin.", cin, cout)
+    _rebnconv(s, p + "rebnconv1.", cout, mid)
+    for k in range(2, depth + 1):
+        _rebnconv(s, p + f"rebnconv{k}.", mid, mid)
+    for k in range(depth - 1, 1, -1):
+        _rebnconv(s, p + f"rebnconv{k}d.", 2 * mid, mid)
+    _rebnconv(s, p + "rebnconv1d.", 2 * mid, cout)
+
+
+U2NETP_STAGES = [("stage1", 7, 3, False), ("stage2", 6, 64, False), ("stage3", 5, 64, False), ("stage4", 4, 64, False),
+                 ("stage5", 4, 64, True), ("stage6", 4, 64, True), ("stage5d", 4, 128, True), ("stage4d", 4, 128, False),
+                 ("stage3d", 5, 128, False), ("stage2d", 6, 128, False), ("stage1d", 7, 128, False)]
+
+
+def u2netp_spec(prefix: str = ""):
+    """U2NETP(3, 1): mid 16, out 64 everywhere (geotr_core.py:745-777)."""
+    s = OrderedDict()
+    for name, depth, cin, flat in U2NETP_STAGES:
+        _rsu(s, f"{prefix}{name}.", depth, cin, 16, 64, flat)
+    for k in range(1, 7):
+        s[f"{prefix}side{k}.weight"] = ((1, 64, 3, 3), "w")
+        s[f"{prefix}side{k}.bias"] = ((1,), "b")
+    s[prefix + "outconv.weight"] = ((1, 6, 1, 1), "w")
+    s[prefix + "outconv.bias"] = ((1,), "b")
+    return s
+
+
+def _double_conv(s, p, cin, cout, mid=None):
+    mid = mid or cout
+    for idx, (a, b) in ((0, (cin, mid)), (3, (mid, cout))):
+        s[p + f"double_conv.{idx}.weight"] = ((b, a, 3, 3), "w")
+        s[p + f"double_conv.{idx}.bias"] = ((b,), "b")
+        q = p + f"double_conv.{idx + 1}."
+        s[q + "weight"] = ((b,), "bn_w")
+        s[q + "bias"] = ((b,), "bn_b")
+        s[q + "running_mean"] = ((b,), "bn_m")
+        s[q + "running_var"] = ((b,), "bn_v")
+        s[q + "num_batches_tracked"] = ((), "bn_n")
+
+
+def unet_spec():
+    """UNet(n_channels=3, n_classes=1, bilinear=True) (unet_model.py:4-23)."""
+    s = OrderedDict()
+    _double_conv(s, "inc.", 3, 64)
+    for k, (a, b) in enumerate(((64, 128), (128, 256), (256, 512), (512, 512)), 1):
+        _double_conv(s, f"down{k}.maxpool_conv.1.", a, b)
+    for k, (a, b) in enumerate(((1024, 256), (512, 128), (256, 64), (128, 64)), 1):
+        _double_conv(s, f"up{k}.conv.", a, b, a // 2)
+    s["outc.conv.weight"] = ((1, 64, 1, 1), "w")
+    s["outc.conv.bias"] = ((1,), "b")
+    return s
+
+
+def synth_convnet_state_dict(kind: str, seed: int = 0, prefix: str = ""):
+    """Synthetic state dict of 'u2netp' (keys optionally prefixed, e.g. 'msk.') or 'unet'.  ReLU-BN stacks with
+    std-1/sqrt(fan_in) uniform weights lose variance layer by layer, so conv weights carry a gain of 1.2 (activations
+    stay O(1) through the ~40-conv-deep U2NETP; with Seg seed 22 the document mask covers ~80 % of the synthetic page)."""
+    spec = u2netp_spec(prefix) if kind == "u2netp" else unet_spec()
+    out = OrderedDict()
+    for k, (shape, knd) in spec.items():
+        t = synth_tensor(f"{kind}/{k}", shape, knd, seed)
+        if knd == "w":
+            t = (t * np.float32(1.2)).astype(np.float32)
+        out[k] = t
+    return out
+
+
+def smooth_image(key: str, h: int, w: int, seed: int = 1234) -> np.ndarray:
+    """[3,h,w] float32 in [0,1]: a page-like picture (a bright quadrilateral with dark 'text' stripes on a darker,
+    textured background) from the counter-based generator - gives the pre-stage nets something with structure, so
+    the document-mask probability is not hovering around its 0.5 threshold everywhere."""
+    ys, xs = np.meshgrid(np.linspace(0, 1, h, dtype=np.float32), np.linspace(0, 1, w, dtype=np.float32), indexing="ij")
+    u = uniform01(key + "/par", 8, seed)
+    cx, cy = 0.5 + 0.08 * (u[0] - 0.5), 0.5 + 0.08 * (u[1] - 0.5)
+    shear = 0.25 * (u[2] - 0.5)
+    xr, yr = xs - cx + shear * (ys - cy), ys - cy - 0.5 * shear * (xs - cx)
+    page = ((np.abs(xr) < 0.30 + 0.05 * u[3]) & (np.abs(yr) < 0.38 + 0.05 * u[4])).astype(np.float32)
+    lines = (np.sin(yr * (60.0 + 30.0 * u[5])) > 0.55).astype(np.float32) * (np.abs(xr) < 0.26)
+    noise = uniform01(key + "/noise", 3 * h * w, seed).reshape(3, h, w)
+    base = np.stack([0.25 + 0.1 * xs, 0.2 + 0.15 * ys, 0.3 - 0.1 * xs * ys]).astype(np.float32)
+    img = base * (1 - page) + page * (0.92 - 0.75 * lines) + 0.06 * (noise - 0.5)
+    return np.clip(img, 0.0, 1.0).astype(np.float32)

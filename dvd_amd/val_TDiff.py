@@ -11,7 +11,7 @@ import torch
 import torch.distributed as dist
 
 from . import dist_util, logger, synth
-from .evaluation import npz_documents, run_evaluation_docunet, synthetic_documents
+from .evaluation import image_documents, npz_documents, run_evaluation_docunet, synthetic_documents
 from .script_util import args_to_dict, create_model_and_diffusion, model_and_diffusion_defaults
 
 
@@ -36,6 +36,9 @@ def run(settings):
         device=dist_util.dev(), train_mode=env.train_mode, tv=env.time_variant, grid_size=env.grid_size,
         **args_to_dict(settings, model_and_diffusion_defaults().keys()))
     setattr(diffusion, "settings", settings)
+    if getattr(env, "use_init_flow", False):
+        raise NotImplementedError("env.use_init_flow needs GeoTr's `ref_bm`, whose weights the reference itself never "
+                                  "loads (val_TDiff.py:57-58 only reloads `.msk`): not a live configuration")
     # rank 0 alone reads the checkpoint (val_TDiff.py:79); the other ranks receive the packed blob below
     if dist_util.rank() == 0:
         if os.path.exists(env.model_path):
@@ -52,27 +55,65 @@ def run(settings):
     model.to(dist_util.dev())
     print(get_parameter_number(model))
     model.eval()
+    pre = load_prestage_models(env) if getattr(env, "use_prestage_nets", False) else None
     # the path's ONE collective, issued eagerly and unconditionally by every rank BEFORE the documents are sharded:
-    # rank 0 packs, one flat broadcast (a rank whose shard is empty still takes part, then goes to the barrier)
-    model.materialize_blob()
+    # rank 0 packs every model (denoiser + the three pre-stage nets) into one flat buffer, one broadcast (a rank whose
+    # shard is empty still takes part, then goes to the barrier)
+    dist_util.materialize_blobs([model] + list(pre or ()))
 
-    if env.eval_dataset_name == "synthetic" or not env.conditioning_dir:
+    if env.eval_dataset_name == "synthetic":
         n_docs = env.num_synthetic_docs
         mine = dist_util.shard_documents(n_docs)
         documents = synthetic_documents(settings, mine)
-    else:
+    elif env.conditioning_dir:
         files = sorted(glob.glob(os.path.join(env.conditioning_dir, "*.npz")))
         mine = dist_util.shard_documents(len(files))
         documents = npz_documents(settings, mine, files)
+    else:      # a benchmark directory of images, as the reference's Doc_benchmark (val_TDiff.py:96-104)
+        files = sorted(f for ext in ("*.jpg", "*.jpeg", "*.png") for f in glob.glob(os.path.join(env.eval_dataset, ext)))
+        mine = dist_util.shard_documents(len(files))
+        documents = image_documents(settings, mine, files)
     logger.info(f"rank {dist_util.rank()}/{dist_util.world_size()}: {len(mine)} documents")
     logger.info("Starting sampling")
-    results = run_evaluation_docunet(settings, logger, documents, diffusion, model, dist_util.dev())
+    results = run_evaluation_docunet(settings, logger, documents, diffusion, model, dist_util.dev(), pre)
     if dist.is_initialized():
         dist.barrier()
         if own_group:
             dist.destroy_process_group()
     logger.log("sampling complete")
     return results
+
+
+def load_prestage_models(env):
+    """The three pre-stage nets exactly as val_TDiff.py:57-75 builds and loads them: GeoTr_Seg_Inf with
+    reload_segmodel(model.msk, seg_model_path), UNet and Seg from {'model': state_dict} checkpoints.  Rank 0 alone reads
+    the files; the packed weights reach the other ranks in the one flat broadcast."""
+    from .prestage import GeoTr_Seg_Inf, Seg, UNet, reload_segmodel
+    dewarp, line, seg = GeoTr_Seg_Inf(), UNet(n_channels=3, n_classes=1), Seg()
+    if dist_util.rank() == 0:
+        def tt(sd):
+            return {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}
+        jobs = ((env.seg_model_path, lambda p: reload_segmodel(dewarp.msk, p),
+                 lambda: dewarp.msk.load_state_dict(tt(synth.synth_convnet_state_dict("u2netp", 11)), strict=True)),
+                (env.line_seg_model_path,
+                 lambda p: line.load_state_dict(dist_util.load_state_dict(p, map_location="cpu")["model"], strict=True),
+                 lambda: line.load_state_dict(tt(synth.synth_convnet_state_dict("unet", 13)), strict=True)),
+                (env.new_seg_model_path,
+                 lambda p: seg.load_state_dict(dist_util.load_state_dict(p, map_location="cpu")["model"], strict=True),
+                 lambda: seg.load_state_dict(tt(synth.synth_convnet_state_dict("u2netp", 22, prefix="msk.")), strict=True)))
+        for path, from_file, synthetic in jobs:
+            if os.path.exists(path):
+                from_file(path)
+                logger.log(f"loaded {path}")
+            elif _want_synthetic_weights(env):
+                synthetic()
+                logger.log(f"{path} not found: using deterministic synthetic weights")
+            else:
+                raise FileNotFoundError(path)
+    for m in (dewarp, seg, line):
+        m.to(dist_util.dev())
+        m.eval()
+    return dewarp, seg, line
 
 
 def _require_gpu():

@@ -216,6 +216,57 @@ int dvd_resize_bilinear_nhwc(const float* in, float* out, int c, int hin, int wi
 int dvd_nhwc_to_nchw(const float* in, float* out, int c, int h, int w, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Pre-stage conditioning nets: the U2NETP document-mask nets and the text-line
+ * UNet that produce mask_cat / mask_y512 / line_msk once per document, before the diffusion loop
+ * (train_settings/dvd/evaluation.py:162-216; train_settings/models/geotr/geotr_core.py:24-46,48-330,
+ * 745-845,984-1019; unet_model.py:4-37; unet_parts.py:8-77).
+ * A net is a flat list of ops over numbered activation slots (slot 0 = the input); the host builds the
+ * list from the architecture and packs the weights (eval-mode BatchNorm folded into conv weight + bias,
+ * conv weight as [cout, kpad] with K order (ky*ks+kx)*cin + c, kpad = ks*ks*cin rounded up to 16,
+ * followed by the bias [cout]; convs packed in op order).  Activations are channels-last f32; convs run
+ * on the exact-f32 MFMA GEMM. */
+enum { DVD_CN_CONV = 0, DVD_CN_POOL = 1, DVD_CN_RESIZE = 2, DVD_CN_ADD = 3, DVD_CN_SIGMOID = 4 };
+typedef struct {
+  int op;           /* DVD_CN_* */
+  int a, b;         /* input slots; b = -1 when unused.  conv: b is concatenated after a along channels
+                       (torch.cat((a, b), 1)); add: second operand; resize: the slot whose size is the target */
+  int dst;          /* output slot (each slot is written once) */
+  int ks, dil;      /* conv: kernel size 1 or 3, dilation (padding = dil * (ks / 2)) */
+  int cout, act;    /* conv: output channels; 0 none, 2 ReLU */
+  long w_off;       /* conv: offset, in floats, of this conv's [cout, kpad] weights (+ bias) in the blob */
+  int h, w;         /* resize with b = -1: explicit target size */
+  int flag;         /* resize: align_corners; pool: ceil_mode */
+} dvd_cn_op;
+
+int dvd_convnet_create(const dvd_cn_op* ops, int n_ops, int n_slots, int in_c, int in_h, int in_w, void** handle);
+int dvd_convnet_destroy(void* handle);
+long dvd_convnet_workspace_bytes(void* handle);
+long dvd_convnet_weight_floats(void* handle);
+int dvd_convnet_slot_shape(void* handle, int slot, int* h, int* w, int* c);
+/* One forward pass: in_nchw [in_c, in_h, in_w] f32 planar; the requested slots are written to out_nchw[k]
+ * as planar [c, h, w].  workspace: >= dvd_convnet_workspace_bytes, 256-byte aligned. */
+int dvd_convnet_run(void* handle, const float* in_nchw, const float* weights, void* workspace, long workspace_bytes,
+                    int n_out, const int* out_slots, float* const* out_nchw, void* stream);
+/* F.interpolate(mode='bilinear', align_corners=...) on `planes` independent [hin, win] f32 images
+ * (evaluation.py:162,199-204,210; geotr_core.py:992,1010). */
+int dvd_resize_bilinear_nchw(const float* in, float* out, long planes, int hin, int win, int hout, int wout,
+                             int align_corners, void* stream);
+/* mskx = (d0 > thr).float() * x  (Seg.forward, geotr_core.py:989-990): d0 [hw], x / out [c, hw];
+ * mask_out (optional) receives the 0/1 mask. */
+int dvd_threshold_mask_mul(const float* d0, const float* x_nchw, float* out_nchw, float* mask_out, int c, long hw,
+                           float thr, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Image ingest (datasets/doc_dataset/doc_benchmark.py:75-97 after the decode):
+ *   y = cv2.resize(rgb, (out, out)) / 255.  as planar f32 [3,out,out]  (OpenCV 8-bit INTER_LINEAR fixed point),
+ *   rgb_hwc_out (optional) = the full-resolution image in RGB order (what the unwarp tail samples).
+ * src_hwc [h,w,3] uint8 on the device; swap_rb: the source is BGR (cv2.imread order).
+ * scratch: dvd_ingest_scratch_bytes(out_size) device bytes. */
+long dvd_ingest_scratch_bytes(int out_size);
+int dvd_ingest_u8(const uint8_t* src_hwc, int h, int w, int swap_rb, float* y_chw, int out_size,
+                  uint8_t* rgb_hwc_out, void* scratch, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Engine: DiT.forward of the live model (idf/cross_model.py:568-647) for docs x n_hyp samples.
  *   create -> workspace_bytes -> bind_workspace -> set_tensor(every tensor of tensor_info) ->
  *   prepare_docs (once per batch of documents) -> denoise_step (once per diffusion step).

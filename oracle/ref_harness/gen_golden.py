@@ -19,6 +19,8 @@ Fixtures:
   G4 ddim_step.npz     ddim_sample on random (x_t,x0) for every t of S=50; p_mean_variance S=250
   G5 unwarp.npz        upsample+affine+grid_sample+uint8 tail on a small ragged image
   G6 grid_sample.npz   register_model2 on the per-step feature-warp shape
+  G8 prestage_g16.npz  the pre-stage conditioning nets (evaluation.py:162-216: GeoTr_Seg_Inf.msk, Seg, line UNet + the six
+                       align_corners=False resizes) on synthetic weights: mask_cat / mask_y512 / line_msk for G=16
   G7 rollout_train_g{G}_s{S}.npz  ddim_sample_loop_for_training(mode='train', n_batch=1, timestep=k) with a
                        non-zero init_flow: the call training_losses_time_variant makes (gaussian_diffusion.py:921-946)
 """
@@ -310,6 +312,54 @@ def gen_train_rollout(mods, grid, steps, timestep):
           f"sample mean {sample.mean():+.5f} std {sample.std():.5f}")
 
 
+# ------------------------------------------------------------------------------- G8
+def gen_prestage(mods, grid=16):
+    """evaluation.py:162-216 with the reference's own modules (val_TDiff.py:57-75 builds them): GeoTr_Seg_Inf (only its
+    U2NETP `.msk` is loaded and only its mask output is read on the live configuration), Seg, UNet."""
+    from train_settings.models.geotr import geotr_core
+    from train_settings.models.geotr.unet_model import UNet
+    sd_a = synth.synth_convnet_state_dict("u2netp", 11)                       # -> GeoTr_Seg_Inf.msk
+    sd_b = synth.synth_convnet_state_dict("u2netp", 22, prefix="msk.")        # -> Seg
+    sd_l = synth.synth_convnet_state_dict("unet", 13)
+    tt = lambda sd: {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}  # noqa: E731
+    msk_net = geotr_core.U2NETP(3, 1)
+    assert list(msk_net.state_dict().keys()) == list(sd_a.keys())
+    msk_net.load_state_dict(tt(sd_a), strict=True)
+    seg = geotr_core.Seg()
+    assert list(seg.state_dict().keys()) == list(sd_b.keys())
+    seg.load_state_dict(tt(sd_b), strict=True)
+    line = UNet(n_channels=3, n_classes=1)
+    assert list(line.state_dict().keys()) == list(sd_l.keys())
+    line.load_state_dict(tt(sd_l), strict=True)
+    for m in (msk_net, seg, line):
+        m.eval()
+    src = torch.from_numpy(synth.smooth_image("g8/src", 512, 512, SEED_IN))[None]       # [1,3,512,512] 0..1
+    with torch.no_grad():
+        src288 = F.interpolate(src, size=(288), mode="bilinear", align_corners=True)                    # :162
+        # GeoTr_Seg_Inf.forward (geotr_core.py:1003-1019) without its dead, never-loaded GeoTr branch
+        msk, *_ = msk_net(src288)
+        mask_x = F.interpolate(msk, size=(512), mode="bilinear", align_corners=True)
+        mskx, d0, hx6, hx5d, hx4d, hx3d, hx2d, hx1d = seg(src288)                                        # :198
+        feats = [F.interpolate(t, size=grid, mode="bilinear", align_corners=False)
+                 for t in (hx6, hx5d, hx4d, hx3d, hx2d, hx1d)]                                           # :199-204
+        seg_map_all = torch.cat(feats, dim=1)                                                           # :206
+        textline_map, textline_mask = line(mskx)                                                        # :209
+        line_small = F.interpolate(textline_map, size=grid, mode="bilinear", align_corners=False)        # :210
+    near = float(((seg.msk(src288)[0] - 0.5).abs() < 1e-4).float().mean())
+    out = {"grid": np.int64(grid), "mask_cat_sub": mask_x[0, 0, ::8, ::8].numpy().copy(), "mask_cat_stats": summ(mask_x),
+           "d0_seg_sub": F.interpolate(d0, size=288, mode="bilinear", align_corners=True)[0, 0, ::4, ::4].numpy().copy(),
+           "d0_512_stats": summ(d0), "mask_fraction": np.float64((mskx.abs().sum(1) > 0).float().mean()),
+           "mask_near_threshold_fraction": np.float64(near),
+           "mask_bits": np.packbits(((seg.msk(src288)[0] > 0.5)[0, 0]).numpy()),
+           "mask_y512": seg_map_all[0].numpy().copy(), "line_msk": line_small[0].numpy().copy(),
+           "hx1d_sub": hx1d[0, ::8, ::16, ::16].numpy().copy(), "hx6": hx6[0].numpy().copy(),
+           "line_map_sub": textline_map[0, ::8, ::16, ::16].numpy().copy(),
+           "line_logits_sub": textline_mask[0, 0, ::8, ::8].numpy().copy()}
+    np.savez_compressed(os.path.join(GOLD, f"prestage_g{grid}.npz"), **out)
+    print(f"G8 prestage_g{grid}.npz  mask fraction {out['mask_fraction']:.3f}  near-threshold {near:.2e}  "
+          f"mask_y512 std {seg_map_all.std():.4f}  line std {line_small.std():.4f}")
+
+
 # ------------------------------------------------------------------------------- G4
 def gen_ddim_step(mods):
     _, gd, respace, script_util, _, _ = mods
@@ -392,7 +442,7 @@ def gen_grid_sample(mods):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="G1,G2,G3,G4,G5,G6,G7")
+    ap.add_argument("--only", default="G1,G2,G3,G4,G5,G6,G7,G8")
     args = ap.parse_args()
     want = set(args.only.split(","))
     os.makedirs(GOLD, exist_ok=True)
@@ -415,6 +465,8 @@ def main():
         gen_loop(mods, 32, 3, True)
         gen_loop(mods, 64, 3, True)
         gen_loop(mods, 64, 10, False)
+    if "G8" in want:
+        gen_prestage(mods, 16)
     if "G7" in want:
         gen_train_rollout(mods, 16, 10, 2)      # t_model 900 .. 300 raw: crosses both override thresholds
         gen_train_rollout(mods, 32, 3, -1)

@@ -24,7 +24,8 @@ def test_library_exports_every_declared_symbol():
 
 def test_python_binding_table_matches_header():
     syms = set(declared_symbols()) - {"dvd_last_error", "dvd_version", "dvd_engine_workspace_bytes",
-                                      "dvd_flash_attn_kernel_name"}
+                                      "dvd_flash_attn_kernel_name", "dvd_convnet_workspace_bytes",
+                                      "dvd_convnet_weight_floats", "dvd_ingest_scratch_bytes"}
     assert syms == set(lib.SIGNATURES), (syms ^ set(lib.SIGNATURES))
 
 

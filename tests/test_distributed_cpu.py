@@ -68,14 +68,15 @@ def test_two_rank_broadcast_and_sharding():
 # COMPUTE entry points stubbed at the lib.call boundary (there is no GPU here; the host-only entry
 # points - create / tensor_info / bind_workspace / set_tensor - run for real).
 # ------------------------------------------------------------------------------------------------
-COMPUTE = {"dvd_unwarp_u8_batch", "dvd_engine_prepare_docs", "dvd_engine_denoise_step", "dvd_engine_feat_nchw", "dvd_sched_step",
+COMPUTE = {"dvd_convnet_run", "dvd_resize_bilinear_nchw", "dvd_threshold_mask_mul", "dvd_ingest_u8",
+           "dvd_unwarp_u8_batch", "dvd_engine_prepare_docs", "dvd_engine_denoise_step", "dvd_engine_feat_nchw", "dvd_sched_step",
            "dvd_hyp_mean_clamp", "dvd_unwarp_u8"}
 
 
 def _stub_compute(calls):
     """Patch the GPU-only pieces; returns nothing, records (name) of every stubbed compute call."""
     import torch as th
-    from dvd_amd import cross_model, engine, lib, ops, val_TDiff
+    from dvd_amd import cross_model, engine, lib, ops, prestage, val_TDiff
     real_call = lib.call
 
     def call(name, *args):
@@ -84,7 +85,7 @@ def _stub_compute(calls):
             return
         return real_call(name, *args)
     lib.call = call
-    for mod in (engine, ops):
+    for mod in (engine, ops, prestage):
         mod.stream_ptr = lambda: None
     ops._chk = lambda *a, **k: None
     engine._is_dev = lambda t: True
@@ -110,13 +111,17 @@ def _run_worker(rank, world, port, n_docs, q, tmp):
     seen = {}
     orig = val_TDiff.run_evaluation_docunet
 
-    def spy(settings, logger, documents, diffusion, model, device):
-        seen["digest"] = hashlib.sha256(model._blob.cpu().numpy().tobytes()).hexdigest()
-        return orig(settings, logger, documents, diffusion, model, device)
+    def spy(settings, logger, documents, diffusion, model, device, prestage_models=None):
+        h = hashlib.sha256(model._blob.cpu().numpy().tobytes())
+        for m in prestage_models:                      # denoiser + pre-stage nets travel in the one flat broadcast
+            h.update((m.msk if hasattr(m, "msk") else m)._blob.cpu().numpy().tobytes())
+        seen["digest"] = h.hexdigest()
+        return orig(settings, logger, documents, diffusion, model, device, prestage_models)
     val_TDiff.run_evaluation_docunet = spy
     results = val_TDiff.run(s)
     q.put((rank, seen["digest"], [p for p, _ in results], calls.count("dvd_engine_denoise_step"),
-           calls.count("dvd_engine_prepare_docs"), calls.count("dvd_unwarp_u8_batch")))
+           calls.count("dvd_engine_prepare_docs"), calls.count("dvd_unwarp_u8_batch"), calls.count("dvd_convnet_run"),
+           calls.count("dvd_ingest_u8")))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -136,14 +141,15 @@ def test_val_tdiff_run_two_ranks(tmp_path, n_docs):
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
-    (r0, d0, docs0, den0, prep0, unw0), (r1, d1, docs1, den1, prep1, unw1) = res
+    (r0, d0, docs0, den0, prep0, unw0, cn0, ing0), (r1, d1, docs1, den1, prep1, unw1, cn1, ing1) = res
     assert d0 == d1, "ranks disagree on the broadcast weight blob"
     want0 = [f"synthetic_{i:05d}" for i in range(0, n_docs, 2)]
     want1 = [f"synthetic_{i:05d}" for i in range(1, n_docs, 2)]
     assert docs0 == want0 and docs1 == want1
-    for docs, den, prep, unw in ((want0, den0, prep0, unw0), (want1, den1, prep1, unw1)):
+    for docs, den, prep, unw, cn, ing in ((want0, den0, prep0, unw0, cn0, ing0), (want1, den1, prep1, unw1, cn1, ing1)):
         batches = (len(docs) + 1) // 2
         assert den == 3 * batches and prep == batches and unw == batches      # one batched unwarp launch per batch
+        assert ing == len(docs) and cn == 3 * len(docs)    # ingest + the three pre-stage nets once per document
 
 
 # ------------------------------------------------------------------------------------------------

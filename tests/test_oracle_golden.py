@@ -168,3 +168,26 @@ def test_loop_s10_vs_reference():
     assert [O.t_rule(float(t)) for t in g["t_model"]] == [2.0, 2.0, 2.0, 600.0, 1.0, 1.0, 300.0, 200.0, 100.0, 0.0]
     out = orc.sample_loop(sch, torch.from_numpy(g["x_T"]), _doc(64))
     np.testing.assert_allclose(out.numpy(), g["sample"], rtol=0, atol=1e-4)
+
+
+# ----------------------------------------------------------------------------- G8
+def test_prestage_oracle_vs_reference():
+    """The pre-stage nets' restatement (oracle/prestage_oracle.py) against the reference's own U2NETP / Seg / UNet
+    modules and the glue of evaluation.py:162-216 (golden G8)."""
+    import torch.nn.functional as F
+    from oracle import prestage_oracle as PO
+    g = load("prestage_g16.npz")
+    grid = int(g["grid"])
+    sd_a = synth.synth_convnet_state_dict("u2netp", 11)
+    sd_b = synth.synth_convnet_state_dict("u2netp", 22, prefix="msk.")
+    sd_l = synth.synth_convnet_state_dict("unet", 13)
+    src = torch.from_numpy(synth.smooth_image("g8/src", 512, 512, 1234))[None]
+    with torch.no_grad():
+        out = PO.prestage(sd_a, sd_b, sd_l, src, grid)
+    assert np.array_equal(np.packbits((out["d0"] > 0.5)[0, 0].numpy()), g["mask_bits"])
+    np.testing.assert_allclose(out["mask_cat"][0, 0, ::8, ::8].numpy(), g["mask_cat_sub"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(out["hx"][0][0].numpy(), g["hx6"], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(out["hx"][5][0, ::8, ::16, ::16].numpy(), g["hx1d_sub"], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(out["mask_y512"][0].numpy(), g["mask_y512"], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(out["line_map"][0, ::8, ::16, ::16].numpy(), g["line_map_sub"], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(out["line_msk"][0].numpy(), g["line_msk"], rtol=0, atol=2e-5)
