@@ -207,7 +207,7 @@ extern "C" int dvd_convnet_create(const dvd_cn_op* ops, int n_ops, int n_slots, 
         const int kp = (o.ks * o.ks * cin + 15) / 16 * 16;
         n->kpad[i] = kp;
         if (o.w_off != wf) return fail("weights must be packed in op order (w_off mismatch)", i);
-        wf += (long)o.cout * kp + o.cout;
+        wf += (long)o.cout * kp + (o.cout + 3) / 4 * 4;   // bias padded to 16 bytes: every conv's weights stay 16-byte aligned
         colmax = std::max(colmax, (size_t)a.h * a.w * kp * 4);
         d.h = a.h; d.w = a.w; d.c = o.cout;
         break;

@@ -44,7 +44,7 @@ class Program:
         dst = self._new(cout)
         self.ops.append(dict(op=CONV, a=a, b=b, dst=dst, ks=ks, dil=dil, cout=cout, act=act, w_off=self.w_floats))
         self.convs.append((src, cin, cout, ks, kp))
-        self.w_floats += cout * kp + cout
+        self.w_floats += cout * kp + (cout + 3) // 4 * 4        # bias padded to 16 bytes
         return dst
 
     def pool(self, a, ceil_mode):
@@ -85,7 +85,7 @@ class Program:
                 blk = torch.zeros(cout, kp)
                 blk[:, :cin] = torch.eye(cout, cin)
                 out[off:off + cout * kp] = blk.reshape(-1)
-                off += cout * kp + cout
+                off += cout * kp + (cout + 3) // 4 * 4
                 continue
             if kind == "rebn":          # REBNCONV: conv_s1 + bn_s1 (geotr_core.py:28-34)
                 p = keys[0]
@@ -110,7 +110,7 @@ class Program:
             blk[:, :flat.shape[1]] = flat
             out[off:off + cout * kp] = blk.reshape(-1).float()
             out[off + cout * kp:off + cout * kp + cout] = b.float()
-            off += cout * kp + cout
+            off += cout * kp + (cout + 3) // 4 * 4
         return out
 
 

@@ -223,7 +223,7 @@ int dvd_nhwc_to_nchw(const float* in, float* out, int c, int h, int w, void* str
  * A net is a flat list of ops over numbered activation slots (slot 0 = the input); the host builds the
  * list from the architecture and packs the weights (eval-mode BatchNorm folded into conv weight + bias,
  * conv weight as [cout, kpad] with K order (ky*ks+kx)*cin + c, kpad = ks*ks*cin rounded up to 16,
- * followed by the bias [cout]; convs packed in op order).  Activations are channels-last f32; convs run
+ * followed by the bias [cout] padded to a multiple of 4 floats; convs packed in op order).  Activations are channels-last f32; convs run
  * on the exact-f32 MFMA GEMM. */
 enum { DVD_CN_CONV = 0, DVD_CN_POOL = 1, DVD_CN_RESIZE = 2, DVD_CN_ADD = 3, DVD_CN_SIGMOID = 4 };
 typedef struct {
