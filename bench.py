@@ -120,6 +120,7 @@ def main():
     ap.add_argument("--full-res", default="3508x2480")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-split-weights", action="store_true")
+    ap.add_argument("--no-ffn-lo", action="store_true", help="opt-in fast mode: drop the lo pass of the decoder FFN convs")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -139,6 +140,8 @@ def main():
     eng = Engine(G, B, H, device=dev)
     if args.no_split_weights:
         eng.set_option("split_weights", 0)
+    if args.no_ffn_lo:
+        eng.set_option("ffn_lo", 0)
 
     # ---- weights: rank 0 builds + packs, ONE flat RCCL broadcast (the only collective of the path) ----
     _, blob_bytes = eng.blob_layout()
@@ -235,19 +238,39 @@ def main():
                     roof["mfma_busy_pmc"] = rec["mfma_busy"]
                     roof["sustained_clock_ghz_pmc"] = rec["sustained_clock_ghz"]
                     roof["pmc_source"] = f"profiles/{PROFILE_ROUND}_{name}.json"
-        # second roofline object: the HBM-bound full-resolution gather (fused u8 tail, one launch per batch)
+        # second roofline object: the HBM-bound full-resolution gather.  SURVEY 8(d) prices it on the drop-in
+        # grid_sample contract (f32: 12 B/px source + 8 B/px grid + 12 B/px output = 32 B/px), so that kernel is
+        # timed here, after the timed region, on this run's own documents (all B in one launch); the fused u8 tail the
+        # timed region actually uses (6 B/px algorithmic, VALU-bound) is reported beside it.
         roof_unwarp = None
         if unwarp_events:
-            ms = sum(a.elapsed_time(b) for a, b in unwarp_events) / len(unwarp_events)
-            bytes_alg = 6 * FH * FW * B                  # fused u8 tail = 3 B/px read + 3 B/px written
-            roof_unwarp = {"kernel": "unwarp_u8_rows_kernel (upsample + affine + grid_sample + uint8, fused; "
-                                     f"{B} documents per launch)", "bound": "hbm",
-                           "achieved": round(bytes_alg / (ms * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                           "frac": round(bytes_alg / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), "traffic": None,
-                           "algorithmic_bytes_per_launch": bytes_alg, "launches_timed": len(unwarp_events),
+            ms_u8 = sum(a.elapsed_time(b) for a, b in unwarp_events) / len(unwarp_events)
+            srcf = src_u8.permute(0, 3, 1, 2).float().contiguous()                        # [B,3,H,W] f32 0..255
+            grid_full = torch.cat([ops.unwarp_grid(flow[d:d + 1].contiguous(), FH, FW) for d in range(B)])   # [B,2,H,W]
+            for _ in range(2):
+                ops.grid_sample(srcf, grid_full)
+            evs = []
+            for _ in range(5):
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                ops.grid_sample(srcf, grid_full)
+                b.record()
+                evs.append((a, b))
+            torch.cuda.synchronize()
+            ms = sum(a.elapsed_time(b) for a, b in evs) / len(evs)
+            bytes_alg = 32 * FH * FW * B
+            roof_unwarp = {"kernel": f"grid_sample_rows_kernel (drop-in register_model2 contract, f32, {B} documents per "
+                                     "launch)", "bound": "hbm", "achieved": round(bytes_alg / (ms * 1e-3) / 1e9, 1),
+                           "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(bytes_alg / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                           "traffic": None, "algorithmic_bytes_per_launch": bytes_alg, "launches_timed": len(evs),
                            "avg_launch_ms": round(ms, 4),
-                           "note": "6 B/px algorithmic (u8 in, u8 out); the drop-in f32 grid_sample contract is 32 B/px "
-                                   "(profiles/, benchmarks/op_bench.py)"}
+                           "fused_u8_tail": {"kernel": "unwarp_u8_rows_kernel (what the timed region runs: upsample + affine "
+                                                       f"+ gather + uint8 fused, {B} documents per launch)",
+                                             "algorithmic_bytes_per_launch": 6 * FH * FW * B,
+                                             "avg_launch_ms": round(ms_u8, 4), "launches_timed": len(unwarp_events),
+                                             "achieved_GBps": round(6 * FH * FW * B / (ms_u8 * 1e-3) / 1e9, 1),
+                                             "note": "VALU-bound at 6 B/px (~150 VALU ops per pixel), not HBM-bound"}}
+            del srcf, grid_full
         flops_total = per_sample_step * n * S * world * args.steps
         if not args.no_split_weights:
             pass   # split weights double the GEMM MFMAs; algorithmic FLOPs are unchanged by definition
@@ -278,7 +301,8 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
             "config": {"workload": workload_name(B, H, S, args.sampler, G, FH, FW, world),
                        "docs_per_gpu": B, "hypotheses": H, "sampler_steps": S, "grid": G,
-                       "weights": "synthetic (seed 7), f16 hi/lo split" if not args.no_split_weights else "synthetic, f16",
+                       "weights": ("synthetic, f16" if args.no_split_weights else "synthetic (seed 7), f16 hi/lo split"
+                                   + (", decoder-FFN lo pass dropped (opt-in fast mode)" if args.no_ffn_lo else "")),
                        "parallelism": f"dp{world} (documents sharded, one weight broadcast)"},
             "algorithmic_tflops": round(flops_total / elapsed / 1e12, 1),
             "weight_broadcast_ms": None if bcast_ms is None else round(bcast_ms, 2),

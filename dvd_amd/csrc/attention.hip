@@ -393,6 +393,18 @@ __global__ void __launch_bounds__(256, (D == 256 ? 1 : DVD_ATTN64_OCC)) flash_at
   // makes every tile's S^T phase wait for the LDS-DMA loads of the NEXT tile issued just before it.  Retire the Q
   // loads here with a wait the compiler does track (vmcnt(0); expcnt / lgkmcnt untouched).
   __builtin_amdgcn_s_waitcnt(0x0F70);
+  // head_dim 64 is VALU-issue-bound (per 64-key tile and wave: 16 MFMAs against 32 v_exp + ~100 other VALU, two
+  // waves per SIMD), so the softmax argument  s * c - m  is taken off the VALU entirely: Q is scaled by c = scale *
+  // log2(e) once per workgroup (fp32 multiply, one f16 rounding), and -m_run enters through the C operand of the first
+  // MFMA of each S^T chain (a 16-register block `negm`, rewritten only in the rare rescale branch) - the accumulators
+  // come out as  s * c - m_run  and feed v_exp directly: 32 v_fma per tile (15 % of the issue slots) are gone.
+  constexpr bool NEGM = (D == 64);
+  if constexpr (NEGM) {
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) qf[ks][j] = (_Float16)((float)qf[ks][j] * p.c);
+  }
 
   // ---- per-lane SOURCE offsets (bytes) of the direct-to-LDS loads, swizzled
   unsigned koff[KINST], voff[VINST];
@@ -425,7 +437,10 @@ __global__ void __launch_bounds__(256, (D == 256 ? 1 : DVD_ATTN64_OCC)) flash_at
   for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
     for (int i = 0; i < 16; ++i) o[dt][i] = 0.f;
-  float m_run = -1e30f, l_run = 0.f;
+  float m_run = NEGM ? 0.f : -1e30f, l_run = 0.f;
+  floatx16 negm;                    // NEGM: all 16 registers = -m_run (the lane's query row owns all of them)
+#pragma unroll
+  for (int i = 0; i < 16; ++i) negm[i] = 0.f;
   // EXPERIMENT (off): take the softmax row sums off the VALU - an all-ones V^T row block makes one extra MFMA per P chunk
   // accumulate sum_k P[k, q] into osum (4 MFMAs per tile instead of 32 v_add_f32).  Correct, but head_dim 64 measured
   // the same with it (861 vs 895 TF/s, inside the box-to-box noise), as it did with two query row blocks per wave and
@@ -504,16 +519,25 @@ __global__ void __launch_bounds__(256, (D == 256 ? 1 : DVD_ATTN64_OCC)) flash_at
     const char* base = smem + cur * BUF;
     half8 fr[FM + 1];
     floatx16 s[2];
+    if constexpr (!NEGM) {
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb)
+      for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) s[kb][i] = 0.f;
+        for (int i = 0; i < 16; ++i) s[kb][i] = 0.f;
+    }
 #pragma unroll
     for (int i = 0; i < PF; ++i) KLOAD(i);
     SB();
 #pragma unroll
     for (int i = 0; i < NS; ++i) {
-      s[i & 1] = mfma32_f16(fr[i & FM], qf[i >> 1], s[i & 1]);
+      if (NEGM && i < 2) {
+        // D = A.B + (-m_run) with C != D: issued from inline asm (early-clobber D), because the builtin makes hipcc copy
+        // negm into the second chain's accumulator first (8 v_mov_b64 per tile).  The consumer of each result is the
+        // chain's next MFMA, two MFMAs later, reading it as SrcC at exactly the same registers.
+        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %3" : "=&v"(s[i & 1]) : "v"(fr[i & FM]), "v"(qf[i >> 1]), "v"(negm));
+      } else {
+        s[i & 1] = mfma32_f16(fr[i & FM], qf[i >> 1], s[i & 1]);
+      }
       if (i + PF < NS) { KLOAD(i + PF); } else { VLOAD(i + PF - NS); }
       if constexpr (SPREAD) {
         if (i % GAP == GAP - 1 && i / GAP < NG) { GLDS_ANY(i / GAP) }
@@ -527,12 +551,28 @@ __global__ void __launch_bounds__(256, (D == 256 ? 1 : DVD_ATTN64_OCC)) flash_at
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int i = 0; i < 16; ++i) mx = fmaxf(mx, s[kb][i]);
-    mx *= p.c;
-    mx = half_swap_max(mx);
-    if (__any(mx - m_run > RESCALE_THR)) {     // deferred rescale, see flash_attn_kernel
-      const float m_new = fmaxf(m_run, mx);
-      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-      m_run = m_new;
+    if constexpr (!NEGM) mx *= p.c;
+    mx = half_swap_max(mx);                    // NEGM: already (row max) * c - m_run
+    bool resc;
+    if constexpr (NEGM) resc = t == 0 || __any(mx > RESCALE_THR);    // the first tile always sets the reference maximum
+    else resc = __any(mx - m_run > RESCALE_THR);
+    if (resc) {                                // deferred rescale, see flash_attn_kernel
+      float alpha;
+      if constexpr (NEGM) {
+        const float delta = t == 0 ? mx : fmaxf(mx, 0.f);
+        alpha = __builtin_amdgcn_exp2f(-delta);
+        m_run += delta;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) negm[i] = -m_run;
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) s[kb][i] -= delta;          // this tile's scores were formed against the old m_run
+      } else {
+        const float m_new = fmaxf(m_run, mx);
+        alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        m_run = m_new;
+      }
       l_run *= alpha;
       if constexpr (MFMA_ROWSUM) {
 #pragma unroll
@@ -553,7 +593,8 @@ __global__ void __launch_bounds__(256, (D == 256 ? 1 : DVD_ATTN64_OCC)) flash_at
     // chunk c of P = registers 8 (c & 1) .. +7 of s[c >> 1]
 #define PEXP(c_, e_)                                                                             \
   {                                                                                              \
-    const float pv_ = __builtin_amdgcn_exp2f(fmaf(s[(c_) >> 1][8 * ((c_) & 1) + (e_)], p.c, -m_run)); \
+    const float sv_ = s[(c_) >> 1][8 * ((c_) & 1) + (e_)];                                       \
+    const float pv_ = __builtin_amdgcn_exp2f(NEGM ? sv_ : fmaf(sv_, p.c, -m_run));               \
     if constexpr (!MFMA_ROWSUM) rs += pv_;                                                       \
     pf[c_][e_] = (_Float16)pv_;                                                                  \
   }

@@ -154,6 +154,7 @@ struct Engine {
   bool prepared = false;
   // ---- options (dvd_engine_set_option; fixed for the life of a captured graph) ----
   bool split_weights = true;   // use the lo parts (fp32-grade weights, 2x GEMM MFMAs)
+  bool ffn_lo = true;          // keep the lo parts of the decoder FFN's two 1x1 convs (see dvd_engine_set_option)
   bool use_graphs = false;     // replay a denoiser evaluation as one hipGraph (launch-bound small grids)
   // optional per-launch timing of the dominant kernel (decoder attention) with HIP events on the launch stream:
   // a ring of event pairs, drained into running totals when it wraps, so EVERY launch of the timed region counts
@@ -170,6 +171,7 @@ struct Engine {
   const float* F(int i) const { return (const float*)wptr[i]; }
   const void* H(int i) const { return wptr[i]; }
   const void* L(int i) const { return split_weights ? wptr[i + 1] : nullptr; }   // (hi, lo) pairs are adjacent
+  const void* Lffn(int i) const { return ffn_lo ? L(i) : nullptr; }
   char* B(int i) const { return ws + bufs[i].off; }
   int find_w(const std::string& name) const {
     for (size_t i = 0; i < specs.size(); ++i)
@@ -393,6 +395,7 @@ extern "C" int dvd_engine_set_option(void* handle, const char* name, int value) 
   DVD_REQUIRE(handle && name, "engine_set_option: null pointer");
   Engine* e = (Engine*)handle;
   if (strcmp(name, "split_weights") == 0) { e->split_weights = value != 0; e->drop_graphs(); return DVD_OK; }
+  if (strcmp(name, "ffn_lo") == 0) { e->ffn_lo = value != 0; e->drop_graphs(); return DVD_OK; }
   if (strcmp(name, "graphs") == 0) {
     e->use_graphs = value != 0;
     if (!e->use_graphs) e->drop_graphs();
@@ -653,10 +656,10 @@ static int enqueue_step(Engine* e, const float* x_t, int feat_mode, const float*
     TRY(dvd_layernorm_rows(z, DEC, 0, h16, DEC, 0, 1, NT, DEC, e->F(dw.n2w), e->F(dw.n2b), nullptr, nullptr, 0,
                            1, 1e-5f, stream));
     TRY(gemm(0, (int)NT, FFN, DEC, 1, h16, DEC, 0, e->H(dw.c1w16), DEC, 0, nullptr, 0, 0, f1, FFN, 0,
-             e->F(dw.c1b), 0, 2, nullptr, 0, nullptr, 0, nullptr, 0, 0, stream, nullptr, e->L(dw.c1w16)));
+             e->F(dw.c1b), 0, 2, nullptr, 0, nullptr, 0, nullptr, 0, 0, stream, nullptr, e->Lffn(dw.c1w16)));
     TRY(dvd_dwconv3x3(f1, f2, e->F(dw.dww), e->F(dw.dwb), N, side, FFN, stream));
     TRY(gemm(0, (int)NT, DEC, FFN, 1, f2, FFN, 0, e->H(dw.c2w16), FFN, 0, z, DEC, 0, nullptr, 0, 0,
-             e->F(dw.c2b), 0, 2, nullptr, 0, nullptr, 0, z, DEC, 0, stream, nullptr, e->L(dw.c2w16)));
+             e->F(dw.c2b), 0, 2, nullptr, 0, nullptr, 0, z, DEC, 0, stream, nullptr, e->Lffn(dw.c2w16)));
     if (e->debug_stop == 4 + j) return check_launch("engine_denoise_step(stop 4+j)");
   }
 

@@ -280,7 +280,12 @@ int dvd_engine_bind_workspace(void* handle, void* workspace, long bytes);
 int dvd_engine_tensor_count(void* handle);
 int dvd_engine_tensor_info(void* handle, int index, const char** name, int* dtype /*0 f32, 1 f16*/, long* nelem);
 int dvd_engine_set_tensor(void* handle, const char* name, const void* dev_ptr, long nelem);
-/* options: "split_weights" (default 1): use the (hi, lo) f16 weight pairs -> fp32-grade weights, 2x GEMM MFMAs. */
+/* options (per handle; no environment variable is read anywhere in the library):
+ *   "split_weights" (default 1): use the (hi, lo) f16 weight pairs -> fp32-grade weights, 2x GEMM MFMAs;
+ *   "ffn_lo"        (default 1): 0 drops the lo pass of the decoder FFN's two 1x1 convs only (-4.8 % step time;
+ *                                measured coordinate error on synthetic weights 1.2e-4 -> 3.3e-4: opt-in);
+ *   "graphs"        (default 0): replay each denoiser evaluation as a captured hipGraph (bit-identical results;
+ *                                the Python engine turns it on for grids <= 128). */
 int dvd_engine_set_option(void* handle, const char* name, int value);
 /* y512 [docs,3,512,512] (0..1), mask_cat [docs,1,512,512], mask_y512 [docs,384,G,G], line_msk [docs,64,G,G]
  * (kwargs of the denoiser call, train_settings/dvd/evaluation.py:106-115). */
