@@ -194,3 +194,10 @@ def test_q_sample_matches_reference_formula():
     a = torch.from_numpy(np.sqrt(ac))[t].float()[:, None, None, None]
     b = torch.from_numpy(np.sqrt(1 - ac))[t].float()[:, None, None, None]
     assert torch.equal(got, a * x0 + b * eps)
+
+
+def test_reference_import_paths_of_the_prestage_nets():
+    """val_TDiff.py:9-10 of the reference imports these names from these modules."""
+    from train_settings.models.geotr.geotr_core import GeoTr_Seg_Inf, Seg, reload_segmodel  # noqa: F401
+    from train_settings.models.geotr.unet_model import UNet
+    assert UNet(n_channels=3, n_classes=1).kind == "unet" and Seg().msk.kind == "u2netp"
