@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""Time the split-weight GEMMs of the decoder at the bench's shapes (M = 331 776 rows).
+usage: [DVD_HIP_LIB=...] python benchmarks/gemm_time.py [reps=5]"""
+import os, sys
+sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
+import torch
+from dvd_amd import ops
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+M = 331776
+for name, N, K in (("qk  N=3072 K=1536", 3072, 1536), ("c1  N=2048 K=1536", 2048, 1536), ("fc  N=1536 K=1536", 1536, 1536),
+                   ("c2  N=1536 K=2048", 1536, 2048)):
+    a = torch.randn(M, K, device="cuda").half()
+    w = torch.randn(N, K, device="cuda") * 0.05
+    hi = w.half(); lo = (w - hi.float()).half()
+    out = torch.empty(M, N, dtype=torch.float16, device="cuda")
+    f = lambda: ops.gemm_nt(a, hi, out16=out, b_lo=lo, lo_scale=1.0)
+    for _ in range(2): f()
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for x, y in ev:
+        x.record(); f(); y.record()
+    torch.cuda.synchronize()
+    ms = sorted(x.elapsed_time(y) for x, y in ev)[len(ev) // 2]
+    print(f"{name}: {ms:.3f} ms  algorithmic {2.0 * M * N * K / ms / 1e9:.0f} TF/s  executed {4.0 * M * N * K / ms / 1e9:.0f} TF/s   lib={os.environ.get('DVD_HIP_LIB', 'product')}")
+    del a, w, hi, lo, out

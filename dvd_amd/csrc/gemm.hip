@@ -53,6 +53,38 @@ struct GemmArgs {
   unsigned long long* stamps;
 };
 
+// Tile walk of the persistent kernels.  Virtual id `vid` runs on XCD vid % 8 (hardware round-robin) as that XCD's k-th
+// tile, k = vid / 8; an XCD owns a contiguous range of row panels.  At any time an XCD's 32 CUs work on 32 consecutive k.
+//  * default: row-major inside the XCD's range - the 32 tiles cover ~32/ntn row panels x all N tiles, so per 32 tiles the
+//    XCD's 4 MB L2 sees (32/ntn) A panels + ntn W panels;
+//  * wide outputs (ntn a multiple of 4, >= 8; needs ntm % 8 == 0): blocks of 8 row panels x 4 N tiles - 8 A panels (0.79 MB
+//    each at K = 1536) + 4 W panels (1.57 MB each, hi + lo), the minimum of a_bytes * rows + w_bytes * cols at rows * cols
+//    = 32; at N = 3072 the row-major walk streamed all 12 W panels (18.9 MB) through L2 for every 32 tiles.
+// The order changes which workgroup computes a tile, never a tile's arithmetic.
+__device__ __forceinline__ void tile_coords(int vid, int ntm, int ntn, int& tm, int& tn) {
+  const int nwg = ntm * ntn;
+  const int q = nwg / 8, rr = nwg % 8, xcd = vid % 8, k = vid / 8;
+  if (rr == 0 && (ntm & 7) == 0 && (ntn & 3) == 0 && ntn >= 8) {
+    const int rows = ntm >> 3;               // row panels per XCD
+    const int grp = 8 * ntn;                 // tiles in a group of 8 row panels (a multiple of 32)
+    const int g = k / grp, rem = k - g * grp;
+    if (g < (rows >> 3)) {
+      const int b = rem >> 5, i = rem & 31;
+      tm = xcd * rows + g * 8 + (i & 7);
+      tn = 4 * b + (i >> 3);
+    } else {                                 // the last rows % 8 row panels of the XCD: row-major
+      const int k2 = k - (rows >> 3) * grp;
+      tm = xcd * rows + (rows & ~7) + k2 / ntn;
+      tn = k2 % ntn;
+    }
+    return;
+  }
+  const int id = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + k;
+  tm = id / ntn;
+  tn = id % ntn;
+}
+
+
 __device__ __forceinline__ float gelu_tanh(float x) {
   const float k0 = 0.7978845608028654f, k1 = 0.044715f;
   float u = k0 * (x + k1 * x * x * x);
@@ -474,12 +506,9 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_big_kernel(GemmArgs p) {
   const int r = lane & 31, h = lane >> 5;
   const int wr = wave >> 2, wc = wave & 3;
   for (int vid = blockIdx.x; vid < nwg; vid += gridDim.x) {
-  int id = vid;
-  {
-    const int q = nwg / 8, rr = nwg % 8, xcd = id % 8, k = id / 8;
-    id = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + k;
-  }
-  const int tm = id / p.ntn, tn = id % p.ntn;
+  int tm, tn;
+  tile_coords(vid, p.ntm, p.ntn, tm, tn);
+  tm = __builtin_amdgcn_readfirstlane(tm); tn = __builtin_amdgcn_readfirstlane(tn);   // wave-uniform: keep in SGPRs
   const int bm0 = tm * 256, bn0 = tn * 256;
   const _Float16* A = (const _Float16*)p.A + z * p.sA;
   const _Float16* B = (const _Float16*)p.B + z * p.sB;
@@ -704,12 +733,9 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_split_kernel(GemmArgs p) {
   const int r = lane & 31, h = lane >> 5;
   const int wr = wave >> 2, wc = wave & 3;
   for (int vid = blockIdx.x; vid < nwg; vid += gridDim.x) {
-  int id = vid;
-  {
-    const int q = nwg / 8, rr = nwg % 8, xcd = id % 8, k = id / 8;
-    id = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + k;
-  }
-  const int tm = id / p.ntn, tn = id % p.ntn;
+  int tm, tn;
+  tile_coords(vid, p.ntm, p.ntn, tm, tn);
+  tm = __builtin_amdgcn_readfirstlane(tm); tn = __builtin_amdgcn_readfirstlane(tn);   // wave-uniform: keep in SGPRs
   const int bm0 = tm * 256, bn0 = tn * 256;
   const _Float16* A = (const _Float16*)p.A + z * p.sA;
   const _Float16* B = (const _Float16*)p.B + z * p.sB;
@@ -880,12 +906,9 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_split128_kernel(GemmArgs p) {
   const int r = lane & 31, h = lane >> 5;
   const int wr = wave >> 1, wc = wave & 1;
   for (int vid = blockIdx.x; vid < nwg; vid += gridDim.x) {
-  int id = vid;
-  {
-    const int q = nwg / 8, rr = nwg % 8, xcd = id % 8, k = id / 8;
-    id = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + k;
-  }
-  const int tm = id / p.ntn, tn = id % p.ntn;
+  int tm, tn;
+  tile_coords(vid, p.ntm, p.ntn, tm, tn);
+  tm = __builtin_amdgcn_readfirstlane(tm); tn = __builtin_amdgcn_readfirstlane(tn);   // wave-uniform: keep in SGPRs
   const int bm0 = tm * 256, bn0 = tn * 128;
   const _Float16* A = (const _Float16*)p.A + z * p.sA;
   const _Float16* B = (const _Float16*)p.B + z * p.sB;
