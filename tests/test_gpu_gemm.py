@@ -25,7 +25,8 @@ def gelu_tanh(x):
     return 0.5 * x * (1 + torch.tanh(0.7978845608028654 * (x + 0.044715 * x ** 3)))
 
 
-@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 384), (200, 130, 128), (1024, 1152, 384), (64, 2048, 1536)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 384), (200, 130, 128), (1024, 1152, 384), (64, 2048, 1536),
+                                   (4096, 2048, 128), (32768, 3072, 64)])
 @pytest.mark.parametrize("dt", ["f16", "f32"])
 def test_gemm_plain(ops, M, N, K, dt):
     a, b = rnd(f"ga{M}{K}", (M, K)), rnd(f"gb{N}{K}", (N, K))
@@ -158,7 +159,10 @@ def test_gemm_large_tile_split_weights(ops):
 
 
 @pytest.mark.parametrize("M,N,K", [(2048, 1536, 1536), (1100, 512, 128), (4096, 256, 64), (1024, 2048, 1536),
-                                   (1100, 384, 384), (2048, 1152, 384), (300, 128, 64)])
+                                   (1100, 384, 384), (2048, 1152, 384), (300, 128, 64),
+                                   # ntm % 8 == 0 and ntn in {8, 12}: the blocked XCD tile walk (8 row panels x 4 N tiles),
+                                   # incl. an XCD range with leftover row panels (M = 6144: 3 per XCD)
+                                   (2048, 2048, 128), (4096, 3072, 64), (6144, 2048, 64), (32768, 3072, 64)])
 def test_gemm_fused_split_kernel(ops, M, N, K):
     """lo_scale = 1 with an UNSCALED lo part (f16 subnormals) routes to the one-pass kernel (three LDS tiles, one
     accumulator set).  Result: fp32-weight grade, and equal to the two-pass kernel up to fp32 summation order;
