@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""Time the full-resolution gathers (3508 x 2480, document-like flow) - drop-in grid_sample f32 (32 B/px), fused f32 tail
+(24 B/px), fused u8 tail (6 B/px) - with B documents per launch.  usage: [DVD_HIP_LIB=...] python benchmarks/warp_time.py [B=8]"""
+import os, sys
+sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
+import torch
+from dvd_amd import ops
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+H, W, G = 3508, 2480, 288
+gen = torch.Generator(device="cuda").manual_seed(3)
+ctrl = (torch.rand(B, 2, 6, 6, device="cuda", generator=gen) - 0.5) * 0.1
+flow = torch.nn.functional.interpolate(ctrl, size=(G, G), mode="bicubic", align_corners=True).contiguous()
+src8 = torch.randint(0, 256, (B, H, W, 3), device="cuda", dtype=torch.uint8, generator=gen)
+srcf = src8.permute(0, 3, 1, 2).float().contiguous()
+grid = torch.cat([ops.unwarp_grid(flow[d:d + 1].contiguous(), H, W) for d in range(B)])
+def t(f, n=7):
+    for _ in range(2): f()
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+    for a, b in ev:
+        a.record(); f(); b.record()
+    torch.cuda.synchronize()
+    return sorted(a.elapsed_time(b) for a, b in ev)[n // 2]
+lib = os.environ.get("DVD_HIP_LIB", "product")
+for name, f, bpp in (("grid_sample f32 (32 B/px)", lambda: ops.grid_sample(srcf, grid), 32),
+                     ("unwarp_f32 fused (24 B/px)", lambda: ops.unwarp_f32_batch(flow, srcf), 24),
+                     ("unwarp_u8 fused (6 B/px)", lambda: ops.unwarp_u8_batch(flow, src8), 6)):
+    ms = t(f)
+    print(f"{name:28s} B={B}: {ms:.3f} ms  {bpp * H * W * B / ms / 1e6:.0f} GB/s   lib={lib}")
