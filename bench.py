@@ -107,7 +107,7 @@ def max_over_ranks(elapsed, world, dev):
     return float(t.item())
 
 
-def main():
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1)
@@ -121,7 +121,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-split-weights", action="store_true")
     ap.add_argument("--no-ffn-lo", action="store_true", help="opt-in fast mode: drop the lo pass of the decoder FFN convs")
-    args = ap.parse_args()
+    ap.add_argument("--backend", default="nccl", help="process-group backend (nccl = RCCL; the CPU test of the rank logic uses gloo)")
+    args = ap.parse_args(argv)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -130,10 +131,10 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    init_dist(world, local)
+    init_dist(world, local, backend=args.backend)
 
     from dvd_amd import lib, ops, sampler, schedule, synth
-    from dvd_amd.engine import Engine
+    from dvd_amd.engine import Engine, aligned_empty
 
     G, B, H, S = args.grid, args.docs, args.hyp, args.ddim_steps
     FH, FW = (int(v) for v in args.full_res.split("x"))
@@ -145,12 +146,11 @@ def main():
 
     # ---- weights: rank 0 builds + packs, ONE flat RCCL broadcast (the only collective of the path) ----
     _, blob_bytes = eng.blob_layout()
+    blob = aligned_empty(blob_bytes, dev)
     if rank == 0:
         sd = synth.synth_state_dict(G, seed=7, blocks=[11])
-        blob = eng.pack_blob(sd).to(dev)
+        blob.copy_(eng.pack_blob(sd))
         del sd
-    else:
-        blob = torch.empty(blob_bytes, dtype=torch.uint8, device=dev)
     bcast_ms = broadcast_weights(blob, world, torch.cuda.synchronize)
     eng.bind_blob(blob)
 

@@ -23,6 +23,13 @@ def _is_dev(t) -> bool:
     return t.is_cuda
 
 
+def aligned_empty(nbytes: int, device, align: int = 256) -> torch.Tensor:
+    """uint8 buffer of `nbytes` whose address is a multiple of `align` (the engine's requirement for blobs and workspaces)."""
+    store = torch.empty(nbytes + align, dtype=torch.uint8, device=device)
+    off = (-store.data_ptr()) % align
+    return store[off:off + nbytes]
+
+
 def tensor_specs(grid: int):
     """[(name, dtype 0=f32/1=f16, nelem)] of the engine's weight set for a grid - host-only (no device memory, no
     workspace): what every rank needs to size the flat blob before the one-shot broadcast."""
