@@ -60,8 +60,9 @@ def main():
 
     res = {"what": f"one document, G={G}, {S}-step DDIM, {H} hypotheses, + {FH}x{FW} u8 unwarp (reference-native point)"}
     flows = {}
-    for tag, on in (("eager", 0), ("graphs", 1)):
+    for tag, on, small in (("eager_256tiles", 0, 0), ("eager", 0, 1), ("graphs", 1, 1)):
         eng.set_option("graphs", on)
+        eng.set_option("small_tiles", small)
         for _ in range(4):
             one()
         torch.cuda.synchronize()

@@ -155,6 +155,7 @@ struct Engine {
   // ---- options (dvd_engine_set_option; fixed for the life of a captured graph) ----
   bool split_weights = true;   // use the lo parts (fp32-grade weights, 2x GEMM MFMAs)
   bool ffn_lo = true;          // keep the lo parts of the decoder FFN's two 1x1 convs (see dvd_engine_set_option)
+  bool small_tiles = false;    // 128x128 GEMM tiles for the per-step GEMMs (small grids; set from the grid in create)
   bool use_graphs = false;     // replay a denoiser evaluation as one hipGraph (launch-bound small grids)
   // optional per-launch timing of the dominant kernel (decoder attention) with HIP events on the launch stream:
   // a ring of event pairs, drained into running totals when it wraps, so EVERY launch of the timed region counts
@@ -275,6 +276,7 @@ static int gemm(int dtype, int M, int N, int K, int batch, const void* A, int ld
   d.pos = pos; d.ldpos = N; d.pos_rows = pos_rows;
   d.gate = gate; d.ldgate = N; d.gate_rows = gate_rows;
   d.res = res; d.ldres = ldres; d.strideRes = sRes;
+  if (dtype == 2) { d.dtype = 0; d.small_tiles = 1; }     // dtype 2 = f16 operands on 128x128 tiles (small grids)
   return dvd_gemm_nt(&d, stream);
 }
 
@@ -312,6 +314,9 @@ extern "C" int dvd_engine_create(int grid, int docs, int n_hyp, void** handle) {
   e->specs = tensor_specs(grid);
   e->wptr.assign(e->specs.size(), nullptr);
   plan(e);
+  // a few thousand rows per GEMM put < 50 of the 256x256 persistent tiles on 256 CUs: small grids take 128x128 tiles.
+  // Decided from the GRID only (never the batch): a document gets the same kernels alone or in a batch.
+  e->small_tiles = e->T <= 1024;
   if (!resolve_indices(e)) {
     delete e;
     set_error("engine_create: internal tensor/buffer table mismatch");
@@ -395,6 +400,7 @@ extern "C" int dvd_engine_set_option(void* handle, const char* name, int value) 
   DVD_REQUIRE(handle && name, "engine_set_option: null pointer");
   Engine* e = (Engine*)handle;
   if (strcmp(name, "split_weights") == 0) { e->split_weights = value != 0; e->drop_graphs(); return DVD_OK; }
+  if (strcmp(name, "small_tiles") == 0) { e->small_tiles = value != 0; e->drop_graphs(); return DVD_OK; }
   if (strcmp(name, "ffn_lo") == 0) { e->ffn_lo = value != 0; e->drop_graphs(); return DVD_OK; }
   if (strcmp(name, "graphs") == 0) {
     e->use_graphs = value != 0;
@@ -540,6 +546,7 @@ static int enqueue_step(Engine* e, const float* x_t, int feat_mode, const float*
   const int G = e->G, N = e->N, side = e->side, hyp = e->hyp;
   const int T = (int)e->T;
   const long NT = e->NT;
+  const int F16 = e->small_tiles ? 2 : 0;     // gemm() dtype code: f16 operands, 128x128 tiles on small grids
 
   float* tbuf = (float*)e->B(e->bi.tbuf);
   float* th = (float*)e->B(e->bi.th);
@@ -573,15 +580,15 @@ static int enqueue_step(Engine* e, const float* x_t, int feat_mode, const float*
   TRY(dvd_embed_obs_ln(x_t, e->F(e->wi.obs_w), e->F(e->wi.obs_b), e->F(e->wi.pos), xtok32, xq16, N, G, stream));
   TRY(dvd_build_r_rows((const float*)e->B(e->bi.feat), init_feat_nchw, init_flow, arows16, RK, N, G, hyp, feat_mode,
                        stream));
-  TRY(gemm(0, (int)NT, HID, RK, 1, arows16, RK, 0, e->H(e->wi.r_w16), RK, 0, nullptr, 0, 0, rtok16, HID, 0, e->F(e->wi.r_b), 0,
+  TRY(gemm(F16, (int)NT, HID, RK, 1, arows16, RK, 0, e->H(e->wi.r_w16), RK, 0, nullptr, 0, 0, rtok16, HID, 0, e->F(e->wi.r_b), 0,
            0, e->F(e->wi.pos), T, nullptr, 0, nullptr, 0, 0, stream, nullptr, e->L(e->wi.r_w16)));
 
   // --- parallel cross-attention of the shared query against the 4 streams (:237-265) ---
-  TRY(gemm(0, (int)NT, HID, HID, 1, xq16, HID, 0, e->H(e->wi.ca_wq16), HID, 0, nullptr, 0, 0, q16, HID, 0, e->F(e->wi.ca_bq),
+  TRY(gemm(F16, (int)NT, HID, HID, 1, xq16, HID, 0, e->H(e->wi.ca_wq16), HID, 0, nullptr, 0, 0, q16, HID, 0, e->F(e->wi.ca_bq),
            0, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0, stream, nullptr, e->L(e->wi.ca_wq16)));
-  TRY(gemm(0, (int)NT, HID, HID, 1, rtok16, HID, 0, e->H(e->wi.ca_wk16), HID, 0, nullptr, 0, 0, kr16, HID, 0,
+  TRY(gemm(F16, (int)NT, HID, HID, 1, rtok16, HID, 0, e->H(e->wi.ca_wk16), HID, 0, nullptr, 0, 0, kr16, HID, 0,
            e->F(e->wi.ca_bk), 0, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0, stream, nullptr, e->L(e->wi.ca_wk16)));
-  TRY(gemm(0, HID, T, HID, N, e->H(e->wi.ca_wv16), HID, 0, rtok16, HID, (long)T * HID, nullptr, 0, 0, vtr16, T,
+  TRY(gemm(F16, HID, T, HID, N, e->H(e->wi.ca_wv16), HID, 0, rtok16, HID, (long)T * HID, nullptr, 0, 0, vtr16, T,
            (long)HID * T, e->F(e->wi.ca_bv), 1, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0, stream, e->L(e->wi.ca_wv16), nullptr));
   {
     const int kn[3] = {e->bi.kc16, e->bi.km16, e->bi.kl16};
@@ -593,27 +600,27 @@ static int enqueue_step(Engine* e, const float* x_t, int feat_mode, const float*
              att16 + (size_t)3 * NT * HID, HID, (long)T * HID, 0.125f, stream));
   }
   // x_s = x + out_proj(attn_s)  -> z[:, 384 s : 384 (s+1)]   (stream order cond, msk6, line, r == cat order :623)
-  TRY(gemm(0, (int)NT, HID, HID, 4, att16, HID, NT * HID, e->H(e->wi.ca_wo16), HID, 0, z, DEC, HID, nullptr, 0, 0,
+  TRY(gemm(F16, (int)NT, HID, HID, 4, att16, HID, NT * HID, e->H(e->wi.ca_wo16), HID, 0, z, DEC, HID, nullptr, 0, 0,
            e->F(e->wi.ca_bo), 0, 0, nullptr, 0, nullptr, 0, xtok32, HID, 0, stream, nullptr, e->L(e->wi.ca_wo16)));
 
   if (e->debug_stop == 1) return check_launch("engine_denoise_step(stop 1)");
   // --- per stream: gated self-attention (:268-289) ---
   TRY(dvd_layernorm_rows(z, DEC, HID, h16, HID, NT * HID, 4, NT, HID, nullptr, nullptr, sh_a, sc_a, 0, (int)NT, 1e-6f,
                          stream));
-  TRY(gemm(0, (int)(4 * NT), 2 * HID, HID, 1, h16, HID, 0, e->H(e->wi.sa_wqk16), HID, 0, nullptr, 0, 0, qk16, 2 * HID, 0,
+  TRY(gemm(F16, (int)(4 * NT), 2 * HID, HID, 1, h16, HID, 0, e->H(e->wi.sa_wqk16), HID, 0, nullptr, 0, 0, qk16, 2 * HID, 0,
            e->F(e->wi.sa_bqk), 0, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0, stream, nullptr, e->L(e->wi.sa_wqk16)));
-  TRY(gemm(0, HID, T, HID, 4 * N, e->H(e->wi.sa_wv16), HID, 0, h16, HID, (long)T * HID, nullptr, 0, 0, vt16, T,
+  TRY(gemm(F16, HID, T, HID, 4 * N, e->H(e->wi.sa_wv16), HID, 0, h16, HID, (long)T * HID, nullptr, 0, 0, vt16, T,
            (long)HID * T, e->F(e->wi.sa_bv), 1, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0, stream, e->L(e->wi.sa_wv16), nullptr));
   TRY(attn(64, 6, 4 * N, T, T, 1, qk16, 2 * HID, (long)T * 2 * HID, qk16 + HID, 2 * HID, (long)T * 2 * HID, vt16, T,
            (long)HID * T, att16, HID, (long)T * HID, 0.125f, stream));
-  TRY(gemm(0, (int)NT, HID, HID, 4, att16, HID, NT * HID, e->H(e->wi.sa_wp16), HID, 0, z, DEC, HID, nullptr, 0, 0,
+  TRY(gemm(F16, (int)NT, HID, HID, 4, att16, HID, NT * HID, e->H(e->wi.sa_wp16), HID, 0, z, DEC, HID, nullptr, 0, 0,
            e->F(e->wi.sa_bp), 0, 0, nullptr, 0, g_a, (int)NT, z, DEC, HID, stream, nullptr, e->L(e->wi.sa_wp16)));
   // --- per stream: gated MLP (:271-292) ---
   TRY(dvd_layernorm_rows(z, DEC, HID, h16, HID, NT * HID, 4, NT, HID, nullptr, nullptr, sh_m, sc_m, 0, (int)NT, 1e-6f,
                          stream));
-  TRY(gemm(0, (int)(4 * NT), 4 * HID, HID, 1, h16, HID, 0, e->H(e->wi.fc1_w16), HID, 0, nullptr, 0, 0, mlp16, 4 * HID, 0,
+  TRY(gemm(F16, (int)(4 * NT), 4 * HID, HID, 1, h16, HID, 0, e->H(e->wi.fc1_w16), HID, 0, nullptr, 0, 0, mlp16, 4 * HID, 0,
            e->F(e->wi.fc1_b), 0, /*gelu*/ 1, nullptr, 0, nullptr, 0, nullptr, 0, 0, stream, nullptr, e->L(e->wi.fc1_w16)));
-  TRY(gemm(0, (int)NT, HID, 4 * HID, 4, mlp16, 4 * HID, NT * 4 * HID, e->H(e->wi.fc2_w16), 4 * HID, 0, z, DEC, HID,
+  TRY(gemm(F16, (int)NT, HID, 4 * HID, 4, mlp16, 4 * HID, NT * 4 * HID, e->H(e->wi.fc2_w16), 4 * HID, 0, z, DEC, HID,
            nullptr, 0, 0, e->F(e->wi.fc2_b), 0, 0, nullptr, 0, g_m, (int)NT, z, DEC, HID, stream, nullptr, e->L(e->wi.fc2_w16)));
 
   if (e->debug_stop == 2) return check_launch("engine_denoise_step(stop 2)");
@@ -637,9 +644,9 @@ static int enqueue_step(Engine* e, const float* x_t, int feat_mode, const float*
     const WIdx::Dec& dw = e->wi.d[j];
     TRY(dvd_layernorm_rows(z, DEC, 0, h16, DEC, 0, 1, NT, DEC, e->F(dw.n1w), e->F(dw.n1b), nullptr, nullptr, 0,
                            1, 1e-5f, stream));
-    TRY(gemm(0, (int)NT, 2 * DEC, DEC, 1, h16, DEC, 0, e->H(dw.wqk16), DEC, 0, nullptr, 0, 0, qk16, 2 * DEC, 0,
+    TRY(gemm(F16, (int)NT, 2 * DEC, DEC, 1, h16, DEC, 0, e->H(dw.wqk16), DEC, 0, nullptr, 0, 0, qk16, 2 * DEC, 0,
              nullptr, 0, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0, stream, nullptr, e->L(dw.wqk16)));
-    TRY(gemm(0, DEC, T, DEC, N, e->H(dw.wv16), DEC, 0, h16, DEC, (long)T * DEC, nullptr, 0, 0, vt16, T,
+    TRY(gemm(F16, DEC, T, DEC, N, e->H(dw.wv16), DEC, 0, h16, DEC, (long)T * DEC, nullptr, 0, 0, vt16, T,
              (long)DEC * T, nullptr, 0, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0, stream, e->L(dw.wv16), nullptr));
     const bool timed = e->prof_on;
     size_t slot = 0;
@@ -651,14 +658,14 @@ static int enqueue_step(Engine* e, const float* x_t, int feat_mode, const float*
     TRY(attn(256, 6, N, T, T, 1, qk16, 2 * DEC, (long)T * 2 * DEC, qk16 + DEC, 2 * DEC, (long)T * 2 * DEC, vt16, T,
              (long)DEC * T, att16, DEC, (long)T * DEC, 0.0625f, stream));
     if (timed) { (void)hipEventRecord(e->prof_ev[2 * slot + 1], st); e->prof_inflight += 1; }
-    TRY(gemm(0, (int)NT, DEC, DEC, 1, att16, DEC, 0, e->H(dw.wfc16), DEC, 0, z, DEC, 0, nullptr, 0, 0, nullptr, 0,
+    TRY(gemm(F16, (int)NT, DEC, DEC, 1, att16, DEC, 0, e->H(dw.wfc16), DEC, 0, z, DEC, 0, nullptr, 0, 0, nullptr, 0,
              0, nullptr, 0, nullptr, 0, z, DEC, 0, stream, nullptr, e->L(dw.wfc16)));
     TRY(dvd_layernorm_rows(z, DEC, 0, h16, DEC, 0, 1, NT, DEC, e->F(dw.n2w), e->F(dw.n2b), nullptr, nullptr, 0,
                            1, 1e-5f, stream));
-    TRY(gemm(0, (int)NT, FFN, DEC, 1, h16, DEC, 0, e->H(dw.c1w16), DEC, 0, nullptr, 0, 0, f1, FFN, 0,
+    TRY(gemm(F16, (int)NT, FFN, DEC, 1, h16, DEC, 0, e->H(dw.c1w16), DEC, 0, nullptr, 0, 0, f1, FFN, 0,
              e->F(dw.c1b), 0, 2, nullptr, 0, nullptr, 0, nullptr, 0, 0, stream, nullptr, e->Lffn(dw.c1w16)));
     TRY(dvd_dwconv3x3(f1, f2, e->F(dw.dww), e->F(dw.dwb), N, side, FFN, stream));
-    TRY(gemm(0, (int)NT, DEC, FFN, 1, f2, FFN, 0, e->H(dw.c2w16), FFN, 0, z, DEC, 0, nullptr, 0, 0,
+    TRY(gemm(F16, (int)NT, DEC, FFN, 1, f2, FFN, 0, e->H(dw.c2w16), FFN, 0, z, DEC, 0, nullptr, 0, 0,
              e->F(dw.c2b), 0, 2, nullptr, 0, nullptr, 0, z, DEC, 0, stream, nullptr, e->Lffn(dw.c2w16)));
     if (e->debug_stop == 4 + j) return check_launch("engine_denoise_step(stop 4+j)");
   }

@@ -1129,9 +1129,10 @@ extern "C" int dvd_gemm_nt(const dvd_gemm_desc* d, void* stream) {
   // large-tile kernel for the big f16 GEMMs (decoder): N a multiple of 256, at least a few row tiles
   // kernel choice depends on (dtype, N, K, split) only, never on M: a document then takes the same kernels - and the
   // same fp32 summation order - whether it is sampled alone or in a batch (bit-identical results, tested)
-  const bool big = d->dtype == 0 && d->N % 256 == 0 && !lab_v1;
+  const bool small = d->small_tiles != 0;      // the caller's problem family is small: 128x128 tiles everywhere
+  const bool big = d->dtype == 0 && d->N % 256 == 0 && !lab_v1 && !small;
   if (d->dtype == 0 && d->N % 128 == 0 && d->N % 256 != 0 && d->B_lo && !d->A_lo && d->lo_scale == 1.f &&
-      !lab_twopass && !lab_v1) {
+      !lab_twopass && !lab_v1 && !small) {
     p.ntm = cdiv(d->M, 256); p.ntn = d->N / 128;
     constexpr int LDS = 8 * 16384;                    // 3 stages x 32 KiB, rounded up to the epilogue's 8 x 16 KiB
     static bool once_s1 = false;

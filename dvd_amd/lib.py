@@ -55,7 +55,7 @@ class GemmDesc(C.Structure):
                 ("act", C.c_int),
                 ("pos", C.c_void_p), ("ldpos", C.c_int), ("pos_rows", C.c_int),
                 ("gate", C.c_void_p), ("ldgate", C.c_int), ("gate_rows", C.c_int), ("strideGate", C.c_long),
-                ("res", C.c_void_p), ("ldres", C.c_int), ("strideRes", C.c_long)]
+                ("res", C.c_void_p), ("ldres", C.c_int), ("strideRes", C.c_long), ("small_tiles", C.c_int)]
 
 
 class AttnDesc(C.Structure):

@@ -138,7 +138,7 @@ def _addr(t):
 
 def gemm_nt(a, b, *, out32=None, out16=None, bias=None, bias_row=False, act=0, pos=None, gate=None,
             gate_rows=0, res=None, batch=1, strides=None, M=None, N=None, K=None, lda=None, ldb=None, b_lo=None,
-            a_lo=None, lo_scale=2.0 ** -11):
+            a_lo=None, lo_scale=2.0 ** -11, small_tiles=False):
     """C = epi(A . B^T).  a [M,K] / b [N,K] f16 or f32 device tensors (2-D views may be strided in rows).
     strides: dict of batch strides in elements (A,B,C32,C16,bias,gate,res)."""
     assert a.dtype == b.dtype and a.dtype in (torch.float16, torch.float32)
@@ -168,6 +168,7 @@ def gemm_nt(a, b, *, out32=None, out16=None, bias=None, bias_row=False, act=0, p
         d.gate, d.ldgate, d.gate_rows, d.strideGate = _addr(gate), gate.stride(-2), gate_rows, st.get("gate", 0)
     if res is not None:
         d.res, d.ldres, d.strideRes = _addr(res), res.stride(-2), st.get("res", 0)
+    d.small_tiles = int(small_tiles)
     lib.call("dvd_gemm_nt", C.byref(d), stream_ptr())
 
 

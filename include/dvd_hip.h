@@ -126,6 +126,10 @@ typedef struct {
   const float* pos; int ldpos; int pos_rows;
   const float* gate; int ldgate; int gate_rows; long strideGate;
   const float* res; int ldres; long strideRes;
+  int small_tiles;                           /* f16 only: 1 = 128x128 tiles for every shape.  The caller's statement about
+                                                its PROBLEM FAMILY (the engine sets it from the grid, never from the batch):
+                                                at a few thousand rows the 256x256 persistent kernels put < 50 workgroups on
+                                                256 CUs and run one workgroup's K loop latency-bound */
 } dvd_gemm_desc;
 
 int dvd_gemm_nt(const dvd_gemm_desc* desc, void* stream);
@@ -285,7 +289,10 @@ int dvd_engine_set_tensor(void* handle, const char* name, const void* dev_ptr, l
  *   "ffn_lo"        (default 1): 0 drops the lo pass of the decoder FFN's two 1x1 convs only (-4.8 % step time;
  *                                measured coordinate error on synthetic weights 1.2e-4 -> 3.3e-4: opt-in);
  *   "graphs"        (default 0): replay each denoiser evaluation as a captured hipGraph (bit-identical results;
- *                                the Python engine turns it on for grids <= 128). */
+ *                                the Python engine turns it on for grids <= 128);
+ *   "small_tiles"   (default: 1 when (grid/2)^2 <= 1024 tokens, i.e. grid <= 64, else 0): 128x128 GEMM tiles for
+ *                                the per-step GEMMs - a function of the grid only, so a document takes the same kernels
+ *                                and the same summation order alone or in a batch. */
 int dvd_engine_set_option(void* handle, const char* name, int value);
 /* y512 [docs,3,512,512] (0..1), mask_cat [docs,1,512,512], mask_y512 [docs,384,G,G], line_msk [docs,64,G,G]
  * (kwargs of the denoiser call, train_settings/dvd/evaluation.py:106-115). */
