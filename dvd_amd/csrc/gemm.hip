@@ -57,6 +57,7 @@ struct GemmArgs {
 // tile, k = vid / 8; an XCD owns a contiguous range of row panels.  At any time an XCD's 32 CUs work on 32 consecutive k.
 //  * default: row-major inside the XCD's range - the 32 tiles cover ~32/ntn row panels x all N tiles, so per 32 tiles the
 //    XCD's 4 MB L2 sees (32/ntn) A panels + ntn W panels;
+//  * few row panels (ntm < 8) and many N tiles: column-major (see below);
 //  * wide outputs (ntn a multiple of 4, >= 8; needs ntm % 8 == 0): blocks of 8 row panels x 4 N tiles - 8 A panels (0.79 MB
 //    each at K = 1536) + 4 W panels (1.57 MB each, hi + lo), the minimum of a_bytes * rows + w_bytes * cols at rows * cols
 //    = 32; at N = 3072 the row-major walk streamed all 12 W panels (18.9 MB) through L2 for every 32 tiles.
@@ -80,6 +81,11 @@ __device__ __forceinline__ void tile_coords(int vid, int ntm, int ntn, int& tm, 
     return;
   }
   const int id = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + k;
+  if (ntm < 8 && ntn >= 32) {      // few row panels, many N tiles (the V^T projections: weights on the A side, M = 1536):
+    tn = id / ntm;                 // column-major - the 32 tiles an XCD works on share ALL ntm A panels and 32 / ntm B
+    tm = id % ntm;                 // panels (9 MB at ntm = 6) instead of one A panel and 32 B panels (26 MB)
+    return;
+  }
   tm = id / ntn;
   tn = id % ntn;
 }

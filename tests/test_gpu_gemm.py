@@ -228,3 +228,20 @@ def test_gemm_kernel_variants(ops, lab, monkeypatch, env):
     ops.gemm_nt(a.cuda(), hi.cuda(), out16=out16, bias=bias.cuda(), act=1)
     refg = torch.nn.functional.gelu((a.double() @ hi.double().t()) + bias.double(), approximate="tanh")
     assert (out16.cpu().double() - refg).abs().max() < 2e-3, env
+
+
+def test_gemm_weights_on_a_side_column_major_walk(ops):
+    """The V^T projection's shape family - split weights on the A side (two sweeps over K), few row panels (ntm = 6) and many
+    N tiles (ntn = 36 >= 32): the column-major XCD tile walk - batched, against float64."""
+    D, T, K, B = 1536, 9216, 128, 2
+    w = rnd("vt/w", (D, K)) * 0.05
+    hi = w.half()
+    lo = (w - hi.float()).half()
+    h = rnd("vt/h", (B * T, K)).half()
+    out = torch.zeros(B, D, T, dtype=torch.float16, device="cuda")
+    ops.gemm_nt(hi.cuda(), h.cuda(), out16=out.view(B * D, T), a_lo=lo.cuda(), lo_scale=1.0, batch=B, M=D, N=T, K=K,
+                lda=K, ldb=K, strides={"B": T * K, "C16": D * T})
+    for b in range(B):
+        ref = w.double() @ h[b * T:(b + 1) * T].double().t()
+        err = (out[b].cpu().double() - ref).abs().max().item()
+        assert err < 2e-3 * max(1.0, ref.abs().max().item()), (b, err)          # f16 output rounding dominates
