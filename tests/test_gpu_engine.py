@@ -124,23 +124,25 @@ def test_sampling_loop_vs_reference_golden(grid, steps):
     assert err < 2.7e-4, (err, per_step)   # measured 6.5e-5 .. 9.0e-5 (x3); north_star's bar is 1e-3
 
 
-@pytest.mark.parametrize("grid,steps", [(16, 50), (32, 50), (96, 50), (72, 50)])
-def test_long_loop_vs_oracle(grid, steps):
+@pytest.mark.parametrize("grid,steps,hyp", [(16, 50, 2), (32, 50, 2), (96, 50, 1), (72, 25, 1)])
+def test_long_loop_vs_oracle(grid, steps, hyp):
     """BASELINE's 50-step DDIM (not reference-runnable natively: local.py has 3 steps) against the CPU oracle.
     G = 96 is an UP-sampling, non-native grid like BASELINE's 288 (feat 64 -> G, T % 64 == 0: the LDS-DMA attention
     kernels, warped-feat branch live from step 2); G = 72 is ragged (T = 1296, T % 64 = 16: the register-staged
-    attention fallback and the GEMM edge tiles)."""
+    attention fallback and the GEMM edge tiles).  The two large grids run one hypothesis (and the ragged one 25 steps) to
+    keep the oracle - which dominates this suite's run time - inside the driver's time limit; the whole 50-step loop at
+    G = 288 is recorded once per round in profiles/ (tests/tools/parity_g288.py)."""
     from dvd_amd import sampler, schedule
     from oracle import dvd_oracle as O
-    eng, orc, doc_t, inv1 = setup(grid)
+    eng, orc, doc_t, inv1 = setup(grid, 1, hyp)
     tab = schedule.Tables(schedule.named_betas("cosine", steps))
-    xT = torch.from_numpy(synth.synth_noise(0, 2, grid, SEED_IN))
+    xT = torch.from_numpy(synth.synth_noise(0, hyp, grid, SEED_IN))
     tr_ref, tr = [], []
     ref = orc.sample_loop(O.Schedule(steps), xT, {k: v[:1] for k, v in doc_t.items()}, trace=tr_ref)
     out = sampler.sample(eng, tab, xT.cuda(), trace=tr)
     per = [float((a.cpu() - b).pow(2).mean().sqrt()) for a, b in zip(tr, tr_ref)]
     err = float((out.cpu() - ref).pow(2).mean().sqrt())
-    print("long loop rmse", grid, steps, err, "per-step[::7]", per[::7], "last", per[-1])
+    print("long loop rmse", grid, steps, hyp, err, "per-step[::7]", per[::7], "last", per[-1])
     assert err < 3.8e-4, (err, per[-1])    # measured 1.2e-4 .. 1.3e-4 at G = 16 / 32 (x3); north_star's bar is 1e-3
     assert per[-1] < 1e-3, per[-1]          # un-clamped, un-averaged x0 of the last step (measured 5.6e-4 .. 6.0e-4)
 
