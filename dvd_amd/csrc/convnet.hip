@@ -27,6 +27,8 @@ struct ConvNet {
   std::vector<dvd_cn_op> ops;
   std::vector<CnSlot> slots;
   std::vector<int> kpad;       // per op (conv only): padded K
+  std::vector<int> ksplit;     // per op (conv only): K slices (1 = none)
+  size_t part_off = 0, part_bytes = 0;   // split-K partial sums
   size_t col_off = 0, col_bytes = 0, need_bytes = 0;
   long weight_floats = 0;
   int in_c, in_h, in_w;
@@ -162,6 +164,18 @@ __global__ void __launch_bounds__(256) mask_mul_kernel(const float* __restrict__
   for (int ch = 0; ch < c; ++ch) out[(long)ch * hw + i] = m * x[(long)ch * hw + i];
 }
 
+// out[i] = act(sum_s part[s][i] + bias[i % c]), slices added in order
+__global__ void __launch_bounds__(256) splitk_reduce_kernel(const float* __restrict__ part, int S, long mn,
+                                                            const float* __restrict__ bias, int c, int act,
+                                                            float* __restrict__ out) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= mn) return;
+  float v = part[i];
+  for (int s = 1; s < S; ++s) v += part[(long)s * mn + i];
+  v += bias[i % c];
+  out[i] = act == 2 ? fmaxf(v, 0.f) : v;
+}
+
 }  // namespace dvd
 
 using namespace dvd;
@@ -176,6 +190,8 @@ extern "C" int dvd_convnet_create(const dvd_cn_op* ops, int n_ops, int n_slots, 
   n->ops.assign(ops, ops + n_ops);
   n->slots.resize(n_slots);
   n->kpad.assign(n_ops, 0);
+  n->ksplit.assign(n_ops, 1);
+  size_t partmax = 0;
   n->in_c = in_c; n->in_h = in_h; n->in_w = in_w;
   n->slots[0].h = in_h; n->slots[0].w = in_w; n->slots[0].c = in_c; n->slots[0].set = true;
   size_t off = 0, colmax = 0;
@@ -210,6 +226,21 @@ extern "C" int dvd_convnet_create(const dvd_cn_op* ops, int n_ops, int n_slots, 
         wf += (long)o.cout * kp + (o.cout + 3) / 4 * 4;   // bias padded to 16 bytes: every conv's weights stay 16-byte aligned
         colmax = std::max(colmax, (size_t)a.h * a.w * kp * 4);
         d.h = a.h; d.w = a.w; d.c = o.cout;
+        {
+          // Small maps with wide channels (the UNet's deep layers: 324 ... 1296 pixels, K up to 9216) give the 128 x 128
+          // tile kernel a handful of workgroups and a K loop of hundreds of barrier-separated steps.  Such a conv is cut
+          // into S slices of K, run as ONE batched GEMM launch (batch stride = K / S along both operands) into S partial
+          // sums, and a small kernel adds them in slice order (deterministic), then bias and activation.
+          const long tiles = (long)((a.h * a.w + 127) / 128) * ((o.cout + 127) / 128);
+          int S = 1;
+          if (o.cout > 64 && kp >= 1024 && tiles < 128) {
+            const int units = kp / 16;
+            for (int c = 2; c <= units && tiles * c <= 256; ++c)
+              if (units % c == 0 && kp / c >= 128) S = c;
+          }
+          n->ksplit[i] = S;
+          if (S > 1) partmax = std::max(partmax, (size_t)S * a.h * a.w * o.cout * 4);
+        }
         break;
       }
       case DVD_CN_POOL:
@@ -239,7 +270,8 @@ extern "C" int dvd_convnet_create(const dvd_cn_op* ops, int n_ops, int n_slots, 
     n->slots[o.dst] = d;
   }
   n->col_off = off; n->col_bytes = al256(colmax);
-  n->need_bytes = off + n->col_bytes;
+  n->part_off = off + n->col_bytes; n->part_bytes = al256(partmax);
+  n->need_bytes = off + n->col_bytes + n->part_bytes;
   n->weight_floats = wf;
   *handle = n;
   return DVD_OK;
@@ -302,6 +334,17 @@ extern "C" int dvd_convnet_run(void* handle, const float* in_nchw, const float* 
         g.C32 = P(o.dst); g.ldc = o.cout;
         g.bias = weights + o.w_off + (long)o.cout * kp; g.act = o.act;
         g.lo_scale = 1.f;
+        const int S = n->ksplit[i];
+        if (S > 1) {                    // split-K: S partial products in one batched launch, then reduce + bias + act
+          float* part = (float*)(ws + n->part_off);
+          const long mn = (long)g.M * g.N;
+          g.K = kp / S; g.batch = S; g.strideA = kp / S; g.strideB = kp / S;
+          g.C32 = part; g.strideC32 = mn; g.bias = nullptr; g.act = 0;
+          if (int e = dvd_gemm_nt(&g, stream)) return e;
+          splitk_reduce_kernel<<<cdiv(mn, 256), 256, 0, st>>>(part, S, mn, weights + o.w_off + (long)o.cout * kp, o.cout,
+                                                             o.act, P(o.dst));
+          break;
+        }
         if (int e = dvd_gemm_nt(&g, stream)) return e;
         break;
       }

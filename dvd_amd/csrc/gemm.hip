@@ -454,6 +454,72 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(GemmArgs p) {
 }
 
 // ================================================================================================
+// Exact-f32 GEMM for NARROW outputs (N <= 64): the pre-stage conv nets' shape family - U2NETP's convs have 16 or 64 output
+// channels (and 1 for the side maps) on maps of 81 ... 82 944 pixels, where the 128 x 128 tile above spends 7/8 of its
+// (slow: 1/16 of the f16 rate) f32 MFMAs on padding columns and a 100-row map leaves one workgroup running a 36-step K
+// loop alone.  Here a wave owns 32 rows x one or two 32-column MFMA tiles: operands go global -> registers directly (16 bytes per
+// lane: lane (r, h) holds k = k0 + 4h .. 4h + 3 of row r - any k assignment is valid as long as A and B agree), 4
+// v_mfma_f32_32x32x2_f32 per 8-deep chunk, two chunks in flight; bias (+ReLU) epilogue straight from the accumulators.
+// ================================================================================================
+template <int NT>   // NT 32-column tiles per wave: N <= 32 * NT
+__global__ void __launch_bounds__(256) gemm_f32_narrow_kernel(GemmArgs p) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int m0 = (blockIdx.x * 4 + wave) * 32;
+  if (m0 >= p.M) return;
+  const int z = blockIdx.y;
+  const float* A = (const float*)p.A + z * p.sA;
+  const float* B = (const float*)p.B + z * p.sB;
+  const float* ap = A + (size_t)min(m0 + r, p.M - 1) * p.lda + 4 * h;
+  const float* bp[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) bp[t] = B + (size_t)min(32 * t + r, p.N - 1) * p.ldb + 4 * h;
+  floatx16 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+  // K % 16 == 0 (checked by the host): two 8-deep chunks per iteration, the next pair prefetched (clamped at the end)
+  floatx4 a0 = *(const floatx4*)ap, a1 = *(const floatx4*)(ap + 8);
+  floatx4 b0[NT], b1[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) { b0[t] = *(const floatx4*)bp[t]; b1[t] = *(const floatx4*)(bp[t] + 8); }
+  for (int k0 = 0; k0 < p.K; k0 += 16) {
+    const int kn = min(k0 + 16, p.K - 16);
+    const floatx4 na0 = *(const floatx4*)(ap + kn), na1 = *(const floatx4*)(ap + kn + 8);
+    floatx4 nb0[NT], nb1[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) { nb0[t] = *(const floatx4*)(bp[t] + kn); nb1[t] = *(const floatx4*)(bp[t] + kn + 8); }
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = mfma32_f32(a0[e], b0[t][e], acc[t]);
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = mfma32_f32(a1[e], b1[t][e], acc[t]);
+    a0 = na0; a1 = na1;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) { b0[t] = nb0[t]; b1[t] = nb1[t]; }
+  }
+  float* C = p.C32 + z * p.sC32;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int col = 32 * t + r;
+    if (col >= p.N) continue;
+    const float bcol = p.bias ? (p.bias + z * p.sBias)[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int row = m0 + (i & 3) + 8 * (i >> 2) + 4 * h;
+      if (row >= p.M) continue;
+      float v = acc[t][i] + bcol;
+      if (p.act == 2) v = fmaxf(v, 0.f);
+      C[(size_t)row * p.ldc + col] = v;
+    }
+  }
+}
+
+// ================================================================================================
 // Large-tile f16 kernel for the decoder GEMMs (92 % of the per-step GEMM FLOPs: M = all tokens, N and K in
 // {1536, 2048, 3072}): 256 x 256 tile per 512-thread workgroup (8 waves as 2 x 4, each 128 x 64 = 4 x 2 MFMA
 // 32x32 tiles, 128 accumulator registers), K-step 64.
@@ -1190,6 +1256,13 @@ extern "C" int dvd_gemm_nt(const dvd_gemm_desc* d, void* stream) {
 #endif
     gemm_nt_big_kernel<0><<<gridb, 512, LDS, (hipStream_t)stream>>>(p);
     return check_launch("gemm_nt(big)");
+  }
+  if (d->dtype == 1 && d->N <= 64 && d->C32 && !d->C16 && !d->pos && !d->gate && !d->res && !d->bias_row &&
+      (d->act == 0 || d->act == 2) && !d->A_lo && !d->B_lo) {
+    const dim3 grd(cdiv(d->M, 128), d->batch);
+    if (d->N <= 32) gemm_f32_narrow_kernel<1><<<grd, 256, 0, (hipStream_t)stream>>>(p);
+    else gemm_f32_narrow_kernel<2><<<grd, 256, 0, (hipStream_t)stream>>>(p);
+    return check_launch("gemm_nt(f32 narrow)");
   }
   p.ntm = cdiv(d->M, 128); p.ntn = cdiv(d->N, 128);
   dim3 grid(p.ntm * p.ntn, d->batch);

@@ -245,3 +245,20 @@ def test_gemm_weights_on_a_side_column_major_walk(ops):
         ref = w.double() @ h[b * T:(b + 1) * T].double().t()
         err = (out[b].cpu().double() - ref).abs().max().item()
         assert err < 2e-3 * max(1.0, ref.abs().max().item()), (b, err)          # f16 output rounding dominates
+
+
+@pytest.mark.parametrize("M,N,K", [(81, 16, 144), (82944, 16, 576), (1296, 1, 576), (5000, 32, 48), (300, 6, 16), (324, 16, 1152),
+                                   (20736, 64, 288), (333, 40, 64)])
+def test_gemm_f32_narrow_outputs(ops, M, N, K):
+    """The pre-stage conv nets' shape family (N <= 64, exact f32): one wave per 32 rows x 32 / 64 columns, operands straight from global
+    memory; bias + ReLU epilogue; ragged M, N = 1."""
+    a, b = rnd(f"na{M}{K}", (M, K)), rnd(f"nb{N}{K}", (N, K))
+    bias = rnd(f"nbias{N}", (N,))
+    ref = a.double() @ b.double().t() + bias.double()
+    out = torch.full((M, N), 7.0, device="cuda")
+    ops.gemm_nt(a.cuda(), b.cuda(), out32=out, bias=bias.cuda(), act=2)
+    err = (out.cpu().double() - torch.relu(ref)).abs().max().item()
+    assert err < 2e-7 * K * 4, err
+    out2 = torch.zeros(M, N, device="cuda")
+    ops.gemm_nt(a.cuda(), b.cuda(), out32=out2)
+    assert (out2.cpu().double() - (ref - bias.double())).abs().max().item() < 2e-7 * K * 4
