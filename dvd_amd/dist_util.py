@@ -31,7 +31,11 @@ def setup_dist(backend=None):
         backend = "nccl" if th.cuda.is_available() else "gloo"
     if backend == "nccl":
         th.cuda.set_device(_env_int("LOCAL_RANK", 0) % max(1, th.cuda.device_count()))
-    dist.init_process_group(backend=backend, init_method="env://")
+        # bind the communicator to this rank's device up front (no device guessing at the first barrier)
+        dist.init_process_group(backend=backend, init_method="env://",
+                                device_id=th.device("cuda", th.cuda.current_device()))
+    else:
+        dist.init_process_group(backend=backend, init_method="env://")
     return True
 
 
