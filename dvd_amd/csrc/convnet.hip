@@ -76,6 +76,80 @@ __global__ void __launch_bounds__(256) im2col_cat_kernel(const float* __restrict
   *reinterpret_cast<float4*>(col + p * kp + k0) = make_float4(v[0], v[1], v[2], v[3]);
 }
 
+
+typedef float cn_floatx4 __attribute__((ext_vector_type(4)));
+typedef float cn_floatx16 __attribute__((ext_vector_type(16)));
+
+// Implicit-GEMM conv for narrow outputs (cout <= 64) over channel counts that are multiples of 16: the arithmetic of
+// im2col_cat_kernel + gemm_f32_narrow_kernel - same K order (tap-major, channels of source a then b), same 8-deep chunks
+// per lane half, same MFMA sequence, so the same bits - without materialising the [H*W, 9*cin] matrix: a wave owns 32
+// consecutive pixels, lane (r, hh) reads 4 consecutive channels of pixel r's tap straight from the channels-last source
+// (zeros outside the map).  One kernel instead of a gather (4.3 ms of a document's 13.6 ms of pre-stage kernel time) + a GEMM.
+template <int NT>
+__global__ void __launch_bounds__(256) conv_f32_narrow_kernel(const float* __restrict__ a, int ca,
+                                                              const float* __restrict__ b, int cb,
+                                                              const float* __restrict__ wgt, int kp,
+                                                              const float* __restrict__ bias, float* __restrict__ out,
+                                                              int cout, int ks, int dil, int h, int w, int act) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, hh = lane >> 5;
+  const long hw = (long)h * w;
+  const long m0 = ((long)blockIdx.x * 4 + wave) * 32;
+  if (m0 >= hw) return;
+  const long pix = min(m0 + r, hw - 1);
+  const int y = (int)(pix / w), x = (int)(pix - (long)y * w);
+  const int cc = ca + cb, rad = ks / 2;
+  const float* wp[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) wp[t] = wgt + (size_t)min(32 * t + r, cout - 1) * kp + 4 * hh;
+  cn_floatx16 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+  const cn_floatx4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  int k0 = 0;
+  for (int tap = 0; tap < ks * ks; ++tap) {
+    const int yy = y + (tap / ks - rad) * dil, xx = x + (tap % ks - rad) * dil;
+    const bool ok = yy >= 0 && yy < h && xx >= 0 && xx < w;
+    const long q = ok ? (long)yy * w + xx : 0;
+    for (int c0 = 0; c0 < cc; c0 += 16, k0 += 16) {
+      // channels c0 + 4 hh .. + 3 and c0 + 8 + 4 hh .. + 3 (ca % 8 == 0: a chunk never straddles the two sources)
+      const int c1 = c0 + 4 * hh, c2 = c0 + 8 + 4 * hh;
+      cn_floatx4 a0 = zero4, a1 = zero4;
+      if (ok) {
+        a0 = c1 < ca ? *(const cn_floatx4*)(a + q * ca + c1) : *(const cn_floatx4*)(b + q * cb + (c1 - ca));
+        a1 = c2 < ca ? *(const cn_floatx4*)(a + q * ca + c2) : *(const cn_floatx4*)(b + q * cb + (c2 - ca));
+      }
+      cn_floatx4 b0[NT], b1[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) { b0[t] = *(const cn_floatx4*)(wp[t] + k0); b1[t] = *(const cn_floatx4*)(wp[t] + k0 + 8); }
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], b0[t][e], acc[t], 0, 0, 0);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], b1[t][e], acc[t], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int col = 32 * t + r;
+    if (col >= cout) continue;
+    const float bcol = bias[col];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const long row = m0 + (i & 3) + 8 * (i >> 2) + 4 * hh;
+      if (row >= hw) continue;
+      float v = acc[t][i] + bcol;
+      if (act == 2) v = fmaxf(v, 0.f);
+      out[row * cout + col] = v;
+    }
+  }
+}
+
 // nn.MaxPool2d(2, stride=2, ceil_mode): windows are clipped at the border
 __global__ void __launch_bounds__(256) maxpool2_ceil_kernel(const float* __restrict__ in, float* __restrict__ out, int c,
                                                             int h, int w, int ho, int wo, long total) {
@@ -319,6 +393,20 @@ extern "C" int dvd_convnet_run(void* handle, const float* in_nchw, const float* 
       case DVD_CN_CONV: {
         const int kp = n->kpad[i];
         const int cb = o.b >= 0 ? n->slots[o.b].c : 0;
+        if (o.cout <= 64 && a.c % 8 == 0 && cb % 8 == 0 && (a.c + cb) % 16 == 0 && n->ksplit[i] == 1) {
+          // narrow output over 16-aligned channels: implicit GEMM, no im2col matrix
+          const dim3 grd(cdiv((long)a.h * a.w, 128));
+          const float* wgt = weights + o.w_off;
+          if (o.cout <= 32)
+            conv_f32_narrow_kernel<1><<<grd, 256, 0, st>>>(P(o.a), a.c, o.b >= 0 ? P(o.b) : nullptr, cb, wgt, kp,
+                                                           wgt + (long)o.cout * kp, P(o.dst), o.cout, o.ks, o.dil, a.h, a.w,
+                                                           o.act);
+          else
+            conv_f32_narrow_kernel<2><<<grd, 256, 0, st>>>(P(o.a), a.c, o.b >= 0 ? P(o.b) : nullptr, cb, wgt, kp,
+                                                           wgt + (long)o.cout * kp, P(o.dst), o.cout, o.ks, o.dil, a.h, a.w,
+                                                           o.act);
+          break;
+        }
         const float* A = P(o.a);
         int lda = a.c;
         if (!(o.ks == 1 && o.b < 0 && a.c == kp)) {   // a 1x1 conv over a 16-aligned single source reads the slot directly
