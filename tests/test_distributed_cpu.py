@@ -21,6 +21,36 @@ def _free_port():
     return p
 
 
+def _spawn_ranks(target, world, extra_args=(), timeout=240, attempts=2):
+    """Start `world` rank processes of `target(rank, world, port, queue, *extra_args)` and collect one result per rank.
+    A rendezvous hiccup (port grabbed between probe and bind, a slow spawn on a loaded machine) gets ONE clean retry on a
+    fresh port; the ranks of a failed attempt are terminated by handle."""
+    import queue as _queue
+    last = None
+    for _ in range(attempts):
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=target, args=(r, world, port, q, *extra_args)) for r in range(world)]
+        for p in procs:
+            p.start()
+        try:
+            res = sorted(q.get(timeout=timeout) for _ in range(world))
+            for p in procs:
+                p.join(timeout=120)
+            if all(p.exitcode == 0 for p in procs):
+                return res
+            last = AssertionError(f"rank exit codes {[p.exitcode for p in procs]}")
+        except _queue.Empty as e:
+            last = e
+        for p in procs:
+            if p.is_alive():
+                p.terminate()
+            p.join(timeout=30)
+    raise AssertionError(f"ranks did not finish after {attempts} attempts: {last!r}")
+
+
+
 def _worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
@@ -49,16 +79,7 @@ def _worker(rank, world, port, q):
 
 
 def test_two_rank_broadcast_and_sharding():
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    res = sorted(q.get(timeout=300) for _ in range(2))
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    res = _spawn_ranks(_worker, 2)
     assert res[0][1] == res[1][1], "ranks disagree on the broadcast weight blob"
     assert res[0][2] == [0, 2, 4, 6] and res[1][2] == [1, 3, 5]
 
@@ -94,7 +115,7 @@ def _stub_compute(calls):
     th.cuda.synchronize = lambda *a, **k: None
 
 
-def _run_worker(rank, world, port, n_docs, q, tmp):
+def _run_worker(rank, world, port, q, n_docs, tmp):
     sys.path.insert(0, ROOT)
     os.chdir(tmp)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
@@ -131,16 +152,7 @@ def test_val_tdiff_run_two_ranks(tmp_path, n_docs):
     """n_docs = 1 < world: rank 1 owns NO document - it must still take part in the one weight broadcast (issued
     eagerly by run(), never lazily by engine()) and reach the final barrier (this used to hang).
     n_docs = 5: disjoint shards [0,2,4] / [1,3], batches of 2, 3 DDIM steps per batch."""
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_run_worker, args=(r, 2, port, n_docs, q, str(tmp_path))) for r in range(2)]
-    for p in procs:
-        p.start()
-    res = sorted(q.get(timeout=240) for _ in range(2))
-    for p in procs:
-        p.join(timeout=120)
-        assert p.exitcode == 0
+    res = _spawn_ranks(_run_worker, 2, (n_docs, str(tmp_path)))
     (r0, d0, docs0, den0, prep0, unw0, cn0, ing0), (r1, d1, docs1, den1, prep1, unw1, cn1, ing1) = res
     assert d0 == d1, "ranks disagree on the broadcast weight blob"
     want0 = [f"synthetic_{i:05d}" for i in range(0, n_docs, 2)]
@@ -177,16 +189,7 @@ def _bench_worker(rank, world, port, q):
 
 
 def test_bench_rank_logic_two_ranks():
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_bench_worker, args=(r, 2, port, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    res = sorted(q.get(timeout=240) for _ in range(2))
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    res = _spawn_ranks(_bench_worker, 2)
     assert res[0][1] == res[1][1] and res[0][2] and res[1][2]
     assert res[0][3] == res[1][3] == 2.0          # every rank reports the slowest rank's time
 
@@ -241,16 +244,7 @@ def _bench_main_worker(rank, world, port, q, tmp):
 
 def test_bench_main_two_ranks(tmp_path):
     import json
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_bench_main_worker, args=(r, 2, port, q, str(tmp_path))) for r in range(2)]
-    for p in procs:
-        p.start()
-    res = sorted(q.get(timeout=240) for _ in range(2))
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    res = _spawn_ranks(_bench_main_worker, 2, (str(tmp_path),))
     (r0, out0, den0, prep0), (r1, out1, den1, prep1) = res
     assert den0 == den1 == 3 * 3 and prep0 == prep1 == 3        # (1 warm-up + 2 timed) x 3 DDIM steps on EVERY rank
     assert out1.strip() == ""                                     # only rank 0 prints
