@@ -60,3 +60,14 @@ def test_argument_validation_without_gpu():
     import ctypes as C
     rc = lib.raw().dvd_unwarp_f32(None, 16, None, None, 10, 10, C.c_float(0.987), None)
     assert rc == -1 and b"null" in lib.raw().dvd_last_error()
+
+
+def test_header_is_plain_c():
+    """The boundary is a C ABI: include/dvd_hip.h (and the lab header) compile as C99 and as C++ with no torch / HIP types."""
+    import subprocess
+    for hdr in ("include/dvd_hip.h", "benchmarks/lab/dvd_hip_lab.h"):
+        path = os.path.join(ROOT, hdr)
+        subprocess.run(["gcc", "-fsyntax-only", "-x", "c", "-std=c99", path], check=True)
+        subprocess.run(["g++", "-fsyntax-only", "-x", "c++", path], check=True)
+    text = open(os.path.join(ROOT, "include", "dvd_hip.h")).read()
+    assert "torch" not in text.lower() and "hipStream_t" not in text
