@@ -121,6 +121,7 @@ def main(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-split-weights", action="store_true")
     ap.add_argument("--no-ffn-lo", action="store_true", help="opt-in fast mode: drop the lo pass of the decoder FFN convs")
+    ap.add_argument("--no-dither", action="store_true", help="round 2's weights: (hi, lo) split in every GEMM, 2x the MFMAs")
     ap.add_argument("--backend", default="nccl", help="process-group backend (nccl = RCCL; the CPU test of the rank logic uses gloo)")
     args = ap.parse_args(argv)
 
@@ -143,6 +144,8 @@ def main(argv=None):
         eng.set_option("split_weights", 0)
     if args.no_ffn_lo:
         eng.set_option("ffn_lo", 0)
+    if args.no_dither:
+        eng.set_option("dither", 0)
 
     # ---- weights: rank 0 builds + packs, ONE flat RCCL broadcast (the only collective of the path) ----
     _, blob_bytes = eng.blob_layout()
@@ -319,7 +322,11 @@ def main(argv=None):
             "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
             "config": {"workload": workload_name(B, H, S, args.sampler, G, FH, FW, world),
                        "docs_per_gpu": B, "hypotheses": H, "sampler_steps": S, "grid": G,
-                       "weights": ("synthetic, f16" if args.no_split_weights else "synthetic (seed 7), f16 hi/lo split"
+                       "weights": ("synthetic (seed 7), " + (
+                           "plain f16 (round-to-nearest once)" if (args.no_split_weights and args.no_dither) else
+                           "f16 hi/lo split in every GEMM" if args.no_dither else
+                           "f16 re-rounded before every evaluation with a zero-mean step-dependent dither for the "
+                           "256-wide GEMMs (one pass), f16 hi/lo split for the 384-wide ones")
                                    + (", decoder-FFN lo pass dropped (opt-in fast mode)" if args.no_ffn_lo else "")),
                        "parallelism": f"dp{world} (documents sharded, one weight broadcast)"},
             "algorithmic_tflops": round(flops_total / elapsed / 1e12, 1),

@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Time dvd_flash_attn at the bench's launch shapes (T = 20736): TF/s for head_dim 64 and 256.
-usage: [DVD_HIP_LIB=...] python benchmarks/attn_time.py [hd=64] [B=16] [reps=5]"""
+usage: python benchmarks/attn_time.py [hd=64] [B=16] [reps=5]"""
 import os, sys
 sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__))); import _lab; LIBSEL = _lab.which()   # --lab selects the lab build
 import torch
 from dvd_amd import ops
 hd = int(sys.argv[1]) if len(sys.argv) > 1 else 64
@@ -21,4 +22,4 @@ for a, b in ev:
 torch.cuda.synchronize()
 ms = sorted(a.elapsed_time(b) for a, b in ev)
 fl = 4.0 * T * T * C * B
-print(f"hd={hd} B={B} lib={os.environ.get('DVD_HIP_LIB', 'product')}: median {ms[len(ms)//2]:.3f} ms  {fl / ms[len(ms)//2] / 1e9:.0f} TF/s  (min {ms[0]:.3f})")
+print(f"hd={hd} B={B} lib={LIBSEL}: median {ms[len(ms)//2]:.3f} ms  {fl / ms[len(ms)//2] / 1e9:.0f} TF/s  (min {ms[0]:.3f})")

@@ -1,5 +1,5 @@
 import os, sys, torch
-os.environ.setdefault("DVD_HIP_LIB", os.path.join(os.path.dirname(os.path.abspath(__file__)), "lab", "libdvd_hip_lab.so"))  # the DVD_* switches exist in the lab build only (make -C dvd_amd/csrc lab)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__))); import _lab; _lab.use_lab()   # the DVD_* switches exist in the lab build only (make -C dvd_amd/csrc lab)
 sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
 from dvd_amd import ops
 n, side, c = 16, 144, 2048

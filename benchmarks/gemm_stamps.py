@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """DVD_GEMM_DEBUG=3 python benchmarks/gemm_stamps.py : where a wave of the large-tile GEMM spends its lifetime."""
 import os, sys
-os.environ.setdefault("DVD_HIP_LIB", os.path.join(os.path.dirname(os.path.abspath(__file__)), "lab", "libdvd_hip_lab.so"))  # the DVD_* switches exist in the lab build only (make -C dvd_amd/csrc lab)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__))); import _lab; _lab.use_lab()   # the DVD_* switches exist in the lab build only (make -C dvd_amd/csrc lab)
 sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
 import ctypes as C
 import torch

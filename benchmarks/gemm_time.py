@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Time the split-weight GEMMs of the decoder at the bench's shapes (M = 331 776 rows).
-usage: [DVD_HIP_LIB=...] python benchmarks/gemm_time.py [reps=5]"""
+usage: python benchmarks/gemm_time.py [reps=5]"""
 import os, sys
 sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__))); import _lab; LIBSEL = _lab.which()   # --lab selects the lab build
 import torch
 from dvd_amd import ops
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
@@ -21,5 +22,5 @@ for name, N, K in (("qk  N=3072 K=1536", 3072, 1536), ("c1  N=2048 K=1536", 2048
         x.record(); f(); y.record()
     torch.cuda.synchronize()
     ms = sorted(x.elapsed_time(y) for x, y in ev)[len(ev) // 2]
-    print(f"{name}: {ms:.3f} ms  algorithmic {2.0 * M * N * K / ms / 1e9:.0f} TF/s  executed {4.0 * M * N * K / ms / 1e9:.0f} TF/s   lib={os.environ.get('DVD_HIP_LIB', 'product')}")
+    print(f"{name}: {ms:.3f} ms  algorithmic {2.0 * M * N * K / ms / 1e9:.0f} TF/s  executed {4.0 * M * N * K / ms / 1e9:.0f} TF/s   lib={LIBSEL}")
     del a, w, hi, lo, out

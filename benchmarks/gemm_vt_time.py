@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Time the V^T projection of a decoder layer at the bench shape: per sample V^T[1536, T] = W_v[1536, 1536] . h^T, weights
-(hi + lo) on the A side, batch 16.  usage: [DVD_HIP_LIB=...] python benchmarks/gemm_vt_time.py"""
+(hi + lo) on the A side, batch 16.  usage: python benchmarks/gemm_vt_time.py"""
 import os, sys
 sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__))); import _lab; LIBSEL = _lab.which()   # --lab selects the lab build
 import torch
 from dvd_amd import ops
 N, T, D = 16, 20736, 1536
@@ -19,4 +20,4 @@ for a, b in ev:
     a.record(); f(); b.record()
 torch.cuda.synchronize()
 ms = sorted(a.elapsed_time(b) for a, b in ev)[3]
-print(f"V^T projection (two-pass A_lo): {ms:.3f} ms  executed {4.0 * N * T * D * D / ms / 1e9:.0f} TF/s  lib={os.environ.get('DVD_HIP_LIB', 'product')}")
+print(f"V^T projection (two-pass A_lo): {ms:.3f} ms  executed {4.0 * N * T * D * D / ms / 1e9:.0f} TF/s  lib={LIBSEL}")

@@ -2,7 +2,7 @@
 """Micro-benchmarks of single HIP ops (timed with events on torch's current stream, which is the
 stream the ops are enqueued on).  Usage: python benchmarks/op_bench.py [unwarp] [gs] ..."""
 import os
-os.environ.setdefault("DVD_HIP_LIB", os.path.join(os.path.dirname(os.path.abspath(__file__)), "lab", "libdvd_hip_lab.so"))  # the DVD_* switches exist in the lab build only (make -C dvd_amd/csrc lab)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__))); import _lab; _lab.use_lab()   # the DVD_* switches exist in the lab build only (make -C dvd_amd/csrc lab)
 import sys
 import json
 

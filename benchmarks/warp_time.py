@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Time the full-resolution gathers (3508 x 2480, document-like flow) - drop-in grid_sample f32 (32 B/px), fused f32 tail
-(24 B/px), fused u8 tail (6 B/px) - with B documents per launch.  usage: [DVD_HIP_LIB=...] python benchmarks/warp_time.py [B=8]"""
+(24 B/px), fused u8 tail (6 B/px) - with B documents per launch.  usage: python benchmarks/warp_time.py [B=8]"""
 import os, sys
 sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__))); import _lab; LIBSEL = _lab.which()   # --lab selects the lab build
 import torch
 from dvd_amd import ops
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
@@ -21,7 +22,7 @@ def t(f, n=7):
         a.record(); f(); b.record()
     torch.cuda.synchronize()
     return sorted(a.elapsed_time(b) for a, b in ev)[n // 2]
-lib = os.environ.get("DVD_HIP_LIB", "product")
+lib = LIBSEL
 for name, f, bpp in (("grid_sample f32 (32 B/px)", lambda: ops.grid_sample(srcf, grid), 32),
                      ("unwarp_f32 fused (24 B/px)", lambda: ops.unwarp_f32_batch(flow, srcf), 24),
                      ("unwarp_u8 fused (6 B/px)", lambda: ops.unwarp_u8_batch(flow, src8), 6)):

@@ -937,12 +937,16 @@ extern "C" int dvd_flash_attn(const dvd_attn_desc* d, void* stream) {
   bool fast = d->tk % 64 == 0;      // the LDS-DMA kernels stream whole 64-key tiles; ragged key counts take the
                                     // register-staged kernel (masked tail)
   bool r64 = d->head_dim == 256 && d->tq >= R64_MIN_TQ;
-  static bool attr_done = false;
-  if (!attr_done) {
+  // hipFuncSetAttribute is per DEVICE: remember which devices have been set up (one bit each), lock-free - the
+  // attribute call is idempotent, so two threads racing on a device's first launch both set it and both are right
+  static DeviceOnce attr_done;
+  const unsigned long long dev_bit = DeviceOnce::current_bit();
+  const bool first_on_device = attr_done.need(dev_bit);
+  if (first_on_device) {
     allow_lds(flash_attn_glds_kernel<256, 0>, 2 * (64 * 512 + 256 * 128));
     allow_lds(flash_attn_r64_kernel<0>, 2 * (32 * 512 + 256 * 64));
     allow_lds(flash_attn_kernel<256>, 2 * (64 * (2 * 256 + 16) + 256 * (2 * 64 + 16)));
-    attr_done = true;
+    attr_done.done(dev_bit);
   }
 #ifdef DVD_LAB
   // ---- lab build: every experiment and diagnostic variant behind its environment switch ----
@@ -951,8 +955,7 @@ extern "C" int dvd_flash_attn(const dvd_attn_desc* d, void* stream) {
   if (getenv("DVD_ATTN_V1")) fast = false;
   if (getenv("DVD_ATTN_R64")) r64 = d->head_dim == 256;
   if (getenv("DVD_ATTN_R32") || getenv("DVD_ATTN_PIPE") || bulk) r64 = false;
-  static bool lab_attr_done = false;
-  if (!lab_attr_done) {
+  if (first_on_device) {
     constexpr int LDS = 2 * (64 * 512 + 256 * 128);
     allow_lds(flash_attn_dsplit_kernel, LDS);
     allow_lds(flash_attn_glds_kernel<256, 1>, LDS);
@@ -961,7 +964,6 @@ extern "C" int dvd_flash_attn(const dvd_attn_desc* d, void* stream) {
     allow_lds(flash_attn_pipe_kernel<0>, LDS);
     allow_lds(flash_attn_pipe_kernel<1>, LDS);
     allow_lds(flash_attn_r64_kernel<1>, 2 * (32 * 512 + 256 * 64));
-    lab_attr_done = true;
   }
   if (fast && d->head_dim == 256) {
     constexpr int LDS = 2 * (64 * 512 + 256 * 128);

@@ -6,6 +6,8 @@
 #include <stdio.h>
 #include <stdarg.h>
 
+#include <atomic>
+
 #include "../../include/dvd_hip.h"
 
 namespace dvd {
@@ -28,6 +30,19 @@ inline int check_launch(const char* what) {
       return DVD_E_ARG;                 \
     }                                   \
   } while (0)
+
+// One-time per-DEVICE setup (hipFuncSetAttribute is a per-device property): one bit per device, lock-free.  The guarded
+// calls are idempotent, so two threads racing on a device's first launch both make them and both are right.
+struct DeviceOnce {
+  std::atomic<unsigned long long> mask{0};
+  static unsigned long long current_bit() {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    return 1ull << (dev & 63);
+  }
+  bool need(unsigned long long b) const { return !(mask.load(std::memory_order_acquire) & b); }
+  void done(unsigned long long b) { mask.fetch_or(b, std::memory_order_release); }
+};
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 

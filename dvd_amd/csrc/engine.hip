@@ -35,6 +35,7 @@ int dvd_im2col3x3(const float*, long, long, long, float*, int, int, int, int, vo
 int dvd_maxpool2_nhwc(const float*, float*, int, int, int, void*);
 int dvd_resize_bilinear_nhwc(const float*, float*, int, int, int, int, int, void*);
 int dvd_nhwc_to_nchw(const float*, float*, int, int, int, void*);
+int dvd_dither_f16(const void*, const void*, void*, long, unsigned, unsigned, void*);
 }
 
 namespace dvd {
@@ -46,6 +47,7 @@ struct TensorSpec {
   std::string name;
   int dtype;  // 0 f32, 1 f16
   long nelem;
+  bool wide;  // f16 weight of a GEMM that takes the 256-wide kernels on large grids (gets a dithered copy, see Engine)
 };
 
 static const int PYR_CIN[7] = {4, 64, 64, 128, 128, 256, 256};
@@ -55,9 +57,13 @@ static inline int pyr_kpad(int i) { return ((9 * PYR_CIN[i] + 63) / 64) * 64; }
 static std::vector<TensorSpec> tensor_specs(int G) {
   const long T = (long)(G / 2) * (G / 2), side = G / 2;
   std::vector<TensorSpec> v;
-  auto f32 = [&](const std::string& n, long e) { v.push_back({n, 0, e}); };
-  // every f16 weight comes as a (hi, lo) pair: W = hi + lo, lo unscaled  (see dvd_gemm_desc.B_lo)
-  auto f16 = [&](const std::string& n, long e) { v.push_back({n, 1, e}); v.push_back({n + "_lo", 1, e}); };
+  auto f32 = [&](const std::string& n, long e) { v.push_back({n, 0, e, false}); };
+  // every f16 weight comes as a (hi, lo) pair: W = hi + lo, lo unscaled  (see dvd_gemm_desc.B_lo).  `wide`: its GEMM has
+  // N % 256 == 0 (B-side weights: N = output features; A-side V^T projections: N = tokens)
+  auto f16 = [&](const std::string& n, long e, bool wide = false) {
+    v.push_back({n, 1, e, wide});
+    v.push_back({n + "_lo", 1, e, false});
+  };
   f32("obs_w", HID * 8); f32("obs_b", HID); f32("pos", T * HID);
   f16("r_w16", (long)HID * RK); f32("r_b", HID);
   f32("c_w", (long)HID * 1024); f32("c_b", HID);
@@ -66,12 +72,12 @@ static std::vector<TensorSpec> tensor_specs(int G) {
   f32("t_w0", HID * 256); f32("t_b0", HID); f32("t_w2", HID * HID); f32("t_b2", HID);
   f32("ada_w", 6 * HID * HID); f32("ada_b", 6 * HID);
   f16("ca_wq16", HID * HID); f32("ca_bq", HID);
-  f16("ca_wk16", HID * HID); f32("ca_bk", HID); f16("ca_wv16", HID * HID); f32("ca_bv", HID);
+  f16("ca_wk16", HID * HID); f32("ca_bk", HID); f16("ca_wv16", HID * HID, true); f32("ca_bv", HID);
   f32("ca_wk32", HID * HID); f32("ca_wv32", HID * HID);
   f16("ca_wo16", HID * HID); f32("ca_bo", HID);
-  f16("sa_wqk16", 2 * HID * HID); f32("sa_bqk", 2 * HID); f16("sa_wv16", HID * HID); f32("sa_bv", HID);
+  f16("sa_wqk16", 2 * HID * HID, true); f32("sa_bqk", 2 * HID); f16("sa_wv16", HID * HID, true); f32("sa_bv", HID);
   f16("sa_wp16", HID * HID); f32("sa_bp", HID);
-  f16("fc1_w16", 4 * HID * HID); f32("fc1_b", 4 * HID); f16("fc2_w16", 4 * HID * HID); f32("fc2_b", HID);
+  f16("fc1_w16", 4 * HID * HID, true); f32("fc1_b", 4 * HID); f16("fc2_w16", 4 * HID * HID); f32("fc2_b", HID);
   for (const char* hw : {"pe_h", "pe_w"}) {
     f32(std::string(hw) + "0_w", (long)DEC * DEC); f32(std::string(hw) + "0_b", DEC);
     f32(std::string(hw) + "2_w", (long)DEC * DEC); f32(std::string(hw) + "2_b", DEC);
@@ -80,11 +86,11 @@ static std::vector<TensorSpec> tensor_specs(int G) {
   for (int j = 0; j < 6; ++j) {
     const std::string p = "d" + std::to_string(j) + "_";
     f32(p + "n1w", DEC); f32(p + "n1b", DEC);
-    f16(p + "wqk16", 2L * DEC * DEC); f16(p + "wv16", (long)DEC * DEC); f16(p + "wfc16", (long)DEC * DEC);
+    f16(p + "wqk16", 2L * DEC * DEC, true); f16(p + "wv16", (long)DEC * DEC, true); f16(p + "wfc16", (long)DEC * DEC, true);
     f32(p + "n2w", DEC); f32(p + "n2b", DEC);
-    f16(p + "c1w16", (long)FFN * DEC); f32(p + "c1b", FFN);
+    f16(p + "c1w16", (long)FFN * DEC, true); f32(p + "c1b", FFN);
     f32(p + "dww", 9 * FFN); f32(p + "dwb", FFN);
-    f16(p + "c2w16", (long)DEC * FFN); f32(p + "c2b", DEC);
+    f16(p + "c2w16", (long)DEC * FFN, true); f32(p + "c2b", DEC);
   }
   f32("dec_nw", DEC); f32("dec_nb", DEC);
   f32("fin_ada_w", 2L * DEC * DEC); f32("fin_ada_b", 2 * DEC); f32("fin_w", 8 * DEC); f32("fin_b", 8);
@@ -108,7 +114,7 @@ static std::vector<TensorSpec> tensor_specs(int G) {
 #define DVD_B_LIST(X)                                                                                              \
   X(feat) X(kc16) X(km16) X(kl16) X(vtc16) X(vtm16) X(vtl16) X(tbuf) X(th) X(cvec) X(mod) X(finmod) X(pooled)      \
   X(petmp) X(hs) X(wsc) X(part) X(xtok32) X(xq16) X(arows16) X(rtok16) X(q16) X(kr16) X(vtr16) X(att16) X(z) X(h16) \
-  X(qk16) X(vt16) X(mlp16) X(p_cat4) X(p_col) X(p_actA) X(p_actB) X(p_rows) X(p_tok32)
+  X(qk16) X(vt16) X(mlp16) X(p_cat4) X(p_col) X(p_actA) X(p_actB) X(p_rows) X(p_tok32) X(w16dith)
 
 struct WIdx {
 #define X(n) int n = -1;
@@ -139,6 +145,7 @@ struct GraphKey {
 struct GraphEntry {
   GraphKey key;
   hipGraphExec_t exec;   // nullptr: the key has been run eagerly once (lazy one-time initialisation done), not yet captured
+  unsigned long last_use;
 };
 
 struct Engine {
@@ -156,6 +163,13 @@ struct Engine {
   bool split_weights = true;   // use the lo parts (fp32-grade weights, 2x GEMM MFMAs)
   bool ffn_lo = true;          // keep the lo parts of the decoder FFN's two 1x1 convs (see dvd_engine_set_option)
   bool small_tiles = false;    // 128x128 GEMM tiles for the per-step GEMMs (small grids; set from the grid in create)
+  // temporal dithering of the f16 weight rounding (dither.hip): the 256-wide GEMMs read a per-evaluation re-rounded
+  // single-f16 copy of their weight (buffer w16dith) and run ONE pass; everything else keeps the (hi, lo) pair
+  bool dither = false;
+  unsigned dither_step = 0;            // evaluation counter fed to the next dvd_dither_f16 (then incremented)
+  std::vector<long> dith_off;          // per weight index: element offset of its copy inside w16dith, or -1
+  std::vector<int> dith_list;          // weight indices that have a copy
+  long dith_total = 0;
   bool use_graphs = false;     // replay a denoiser evaluation as one hipGraph (launch-bound small grids)
   // optional per-launch timing of the dominant kernel (decoder attention) with HIP events on the launch stream:
   // a ring of event pairs, drained into running totals when it wraps, so EVERY launch of the timed region counts
@@ -170,9 +184,15 @@ struct Engine {
   hipStream_t cap_stream = nullptr;
 
   const float* F(int i) const { return (const float*)wptr[i]; }
-  const void* H(int i) const { return wptr[i]; }
-  const void* L(int i) const { return split_weights ? wptr[i + 1] : nullptr; }   // (hi, lo) pairs are adjacent
-  const void* Lffn(int i) const { return ffn_lo ? L(i) : nullptr; }
+  // `wide`: the GEMM that consumes weight i takes the 256-wide kernels (its N is a multiple of 256 on a large grid)
+  bool dithered(int i, bool wide) const { return dither && wide && !small_tiles && dith_off[i] >= 0; }
+  const void* H(int i, bool wide = false) const {
+    return dithered(i, wide) ? (const void*)((const _Float16*)(ws + bufs[bi.w16dith].off) + dith_off[i]) : wptr[i];
+  }
+  const void* L(int i, bool wide = false) const {                      // (hi, lo) pairs are adjacent
+    return (split_weights && !dithered(i, wide)) ? wptr[i + 1] : nullptr;
+  }
+  const void* Lffn(int i, bool wide = false) const { return ffn_lo ? L(i, wide) : nullptr; }
   char* B(int i) const { return ws + bufs[i].off; }
   int find_w(const std::string& name) const {
     for (size_t i = 0; i < specs.size(); ++i)
@@ -184,10 +204,34 @@ struct Engine {
       if (bufs[i].name == name) return (int)i;
     return -1;
   }
+  unsigned long graph_clock = 0;
   void drop_graphs() {
+    bool any = false;
+    for (auto& g : graphs) any = any || g.exec;
+    if (any) (void)hipDeviceSynchronize();   // an exec may still be in flight on the caller's stream (rare path)
     for (auto& g : graphs)
       if (g.exec) (void)hipGraphExecDestroy(g.exec);
     graphs.clear();
+  }
+  // Evict ONE entry when the cache is full: a key that was only ever run eagerly if there is one (single-step entry
+  // points pass freshly allocated tensors and leave such never-replayed keys behind), else the least recently used
+  // exec - never the whole cache, so the sampler's captured evaluations survive.
+  void evict_one(hipStream_t st) {
+    size_t victim = 0;
+    bool found_eager = false;
+    for (size_t i = 0; i < graphs.size(); ++i) {
+      if (!graphs[i].exec) {
+        if (!found_eager || graphs[i].last_use < graphs[victim].last_use) victim = i;
+        found_eager = true;
+      } else if (!found_eager && graphs[i].last_use < graphs[victim].last_use) {
+        victim = i;
+      }
+    }
+    if (graphs[victim].exec) {
+      (void)hipStreamSynchronize(st);        // it may still be running
+      (void)hipGraphExecDestroy(graphs[victim].exec);
+    }
+    graphs.erase(graphs.begin() + (long)victim);
   }
 };
 
@@ -241,6 +285,17 @@ static void plan(Engine* e) {
   add("tbuf", 256); add("th", HID * 4); add("cvec", HID * 4); add("mod", 6 * HID * 4); add("finmod", 2 * DEC * 4);
   add("pooled", N * DEC * 4); add("petmp", N * DEC * 4); add("hs", N * DEC * 4); add("wsc", N * DEC * 4);
   add("part", N * COLCHUNKS * DEC * 4);
+  // dithered single-f16 copies of the weights of the 256-wide GEMMs (persistent: rewritten before every evaluation)
+  e->dith_off.assign(e->specs.size(), -1);
+  e->dith_list.clear();
+  e->dith_total = 0;
+  for (size_t i = 0; i + 1 < e->specs.size(); ++i) {
+    if (!e->specs[i].wide) continue;
+    e->dith_off[i] = e->dith_total;
+    e->dith_list.push_back((int)i);
+    e->dith_total += (e->specs[i].nelem + 127) / 128 * 128;
+  }
+  add("w16dith", (size_t)e->dith_total * 2);
   const size_t scratch0 = off;
   // per-step activations
   add("xtok32", NT * HID * 4); add("xq16", NT * HID * 2); add("arows16", NT * RK * 2); add("rtok16", NT * HID * 2);
@@ -317,6 +372,7 @@ extern "C" int dvd_engine_create(int grid, int docs, int n_hyp, void** handle) {
   // a few thousand rows per GEMM put < 50 of the 256x256 persistent tiles on 256 CUs: small grids take 128x128 tiles.
   // Decided from the GRID only (never the batch): a document gets the same kernels alone or in a batch.
   e->small_tiles = e->T <= 1024;
+  e->dither = !e->small_tiles;
   if (!resolve_indices(e)) {
     delete e;
     set_error("engine_create: internal tensor/buffer table mismatch");
@@ -402,6 +458,8 @@ extern "C" int dvd_engine_set_option(void* handle, const char* name, int value) 
   if (strcmp(name, "split_weights") == 0) { e->split_weights = value != 0; e->drop_graphs(); return DVD_OK; }
   if (strcmp(name, "small_tiles") == 0) { e->small_tiles = value != 0; e->drop_graphs(); return DVD_OK; }
   if (strcmp(name, "ffn_lo") == 0) { e->ffn_lo = value != 0; e->drop_graphs(); return DVD_OK; }
+  if (strcmp(name, "dither") == 0) { e->dither = value != 0; e->drop_graphs(); return DVD_OK; }
+  if (strcmp(name, "dither_step") == 0) { e->dither_step = (unsigned)value; return DVD_OK; }
   if (strcmp(name, "graphs") == 0) {
     e->use_graphs = value != 0;
     if (!e->use_graphs) e->drop_graphs();
@@ -588,8 +646,8 @@ static int enqueue_step(Engine* e, const float* x_t, int feat_mode, const float*
            0, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0, stream, nullptr, e->L(e->wi.ca_wq16)));
   TRY(gemm(F16, (int)NT, HID, HID, 1, rtok16, HID, 0, e->H(e->wi.ca_wk16), HID, 0, nullptr, 0, 0, kr16, HID, 0,
            e->F(e->wi.ca_bk), 0, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0, stream, nullptr, e->L(e->wi.ca_wk16)));
-  TRY(gemm(F16, HID, T, HID, N, e->H(e->wi.ca_wv16), HID, 0, rtok16, HID, (long)T * HID, nullptr, 0, 0, vtr16, T,
-           (long)HID * T, e->F(e->wi.ca_bv), 1, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0, stream, e->L(e->wi.ca_wv16), nullptr));
+  TRY(gemm(F16, HID, T, HID, N, e->H(e->wi.ca_wv16, true), HID, 0, rtok16, HID, (long)T * HID, nullptr, 0, 0, vtr16, T,
+           (long)HID * T, e->F(e->wi.ca_bv), 1, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0, stream, e->L(e->wi.ca_wv16, true), nullptr));
   {
     const int kn[3] = {e->bi.kc16, e->bi.km16, e->bi.kl16};
     const int vn[3] = {e->bi.vtc16, e->bi.vtm16, e->bi.vtl16};
@@ -607,10 +665,10 @@ static int enqueue_step(Engine* e, const float* x_t, int feat_mode, const float*
   // --- per stream: gated self-attention (:268-289) ---
   TRY(dvd_layernorm_rows(z, DEC, HID, h16, HID, NT * HID, 4, NT, HID, nullptr, nullptr, sh_a, sc_a, 0, (int)NT, 1e-6f,
                          stream));
-  TRY(gemm(F16, (int)(4 * NT), 2 * HID, HID, 1, h16, HID, 0, e->H(e->wi.sa_wqk16), HID, 0, nullptr, 0, 0, qk16, 2 * HID, 0,
-           e->F(e->wi.sa_bqk), 0, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0, stream, nullptr, e->L(e->wi.sa_wqk16)));
-  TRY(gemm(F16, HID, T, HID, 4 * N, e->H(e->wi.sa_wv16), HID, 0, h16, HID, (long)T * HID, nullptr, 0, 0, vt16, T,
-           (long)HID * T, e->F(e->wi.sa_bv), 1, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0, stream, e->L(e->wi.sa_wv16), nullptr));
+  TRY(gemm(F16, (int)(4 * NT), 2 * HID, HID, 1, h16, HID, 0, e->H(e->wi.sa_wqk16, true), HID, 0, nullptr, 0, 0, qk16, 2 * HID, 0,
+           e->F(e->wi.sa_bqk), 0, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0, stream, nullptr, e->L(e->wi.sa_wqk16, true)));
+  TRY(gemm(F16, HID, T, HID, 4 * N, e->H(e->wi.sa_wv16, true), HID, 0, h16, HID, (long)T * HID, nullptr, 0, 0, vt16, T,
+           (long)HID * T, e->F(e->wi.sa_bv), 1, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0, stream, e->L(e->wi.sa_wv16, true), nullptr));
   TRY(attn(64, 6, 4 * N, T, T, 1, qk16, 2 * HID, (long)T * 2 * HID, qk16 + HID, 2 * HID, (long)T * 2 * HID, vt16, T,
            (long)HID * T, att16, HID, (long)T * HID, 0.125f, stream));
   TRY(gemm(F16, (int)NT, HID, HID, 4, att16, HID, NT * HID, e->H(e->wi.sa_wp16), HID, 0, z, DEC, HID, nullptr, 0, 0,
@@ -618,8 +676,8 @@ static int enqueue_step(Engine* e, const float* x_t, int feat_mode, const float*
   // --- per stream: gated MLP (:271-292) ---
   TRY(dvd_layernorm_rows(z, DEC, HID, h16, HID, NT * HID, 4, NT, HID, nullptr, nullptr, sh_m, sc_m, 0, (int)NT, 1e-6f,
                          stream));
-  TRY(gemm(F16, (int)(4 * NT), 4 * HID, HID, 1, h16, HID, 0, e->H(e->wi.fc1_w16), HID, 0, nullptr, 0, 0, mlp16, 4 * HID, 0,
-           e->F(e->wi.fc1_b), 0, /*gelu*/ 1, nullptr, 0, nullptr, 0, nullptr, 0, 0, stream, nullptr, e->L(e->wi.fc1_w16)));
+  TRY(gemm(F16, (int)(4 * NT), 4 * HID, HID, 1, h16, HID, 0, e->H(e->wi.fc1_w16, true), HID, 0, nullptr, 0, 0, mlp16, 4 * HID, 0,
+           e->F(e->wi.fc1_b), 0, /*gelu*/ 1, nullptr, 0, nullptr, 0, nullptr, 0, 0, stream, nullptr, e->L(e->wi.fc1_w16, true)));
   TRY(gemm(F16, (int)NT, HID, 4 * HID, 4, mlp16, 4 * HID, NT * 4 * HID, e->H(e->wi.fc2_w16), 4 * HID, 0, z, DEC, HID,
            nullptr, 0, 0, e->F(e->wi.fc2_b), 0, 0, nullptr, 0, g_m, (int)NT, z, DEC, HID, stream, nullptr, e->L(e->wi.fc2_w16)));
 
@@ -644,10 +702,10 @@ static int enqueue_step(Engine* e, const float* x_t, int feat_mode, const float*
     const WIdx::Dec& dw = e->wi.d[j];
     TRY(dvd_layernorm_rows(z, DEC, 0, h16, DEC, 0, 1, NT, DEC, e->F(dw.n1w), e->F(dw.n1b), nullptr, nullptr, 0,
                            1, 1e-5f, stream));
-    TRY(gemm(F16, (int)NT, 2 * DEC, DEC, 1, h16, DEC, 0, e->H(dw.wqk16), DEC, 0, nullptr, 0, 0, qk16, 2 * DEC, 0,
-             nullptr, 0, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0, stream, nullptr, e->L(dw.wqk16)));
-    TRY(gemm(F16, DEC, T, DEC, N, e->H(dw.wv16), DEC, 0, h16, DEC, (long)T * DEC, nullptr, 0, 0, vt16, T,
-             (long)DEC * T, nullptr, 0, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0, stream, e->L(dw.wv16), nullptr));
+    TRY(gemm(F16, (int)NT, 2 * DEC, DEC, 1, h16, DEC, 0, e->H(dw.wqk16, true), DEC, 0, nullptr, 0, 0, qk16, 2 * DEC, 0,
+             nullptr, 0, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0, stream, nullptr, e->L(dw.wqk16, true)));
+    TRY(gemm(F16, DEC, T, DEC, N, e->H(dw.wv16, true), DEC, 0, h16, DEC, (long)T * DEC, nullptr, 0, 0, vt16, T,
+             (long)DEC * T, nullptr, 0, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0, stream, e->L(dw.wv16, true), nullptr));
     const bool timed = e->prof_on;
     size_t slot = 0;
     if (timed) {
@@ -658,15 +716,15 @@ static int enqueue_step(Engine* e, const float* x_t, int feat_mode, const float*
     TRY(attn(256, 6, N, T, T, 1, qk16, 2 * DEC, (long)T * 2 * DEC, qk16 + DEC, 2 * DEC, (long)T * 2 * DEC, vt16, T,
              (long)DEC * T, att16, DEC, (long)T * DEC, 0.0625f, stream));
     if (timed) { (void)hipEventRecord(e->prof_ev[2 * slot + 1], st); e->prof_inflight += 1; }
-    TRY(gemm(F16, (int)NT, DEC, DEC, 1, att16, DEC, 0, e->H(dw.wfc16), DEC, 0, z, DEC, 0, nullptr, 0, 0, nullptr, 0,
-             0, nullptr, 0, nullptr, 0, z, DEC, 0, stream, nullptr, e->L(dw.wfc16)));
+    TRY(gemm(F16, (int)NT, DEC, DEC, 1, att16, DEC, 0, e->H(dw.wfc16, true), DEC, 0, z, DEC, 0, nullptr, 0, 0, nullptr, 0,
+             0, nullptr, 0, nullptr, 0, z, DEC, 0, stream, nullptr, e->L(dw.wfc16, true)));
     TRY(dvd_layernorm_rows(z, DEC, 0, h16, DEC, 0, 1, NT, DEC, e->F(dw.n2w), e->F(dw.n2b), nullptr, nullptr, 0,
                            1, 1e-5f, stream));
-    TRY(gemm(F16, (int)NT, FFN, DEC, 1, h16, DEC, 0, e->H(dw.c1w16), DEC, 0, nullptr, 0, 0, f1, FFN, 0,
-             e->F(dw.c1b), 0, 2, nullptr, 0, nullptr, 0, nullptr, 0, 0, stream, nullptr, e->Lffn(dw.c1w16)));
+    TRY(gemm(F16, (int)NT, FFN, DEC, 1, h16, DEC, 0, e->H(dw.c1w16, true), DEC, 0, nullptr, 0, 0, f1, FFN, 0,
+             e->F(dw.c1b), 0, 2, nullptr, 0, nullptr, 0, nullptr, 0, 0, stream, nullptr, e->Lffn(dw.c1w16, true)));
     TRY(dvd_dwconv3x3(f1, f2, e->F(dw.dww), e->F(dw.dwb), N, side, FFN, stream));
-    TRY(gemm(F16, (int)NT, DEC, FFN, 1, f2, FFN, 0, e->H(dw.c2w16), FFN, 0, z, DEC, 0, nullptr, 0, 0,
-             e->F(dw.c2b), 0, 2, nullptr, 0, nullptr, 0, z, DEC, 0, stream, nullptr, e->Lffn(dw.c2w16)));
+    TRY(gemm(F16, (int)NT, DEC, FFN, 1, f2, FFN, 0, e->H(dw.c2w16, true), FFN, 0, z, DEC, 0, nullptr, 0, 0,
+             e->F(dw.c2b), 0, 2, nullptr, 0, nullptr, 0, z, DEC, 0, stream, nullptr, e->Lffn(dw.c2w16, true)));
     if (e->debug_stop == 4 + j) return check_launch("engine_denoise_step(stop 4+j)");
   }
 
@@ -687,6 +745,14 @@ extern "C" int dvd_engine_denoise_step(void* handle, const float* x_t, float t_e
   DVD_REQUIRE(4 * e->NT < (1L << 31), "engine_denoise_step: batch too large for 32-bit row indices (NT=%ld)", e->NT);
   hipStream_t st = (hipStream_t)stream;
   set_scalar_kernel<<<1, 1, 0, st>>>((float*)e->B(e->bi.tbuf), t_embed);
+  if (e->dither && !e->small_tiles) {
+    // re-round the weights of the 256-wide GEMMs for this evaluation (outside any captured graph: the phase changes)
+    _Float16* dst = (_Float16*)e->B(e->bi.w16dith);
+    for (int i : e->dith_list)
+      TRY(dvd_dither_f16(e->wptr[i], e->wptr[i + 1], dst + e->dith_off[i], e->specs[i].nelem, (unsigned)e->dith_off[i],
+                         e->dither_step, stream));
+    e->dither_step += 1;
+  }
   if (!e->use_graphs || e->prof_on || e->debug_stop)
     return enqueue_step(e, x_t, feat_mode, init_flow, init_feat_nchw, x0_out, stream);
 
@@ -696,11 +762,13 @@ extern "C" int dvd_engine_denoise_step(void* handle, const float* x_t, float t_e
   GraphEntry* ge = nullptr;
   for (auto& g : e->graphs)
     if (g.key == key) { ge = &g; break; }
+  e->graph_clock += 1;
   if (!ge) {
-    if (e->graphs.size() >= 32) e->drop_graphs();
-    e->graphs.push_back({key, nullptr});
+    if (e->graphs.size() >= 32) e->evict_one(st);
+    e->graphs.push_back({key, nullptr, e->graph_clock});
     return enqueue_step(e, x_t, feat_mode, init_flow, init_feat_nchw, x0_out, stream);
   }
+  ge->last_use = e->graph_clock;
   if (!ge->exec) {
     if (!e->cap_stream && hipStreamCreateWithFlags(&e->cap_stream, hipStreamNonBlocking) != hipSuccess) {
       set_error("engine_denoise_step: cannot create the capture stream");

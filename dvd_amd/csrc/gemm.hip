@@ -1207,10 +1207,10 @@ extern "C" int dvd_gemm_nt(const dvd_gemm_desc* d, void* stream) {
       !lab_twopass && !lab_v1 && !small) {
     p.ntm = cdiv(d->M, 256); p.ntn = d->N / 128;
     constexpr int LDS = 8 * 16384;                    // 3 stages x 32 KiB, rounded up to the epilogue's 8 x 16 KiB
-    static bool once_s1 = false;
-    if (!once_s1) {
+    static DeviceOnce once_s1;
+    if (const auto bit = DeviceOnce::current_bit(); once_s1.need(bit)) {
       (void)hipFuncSetAttribute((const void*)gemm_nt_split128_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-      once_s1 = true;
+      once_s1.done(bit);
     }
     int nblk = p.ntm * p.ntn;
     if (nblk > 256) nblk = 256;
@@ -1220,10 +1220,10 @@ extern "C" int dvd_gemm_nt(const dvd_gemm_desc* d, void* stream) {
   if (big && d->B_lo && !d->A_lo && d->lo_scale == 1.f && d->K % 32 == 0 && !lab_twopass) {
     p.ntm = cdiv(d->M, 256); p.ntn = d->N / 256;
     constexpr int LDS = 3 * 3 * 256 * 64;
-    static bool once_s = false;
-    if (!once_s) {
+    static DeviceOnce once_s;
+    if (const auto bit = DeviceOnce::current_bit(); once_s.need(bit)) {
       (void)hipFuncSetAttribute((const void*)gemm_nt_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-      once_s = true;
+      once_s.done(bit);
     }
     int nblk = p.ntm * p.ntn;
     if (nblk > 256) nblk = 256;
@@ -1233,8 +1233,8 @@ extern "C" int dvd_gemm_nt(const dvd_gemm_desc* d, void* stream) {
   if (big) {
     p.ntm = cdiv(d->M, 256); p.ntn = d->N / 256;
     constexpr int LDS = 2 * 2 * 256 * 128;
-    static bool once = false;
-    if (!once) {
+    static DeviceOnce once;
+    if (const auto bit = DeviceOnce::current_bit(); once.need(bit)) {
       (void)hipFuncSetAttribute((const void*)gemm_nt_big_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
 #ifdef DVD_LAB
       (void)hipFuncSetAttribute((const void*)gemm_nt_big_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -1242,7 +1242,7 @@ extern "C" int dvd_gemm_nt(const dvd_gemm_desc* d, void* stream) {
       (void)hipFuncSetAttribute((const void*)gemm_nt_big_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
       (void)hipFuncSetAttribute((const void*)gemm_nt_big_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
 #endif
-      once = true;
+      once.done(bit);
     }
     int nblk = p.ntm * p.ntn;
     if (nblk > 256 && !lab_nonpersistent) nblk = 256;

@@ -20,6 +20,10 @@ def _env_int(name, default):
 def setup_dist(backend=None):
     """Initialise torch.distributed from torchrun's environment (single process: a 1-rank group).
     Returns True when this call created the group (the caller then owns destroying it)."""
+    # the device of this process is chosen HERE, once, for every backend and also when the caller brought its own
+    # process group: dev() reads it back (the reference maps rank % GPUS_PER_NODE, idf/dist_util.py:44-50)
+    if th.cuda.is_available():
+        th.cuda.set_device(_env_int("LOCAL_RANK", _env_int("RANK", 0)) % max(1, th.cuda.device_count()))
     if dist.is_initialized():
         return False
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -30,7 +34,6 @@ def setup_dist(backend=None):
     if backend is None:
         backend = "nccl" if th.cuda.is_available() else "gloo"
     if backend == "nccl":
-        th.cuda.set_device(_env_int("LOCAL_RANK", 0) % max(1, th.cuda.device_count()))
         # bind the communicator to this rank's device up front (no device guessing at the first barrier)
         dist.init_process_group(backend=backend, init_method="env://",
                                 device_id=th.device("cuda", th.cuda.current_device()))
@@ -53,6 +56,20 @@ def dev():
     if th.cuda.is_available():
         return th.device("cuda", th.cuda.current_device())
     return th.device("cpu")
+
+
+def raise_together(exc=None, what="checkpoint loading"):
+    """COLLECTIVE error hand-shake: every rank calls it with the exception it caught (or None).  If any rank failed, ALL
+    ranks raise - a rank that failed alone would otherwise leave the others blocked in the weight broadcast until the
+    launcher kills them (only rank 0 reads the checkpoint files)."""
+    if world_size() > 1:
+        on_gpu = dist.get_backend() == "nccl"
+        flag = th.tensor([0 if exc is None else 1], dtype=th.int32, device=dev() if on_gpu else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        if int(flag.item()) and exc is None:
+            raise RuntimeError(f"{what} failed on another rank (see its log)")
+    if exc is not None:
+        raise exc
 
 
 def load_state_dict(path, **kwargs):

@@ -52,9 +52,11 @@ def synthetic_documents(settings, indices):
 def image_documents(settings, indices, files):
     """Image files of a benchmark directory (doc_benchmark.py:60-62,80-83): decoded on the CPU (PIL -> RGB uint8);
     everything after the decode runs on the GPU."""
-    from PIL import Image
+    from PIL import Image, ImageOps
     for i in indices:
-        d = {"image_u8": np.ascontiguousarray(np.asarray(Image.open(files[i]).convert("RGB"), dtype=np.uint8))}
+        # cv2.imread applies the EXIF orientation (IMREAD_COLOR without IMREAD_IGNORE_ORIENTATION); PIL does not by itself
+        im = ImageOps.exif_transpose(Image.open(files[i]))
+        d = {"image_u8": np.ascontiguousarray(np.asarray(im.convert("RGB"), dtype=np.uint8))}
         d["path"] = os.path.splitext(os.path.basename(files[i]))[0]
         yield d
 
@@ -69,22 +71,25 @@ def npz_documents(settings, indices, files):
 
 def prepare_conditioning(batch, device, grid, prestage_models):
     """Documents given as decoded images: ingest (cv2.resize to 512^2, / 255; doc_benchmark.py:84-88) and the pre-stage
-    nets (evaluation.py:162-216) fill in y512 / mask_cat / mask_y512 / line_msk / src_u8 as DEVICE tensors."""
+    nets (evaluation.py:162-216) fill in y512 / mask_cat / mask_y512 / line_msk / src_u8 as DEVICE tensors.  Documents
+    that already carry their conditioning tensors (synthetic ones with env.use_prestage_nets=False, .npz files of
+    env.conditioning_dir) pass through untouched and need no pre-stage nets."""
     from . import prestage
-    if prestage_models is None:
-        raise RuntimeError("documents were given as images but the pre-stage nets are not loaded (env.use_prestage_nets)")
-    for d in batch:
-        if "image_u8" not in d or "y512" in d:
-            continue
+    need_ingest = [d for d in batch if "image_u8" in d and "y512" not in d]
+    for d in need_ingest:
         img = th.from_numpy(d["image_u8"]).to(device)
         d["y512"], d["src_u8"] = ops.ingest_u8(img, swap_rb=False, out_size=512, want_rgb=True)
-    todo = [d for d in batch if "mask_cat" not in d]
-    if todo:
-        src = th.stack([d["y512"] if th.is_tensor(d["y512"]) else th.from_numpy(d["y512"]).to(device) for d in todo])
-        cond = prestage.conditioning(*prestage_models, src, grid)
-        for j, d in enumerate(todo):
-            for k in ("mask_cat", "mask_y512", "line_msk"):
-                d[k] = cond[k][j]
+    todo = [d for d in batch if any(k not in d for k in ("mask_cat", "mask_y512", "line_msk"))]
+    if not todo:
+        return
+    if prestage_models is None:
+        raise RuntimeError(f"{len(todo)} document(s) lack mask_cat / mask_y512 / line_msk and the pre-stage nets are not "
+                           "loaded (env.use_prestage_nets=False): give ready conditioning tensors or load the nets")
+    src = th.stack([d["y512"] if th.is_tensor(d["y512"]) else th.from_numpy(d["y512"]).to(device) for d in todo])
+    cond = prestage.conditioning(*prestage_models, src, grid)
+    for j, d in enumerate(todo):
+        for k in ("mask_cat", "mask_y512", "line_msk"):
+            d[k] = cond[k][j]
 
 
 def run_evaluation_docunet(settings, logger, documents, diffusion, model, device, prestage_models=None):

@@ -16,8 +16,9 @@ import os
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# DVD_HIP_LIB: A/B runs of an alternative build of the SAME library (benchmarks only); default = the in-tree build
-LIB_PATH = os.environ.get("DVD_HIP_LIB") or os.path.join(_HERE, "libdvd_hip.so")
+# The product loads the in-tree build and nothing else: no environment variable can put another library under it.
+# benchmarks/ and the `lab` pytest fixture swap in the lab build explicitly, in their own process (use_library below).
+LIB_PATH = os.path.join(_HERE, "libdvd_hip.so")
 
 
 class DvdError(RuntimeError):
@@ -116,6 +117,7 @@ SIGNATURES = {
     "dvd_resize_bilinear_nchw": [c_void, c_void, C.c_long, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_void],
     "dvd_threshold_mask_mul": [c_void, c_void, c_void, c_void, C.c_int, C.c_long, C.c_float, c_void],
     "dvd_ingest_u8": [c_void, C.c_int, C.c_int, C.c_int, c_void, C.c_int, c_void, c_void, c_void],
+    "dvd_dither_f16": [c_void, c_void, c_void, C.c_long, C.c_uint, C.c_uint, c_void],
     "dvd_engine_create": [C.c_int, C.c_int, C.c_int, C.POINTER(c_void)],
     "dvd_engine_destroy": [c_void],
     "dvd_engine_bind_workspace": [c_void, c_void, C.c_long],
@@ -133,7 +135,7 @@ SIGNATURES = {
 }
 
 
-# entry points that exist only in the lab build (benchmarks/lab/dvd_hip_lab.h; DVD_HIP_LIB=benchmarks/lab/libdvd_hip_lab.so)
+# entry points that exist only in the lab build (benchmarks/lab/dvd_hip_lab.h; loaded through use_library)
 LAB_SIGNATURES = {"dvd_gemm_debug_stamps": [c_void], "dvd_attn_debug_stamps": [c_void]}
 
 
@@ -159,6 +161,14 @@ def bind(cdll):
 
 
 bind(_lib)
+
+
+def use_library(path: str):
+    """Route this process through another build of the SAME library (benchmarks/_lab.py and the `lab` pytest fixture
+    load benchmarks/lab/libdvd_hip_lab.so this way).  An explicit call in the caller's code - never the environment."""
+    global _lib
+    _lib = bind(C.CDLL(os.path.abspath(path)))
+    return _lib
 
 
 def call(name: str, *args):

@@ -126,6 +126,17 @@ def hyp_mean_clamp(x0: torch.Tensor, n_hyp: int) -> torch.Tensor:
     return out
 
 
+def dither_f16(hi: torch.Tensor, lo: torch.Tensor, step: int, elem0: int = 0, out=None) -> torch.Tensor:
+    """W = hi + lo (both f16) re-rounded to ONE f16 with the step-dependent sub-ulp offset of dvd_dither_f16."""
+    _chk(hi, torch.float16, "hi")
+    _chk(lo, torch.float16, "lo")
+    if out is None:
+        out = torch.empty_like(hi)
+    lib.call("dvd_dither_f16", ptr(hi), ptr(lo), ptr(out), hi.numel(), C.c_uint(elem0 & 0xFFFFFFFF),
+             C.c_uint(step & 0xFFFFFFFF), stream_ptr())
+    return out
+
+
 def selftest_mfma(a16, b16, vt16):
     out = torch.empty(3072, dtype=torch.float32, device=a16.device)
     lib.call("dvd_selftest_mfma", ptr(a16), ptr(b16), ptr(vt16), ptr(out), stream_ptr())

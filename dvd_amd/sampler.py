@@ -59,7 +59,7 @@ def sample(engine: Engine, tables: schedule.Tables, x_T: torch.Tensor, sampler: 
         if first and mode == 0 and init_feat is not None:      # a first step at t_model <= 600 sees the caller's init_feat
             mode, feat_in = 3, init_feat.to(img.device, torch.float32).contiguous()
         t_embed = schedule.embedded_time(t_model) if t_override else float(t_model)
-        x0 = engine.denoise(img, t_embed, mode, flow, out=out, init_feat=feat_in)
+        x0 = engine.denoise(img, t_embed, mode, flow, out=out, init_feat=feat_in, dither_step=k)
         if trace is not None:
             trace.append(x0.clone())
         if sampler == "ddim":

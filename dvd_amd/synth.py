@@ -218,8 +218,19 @@ def synth_tensor(key: str, shape, kind: str, seed: int = 0) -> np.ndarray:
     raise ValueError(f"no synthetic rule for kind {kind!r} ({key})")
 
 
-def synth_state_dict(grid: int = 64, seed: int = 0, blocks=range(DEPTH), keys=None):
-    """name -> numpy array for every tensor of the spec (or only `keys`)."""
+def tame_gain(steps: int) -> float:
+    """`out_gain` of the TAME weight family for an S-step roll-out.  The denoiser's output is `o + init_flow` with
+    init_flow = the previous step's x0 (idf/cross_model.py:645-646, idf/gaussian_diffusion.py:618-620), so under random
+    weights x0 grows roughly linearly with the step count: with the plain family (out_gain 1) 60-90 % of the last
+    step's pixels lie outside [-1, 1] and the final clamp hides their error.  A trained model's coordinates stay inside
+    (-1, 1); 1.6 / S keeps the last-step x0 at a standard deviation of 0.3-0.5 with no saturated pixel, so the parity
+    tests can assert on the un-clamped, un-averaged x0."""
+    return 1.6 / steps
+
+
+def synth_state_dict(grid: int = 64, seed: int = 0, blocks=range(DEPTH), keys=None, out_gain: float = 1.0):
+    """name -> numpy array for every tensor of the spec (or only `keys`).  out_gain scales the final linear layer
+    (weight and bias): 1.0 is the family the golden vectors were made with, `tame_gain(S)` the tame family."""
     spec = state_dict_spec(grid, blocks)
     out = OrderedDict()
     for k, (shape, kind) in spec.items():
@@ -233,6 +244,8 @@ def synth_state_dict(grid: int = 64, seed: int = 0, blocks=range(DEPTH), keys=No
             out[k] = decoder_sinusoid_table(grid // 2, DEC).T.reshape(1, DEC, 1, grid // 2).copy()
         else:
             out[k] = synth_tensor(k, shape, kind, seed)
+            if out_gain != 1.0 and k.startswith("final_layer2.linear."):
+                out[k] = (out[k] * np.float32(out_gain)).astype(np.float32)
     return out
 
 

@@ -39,23 +39,35 @@ def run(settings):
     if getattr(env, "use_init_flow", False):
         raise NotImplementedError("env.use_init_flow needs GeoTr's `ref_bm`, whose weights the reference itself never "
                                   "loads (val_TDiff.py:57-58 only reloads `.msk`): not a live configuration")
-    # rank 0 alone reads the checkpoint (val_TDiff.py:79); the other ranks receive the packed blob below
+    # rank 0 alone reads the checkpoint (val_TDiff.py:79); the other ranks receive the packed blob below.  A failure on
+    # rank 0 (missing / corrupt file) is agreed on by every rank BEFORE the broadcast, so all ranks raise together.
+    failure = None
     if dist_util.rank() == 0:
-        if os.path.exists(env.model_path):
-            model.cpu().load_state_dict(dist_util.load_state_dict(env.model_path, map_location="cpu"), strict=False)
-            logger.log(f"Model loaded with {env.model_path}")
-        elif _want_synthetic_weights(env):
-            sd = synth.synth_state_dict(env.grid_size, seed=7)
-            model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
-            logger.log(f"{env.model_path} not found: using deterministic synthetic weights (seed 7)")
-        else:
-            raise FileNotFoundError(f"{env.model_path} (set env.synthetic_weights_if_missing=True to sample with "
-                                    "synthetic stand-in weights)")
+        try:
+            if os.path.exists(env.model_path):
+                model.cpu().load_state_dict(dist_util.load_state_dict(env.model_path, map_location="cpu"), strict=False)
+                logger.log(f"Model loaded with {env.model_path}")
+            elif _want_synthetic_weights(env):
+                sd = synth.synth_state_dict(env.grid_size, seed=7)
+                model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+                logger.log(f"{env.model_path} not found: using deterministic synthetic weights (seed 7)")
+            else:
+                raise FileNotFoundError(f"{env.model_path} (set env.synthetic_weights_if_missing=True to sample with "
+                                        "synthetic stand-in weights)")
+        except Exception as e:  # noqa: BLE001 - re-raised on every rank by raise_together
+            failure = e
+    dist_util.raise_together(failure, "loading the denoiser checkpoint")
     _require_gpu()
     model.to(dist_util.dev())
     print(get_parameter_number(model))
     model.eval()
-    pre = load_prestage_models(env) if getattr(env, "use_prestage_nets", False) else None
+    pre, failure = None, None
+    if getattr(env, "use_prestage_nets", False):
+        try:
+            pre = load_prestage_models(env)
+        except Exception as e:  # noqa: BLE001
+            failure = e
+        dist_util.raise_together(failure, "loading the pre-stage checkpoints")
     # the path's ONE collective, issued eagerly and unconditionally by every rank BEFORE the documents are sharded:
     # rank 0 packs every model (denoiser + the three pre-stage nets) into one flat buffer, one broadcast (a rank whose
     # shard is empty still takes part, then goes to the barrier)
@@ -70,7 +82,11 @@ def run(settings):
         mine = dist_util.shard_documents(len(files))
         documents = npz_documents(settings, mine, files)
     else:      # a benchmark directory of images, as the reference's Doc_benchmark (val_TDiff.py:96-104)
-        files = sorted(f for ext in ("*.jpg", "*.jpeg", "*.png") for f in glob.glob(os.path.join(env.eval_dataset, ext)))
+        # the reference lists the directory (os.listdir, doc_benchmark.py:60-62) and cv2.imread decodes whatever it finds;
+        # here: every file with an image extension, case-insensitively (.JPG from cameras included), in sorted order
+        exts = (".jpg", ".jpeg", ".png", ".bmp", ".tif", ".tiff", ".webp")
+        files = sorted(os.path.join(env.eval_dataset, f) for f in os.listdir(env.eval_dataset)
+                       if f.lower().endswith(exts))
         mine = dist_util.shard_documents(len(files))
         documents = image_documents(settings, mine, files)
     logger.info(f"rank {dist_util.rank()}/{dist_util.world_size()}: {len(mine)} documents")

@@ -270,6 +270,14 @@ long dvd_ingest_scratch_bytes(int out_size);
 int dvd_ingest_u8(const uint8_t* src_hwc, int h, int w, int swap_rb, float* y_chw, int out_size,
                   uint8_t* rgb_hwc_out, void* scratch, void* stream);
 
+/* Temporal dithering of the f16 weight rounding (no reference counterpart: the reference is fp32; the GEMMs that consume
+ * the result are the per-step nn.Linear / 1x1 convs, idf/cross_attn.py:197-221,52-57, idf/cross_model.py:163-174).
+ * hi, lo [nelem] f16 with W = hi + lo (hi = round-to-nearest f16 of W); out [nelem] f16 = W re-rounded to one of its two
+ * f16 neighbours so that the MEAN over consecutive `step`s is W: up iff hash(elem0 + i) + step * 2^32/phi (mod 2^32) <
+ * 2^32 * (W - down)/(up - down).  nelem % 8 == 0, 16-byte aligned.  The engine calls it before each evaluation when
+ * its "dither" option is on. */
+int dvd_dither_f16(const void* hi, const void* lo, void* out, long nelem, unsigned elem0, unsigned step, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Engine: DiT.forward of the live model (idf/cross_model.py:568-647) for docs x n_hyp samples.
  *   create -> workspace_bytes -> bind_workspace -> set_tensor(every tensor of tensor_info) ->
@@ -286,6 +294,12 @@ int dvd_engine_tensor_info(void* handle, int index, const char** name, int* dtyp
 int dvd_engine_set_tensor(void* handle, const char* name, const void* dev_ptr, long nelem);
 /* options (per handle; no environment variable is read anywhere in the library):
  *   "split_weights" (default 1): use the (hi, lo) f16 weight pairs -> fp32-grade weights, 2x GEMM MFMAs;
+ *   "dither"        (default: 1 when the grid takes the 256-wide GEMM kernels, i.e. grid >= 66, else 0): the weights of
+ *                                the 256-wide per-step GEMMs are re-rounded to ONE f16 before every evaluation with a
+ *                                step-dependent sub-ulp offset (dvd_dither_f16: zero-mean over the steps) and those
+ *                                GEMMs run one pass - half the MFMAs of the split; the other GEMMs keep the (hi, lo) pair;
+ *   "dither_step"              : the evaluation counter the next denoise_step dithers with (it then increments); the
+ *                                sampler sets it to the loop index so a roll-out does not depend on the handle's history;
  *   "ffn_lo"        (default 1): 0 drops the lo pass of the decoder FFN's two 1x1 convs only (-4.8 % step time;
  *                                measured coordinate error on synthetic weights 1.2e-4 -> 3.3e-4: opt-in);
  *   "graphs"        (default 0): replay each denoiser evaluation as a captured hipGraph (bit-identical results;

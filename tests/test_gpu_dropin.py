@@ -154,3 +154,80 @@ def test_single_step_signatures_vs_reference_golden():
     np.testing.assert_allclose(pmv["log_variance"].cpu().numpy().ravel()[0], sch["s3/fixed_large_logvar_f32"][2], rtol=1e-6)
     with pytest.raises(ValueError):
         diffusion.ddim_sample(model, x_in, torch.tensor([2, 1], device="cuda"), clip_denoised=False, model_kwargs=kw)
+
+
+def _settings(name, grid=16, steps=3, docs=3, batch=2, full_res=(160, 120)):
+    import admin.settings as ws
+    s = ws.Settings()
+    s.env.grid_size, s.env.diffusion_steps = grid, steps
+    s.env.num_synthetic_docs, s.env.batch_docs, s.env.full_res = docs, batch, full_res
+    s.env.visualize = False
+    s.name, s.seed, s.severity, s.corruption_number = name, 0, 0, 0
+    return s
+
+
+def test_plugin_run_from_checkpoint_files(tmp_path, monkeypatch):
+    """the four checkpoints written in the reference's ON-DISK formats and loaded by val_TDiff.run the
+    way val_TDiff.py:57-79 / geotr_core.py:1090-1112 load them -
+      seg.pth          flat dict, every key prefixed 'model.' (reload_segmodel strips 6 characters),
+      line_model2.pth  {'model': state_dict} for UNet(3, 1), strict=True,
+      seg_model.pth    {'model': state_dict} for Seg() (keys 'msk.*'), strict=True,
+      model1852000.pt  plain state dict of the denoiser, strict=False: one (dead-block) key missing and one unexpected
+                       key present must both be tolerated -
+    give bit-identical documents to the in-memory load_state_dict path on the same weights."""
+    monkeypatch.chdir(tmp_path)
+    from dvd_amd import val_TDiff
+    tt = lambda sd: {k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}  # noqa: E731
+    s = _settings("from_memory")
+    s.env.use_prestage_nets = True
+    torch.manual_seed(0)
+    want = val_TDiff.run(s)            # no files: synthetic weights (denoiser seed 7, nets seeds 11 / 13 / 22) in memory
+
+    os.makedirs("checkpoints")
+    torch.save({"model." + k: v for k, v in tt(synth.synth_convnet_state_dict("u2netp", 11)).items()}, "checkpoints/seg.pth")
+    torch.save({"model": tt(synth.synth_convnet_state_dict("unet", 13))}, "checkpoints/line_model2.pth")
+    torch.save({"model": tt(synth.synth_convnet_state_dict("u2netp", 22, prefix="msk."))}, "checkpoints/seg_model.pth")
+    sd = tt(synth.synth_state_dict(16, seed=7))
+    del sd["blocks.0.attn.qkv.weight"]                                 # missing key (a dead block: result unchanged)
+    sd["ema_decay_not_a_parameter"] = torch.zeros(3)                   # unexpected key
+    torch.save(sd, "checkpoints/model1852000.pt")
+    s2 = _settings("from_files")
+    s2.env.use_prestage_nets = True
+    s2.env.synthetic_weights_if_missing = False                        # a missing file must raise, not fall back
+    for attr, f in (("model_path", "model1852000.pt"), ("seg_model_path", "seg.pth"),
+                    ("line_seg_model_path", "line_model2.pth"), ("new_seg_model_path", "seg_model.pth")):
+        setattr(s2.env, attr, os.path.join("checkpoints", f))
+    torch.manual_seed(0)
+    got = val_TDiff.run(s2)
+    assert len(got) == len(want) == 3
+    for (pa, a), (pb, b) in zip(want, got):
+        assert pa == pb and torch.equal(a, b), pa
+    # and a missing file on a run that may not fall back raises
+    os.remove("checkpoints/seg_model.pth")
+    with pytest.raises(FileNotFoundError):
+        val_TDiff.run(s2)
+
+
+def test_plugin_run_without_prestage_nets_and_from_npz(tmp_path, monkeypatch):
+    """env.use_prestage_nets=False: synthetic documents carry ready conditioning tensors and no pre-stage net is built
+    (round-2 ADVICE: this configuration raised); the same documents written as conditioning .npz files
+    (env.conditioning_dir) give the same bits."""
+    monkeypatch.chdir(tmp_path)
+    from dvd_amd import val_TDiff
+    s = _settings("no_prestage")
+    s.env.use_prestage_nets = False
+    torch.manual_seed(0)
+    want = val_TDiff.run(s)
+    assert len(want) == 3 and all(img.dtype == torch.uint8 and tuple(img.shape) == (160, 120, 3) for _, img in want)
+    os.makedirs("cond")
+    for i in range(3):
+        d = synth.synth_document(i, 16, seed=1234, full_res=(160, 120))
+        np.savez(f"cond/synthetic_{i:05d}.npz", **d)
+    s2 = _settings("from_npz")
+    s2.env.use_prestage_nets = False
+    s2.env.eval_dataset_name, s2.env.conditioning_dir = "npz_docs", "cond"
+    s2.env.synthetic_weights_if_missing = True
+    torch.manual_seed(0)
+    got = val_TDiff.run(s2)
+    for (pa, a), (pb, b) in zip(want, got):
+        assert pa == pb and torch.equal(a, b), pa

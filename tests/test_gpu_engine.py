@@ -16,13 +16,16 @@ SEED_W, SEED_IN = 7, 1234
 _cache = {}
 
 
-def setup(grid, docs=1, hyp=2):
-    key = (grid, docs, hyp)
+def setup(grid, docs=1, hyp=2, out_gain=1.0):
+    """Engine + oracle on the same synthetic weights and documents.  out_gain = 1 is the family of the golden vectors;
+    synth.tame_gain(S) the TAME family whose S-step roll-out stays inside (-1, 1), so the long-loop tests can assert on
+    the un-clamped, un-averaged x0 of the last step (with the plain family most of its pixels saturate the clamp)."""
+    key = (grid, docs, hyp, out_gain)
     if key in _cache:
         return _cache[key]
     from dvd_amd.engine import Engine
     from oracle import dvd_oracle as O
-    sd = synth.synth_state_dict(grid, SEED_W, blocks=[11])
+    sd = synth.synth_state_dict(grid, SEED_W, blocks=[11], out_gain=out_gain)
     eng = Engine(grid, docs, hyp)
     eng.load_state_dict(sd)
     orc = O.Oracle(sd, grid)
@@ -124,17 +127,25 @@ def test_sampling_loop_vs_reference_golden(grid, steps):
     assert err < 2.7e-4, (err, per_step)   # measured 6.5e-5 .. 9.0e-5 (x3); north_star's bar is 1e-3
 
 
-@pytest.mark.parametrize("grid,steps,hyp", [(16, 50, 2), (32, 50, 2), (96, 50, 1), (72, 25, 1)])
-def test_long_loop_vs_oracle(grid, steps, hyp):
+def _saturated(x):
+    return float((x.abs() >= 1).float().mean())
+
+
+@pytest.mark.parametrize("grid,steps,hyp,family", [(16, 50, 2, "plain"), (16, 50, 2, "tame"), (32, 50, 2, "tame"),
+                                                   (96, 50, 1, "tame"), (72, 25, 1, "tame")])
+def test_long_loop_vs_oracle(grid, steps, hyp, family):
     """BASELINE's 50-step DDIM (not reference-runnable natively: local.py has 3 steps) against the CPU oracle.
     G = 96 is an UP-sampling, non-native grid like BASELINE's 288 (feat 64 -> G, T % 64 == 0: the LDS-DMA attention
     kernels, warped-feat branch live from step 2); G = 72 is ragged (T = 1296, T % 64 = 16: the register-staged
     attention fallback and the GEMM edge tiles).  The two large grids run one hypothesis (and the ragged one 25 steps) to
     keep the oracle - which dominates this suite's run time - inside the driver's time limit; the whole 50-step loop at
-    G = 288 is recorded once per round in profiles/ (tests/tools/parity_g288.py)."""
+    G = 288 is recorded once per round in profiles/ (tests/tools/parity_g288.py).
+    The bar of 1e-3 is asserted on the UN-CLAMPED, UN-AVERAGED x0 of the last step; on the tame family (every pixel
+    inside (-1, 1), like a trained model's coordinates) no error hides behind the final clamp."""
     from dvd_amd import sampler, schedule
     from oracle import dvd_oracle as O
-    eng, orc, doc_t, inv1 = setup(grid, 1, hyp)
+    gain = synth.tame_gain(steps) if family == "tame" else 1.0
+    eng, orc, doc_t, inv1 = setup(grid, 1, hyp, gain)
     tab = schedule.Tables(schedule.named_betas("cosine", steps))
     xT = torch.from_numpy(synth.synth_noise(0, hyp, grid, SEED_IN))
     tr_ref, tr = [], []
@@ -142,30 +153,63 @@ def test_long_loop_vs_oracle(grid, steps, hyp):
     out = sampler.sample(eng, tab, xT.cuda(), trace=tr)
     per = [float((a.cpu() - b).pow(2).mean().sqrt()) for a, b in zip(tr, tr_ref)]
     err = float((out.cpu() - ref).pow(2).mean().sqrt())
-    print("long loop rmse", grid, steps, hyp, err, "per-step[::7]", per[::7], "last", per[-1])
-    assert err < 3.8e-4, (err, per[-1])    # measured 1.2e-4 .. 1.3e-4 at G = 16 / 32 (x3); north_star's bar is 1e-3
-    assert per[-1] < 1e-3, per[-1]          # un-clamped, un-averaged x0 of the last step (measured 5.6e-4 .. 6.0e-4)
+    sat = _saturated(tr_ref[-1])
+    print(f"long loop rmse G={grid} S={steps} H={hyp} {family}: final {err:.2e}, un-clamped last x0 {per[-1]:.2e}, "
+          f"last x0 std {float(tr_ref[-1].std()):.3f}, saturated pixels {sat:.4f}, per-step[::7]", per[::7])
+    if grid >= 66:
+        # large grids dither the weights of the 256-wide GEMMs by default (one GEMM pass); the same loop with the
+        # (hi, lo) split everywhere (2x the GEMM MFMAs, round 2's default) and with plain f16 weights, for the record
+        try:
+            for name, opts in (("split (dither off)", {"dither": 0}), ("plain f16 (no split, no dither)",
+                                                                       {"dither": 0, "split_weights": 0})):
+                for k, v in opts.items():
+                    eng.set_option(k, v)
+                tr2 = []
+                out2 = sampler.sample(eng, tab, xT.cuda(), trace=tr2)
+                per2 = [float((a.cpu() - b).pow(2).mean().sqrt()) for a, b in zip(tr2, tr_ref)]
+                print(f"   {name}: final {float((out2.cpu() - ref).pow(2).mean().sqrt()):.2e}, un-clamped last x0 "
+                      f"{per2[-1]:.2e}, per-step[::7]", per2[::7])
+                if "split_weights" not in opts:
+                    assert per2[-1] < 1e-3, per2[-1]
+        finally:
+            eng.set_option("dither", 1)
+            eng.set_option("split_weights", 1)
+    assert per[-1] < 1e-3, per[-1]          # un-clamped, un-averaged x0 of the last step
+    if family == "tame":
+        assert sat < 0.01, sat              # the family does what it is for
+        assert per[-1] < 3e-4, per[-1]      # PROVISIONAL until measured on MI355X
+    assert err < 3.8e-4, (err, per[-1])
 
 
-def test_ddpm_loop_vs_oracle():
-    """BASELINE config 4 sampler (DDPM ancestral, FIXED_LARGE) at a small size against the oracle."""
+@pytest.mark.parametrize("steps", [25, 250])
+def test_ddpm_loop_vs_oracle(steps):
+    """BASELINE configs[3]'s sampler (DDPM ancestral, FIXED_LARGE variance, fixed noise table) at G = 16 against the
+    oracle, short and at full length: 250 noise-driven steps accumulate the denoiser's error.  Tame family: the bar is
+    asserted on the un-clamped, un-averaged last x0."""
     from dvd_amd import sampler, schedule
     from oracle import dvd_oracle as O
-    grid, steps = 16, 25
-    eng, orc, doc_t, inv1 = setup(grid)
+    grid = 16
+    eng, orc, doc_t, inv1 = setup(grid, 1, 2, synth.tame_gain(steps))
     tab = schedule.Tables(schedule.named_betas("cosine", steps))
     xT = torch.from_numpy(synth.synth_noise(0, 2, grid, SEED_IN))
     noises = {i: torch.from_numpy(synth.synth_noise(0, 2, grid, SEED_IN, step=i)) for i in range(steps)}
-    ref = orc.sample_loop(O.Schedule(steps), xT, {k: v[:1] for k, v in doc_t.items()}, sampler="ddpm", noises=noises)
-    out = sampler.sample(eng, tab, xT.cuda(), sampler="ddpm", noise_fn=lambda i: noises[i].cuda())
+    tr_ref, tr = [], []
+    ref = orc.sample_loop(O.Schedule(steps), xT, {k: v[:1] for k, v in doc_t.items()}, sampler="ddpm", noises=noises,
+                          trace=tr_ref)
+    out = sampler.sample(eng, tab, xT.cuda(), sampler="ddpm", noise_fn=lambda i: noises[i].cuda(), trace=tr)
+    per = [float((a.cpu() - b).pow(2).mean().sqrt()) for a, b in zip(tr, tr_ref)]
     err = float((out.cpu() - ref).pow(2).mean().sqrt())
-    print("ddpm loop rmse", err)
-    assert err < 2.8e-4, err               # measured 9.3e-5 (x3)
+    sat = _saturated(tr_ref[-1])
+    print(f"ddpm loop S={steps}: final {err:.2e}, un-clamped last x0 {per[-1]:.2e}, last x0 std "
+          f"{float(tr_ref[-1].std()):.3f}, saturated pixels {sat:.4f}, per-step[::25]", per[::25])
+    assert sat < 0.01, sat
+    assert per[-1] < 1e-3 and err < 1e-3, (err, per[-1])
+    assert per[-1] < 5e-4, per[-1]          # PROVISIONAL until measured on MI355X
 
 
-def test_ddpm_250_steps_vs_oracle():
-    """BASELINE configs[3]'s sampler at full length: 250 ancestral steps (FIXED_LARGE variance, fixed noise table) at
-    G = 16 against the oracle - the stochastic path accumulates the denoiser's error through 250 noise-driven steps."""
+def test_ddpm_250_steps_plain_family_vs_oracle():
+    """The same 250-step ancestral loop on the PLAIN weight family (x0 grows to |x0| >> 1: most pixels saturate the
+    final clamp, so only the clamped map is comparable with round 2's record)."""
     from dvd_amd import sampler, schedule
     from oracle import dvd_oracle as O
     grid, steps = 16, 250
@@ -179,8 +223,11 @@ def test_ddpm_250_steps_vs_oracle():
     out = sampler.sample(eng, tab, xT.cuda(), sampler="ddpm", noise_fn=lambda i: noises[i].cuda(), trace=tr)
     per = [float((a.cpu() - b).pow(2).mean().sqrt()) for a, b in zip(tr, tr_ref)]
     err = float((out.cpu() - ref).pow(2).mean().sqrt())
-    print("ddpm 250 loop rmse", err, "per-step[::25]", per[::25], "last", per[-1])
+    rel_last = per[-1] / float(tr_ref[-1].std())
+    print(f"ddpm 250 (plain family): final {err:.2e}, un-clamped last x0 {per[-1]:.2e} on std {float(tr_ref[-1].std()):.2f} "
+          f"(relative {rel_last:.2e}), saturated pixels {_saturated(tr_ref[-1]):.3f}")
     assert err < 1e-3, (err, per[-1])
+    assert rel_last < 1e-3, rel_last
 
 
 def test_batched_documents_match_single():
@@ -223,3 +270,56 @@ def test_graph_replay_equals_eager():
         eng.set_option("graphs", 1)
     for r in runs:
         assert torch.equal(r, eager)
+
+
+def test_engine_at_the_baseline_grid_vs_oracle():
+    """G = 288 (BASELINE configs[1]-[4]) under -m gpu: Engine(288, 2 documents, 2 hypotheses).  (a) the first loop step
+    (t_model > 600: init_feat <- feat) and an evaluation on the warped-feature branch (feat_mode 2, init_flow = the
+    first step's x0) of document 0 / hypothesis 0 against the CPU oracle, coordinate RMSE < 1e-3; (b) the two documents
+    batched give the same bits as each document alone (no cross-document arithmetic at the production size)."""
+    from dvd_amd import sampler, schedule
+    from dvd_amd.engine import Engine
+    from oracle import dvd_oracle as O
+    torch.set_num_threads(min(os.cpu_count() or 1, 32))
+    G, S = 288, 50
+    sd = synth.synth_state_dict(G, SEED_W, blocks=[11])
+    keys = ("y512", "mask_cat", "mask_y512", "line_msk")
+    ds = [synth.synth_document(d, G, SEED_IN) for d in range(2)]
+    doc_t = {k: torch.from_numpy(np.stack([d[k] for d in ds])) for k in keys}
+    xT = torch.from_numpy(np.concatenate([synth.synth_noise(d, 2, G, SEED_IN) for d in range(2)]))
+    tab = schedule.Tables(schedule.named_betas("cosine", S))
+    both = Engine(G, 2, 2)
+    both.load_state_dict(sd)
+    both.prepare(*[doc_t[k].cuda() for k in keys])
+    t_first = tab.model_time(S - 1)
+    i_mid = max(i for i in range(S) if tab.model_time(i) <= 600.0)
+    t_mid = tab.model_time(i_mid)
+    zeros = torch.zeros(4, 2, G, G, device="cuda")
+    x0_first = both.denoise(xT.cuda(), schedule.embedded_time(t_first), sampler.feat_mode_for(t_first, 4, True), zeros,
+                            dither_step=0).clone()
+    x0_mid = both.denoise(xT.cuda(), schedule.embedded_time(t_mid), 2, x0_first, dither_step=1).clone()
+    # (b) batch == single, bit for bit
+    one = Engine(G, 1, 2)
+    one.bind_blob(both.blob)
+    for d in range(2):
+        one.prepare(*[doc_t[k][d:d + 1].cuda() for k in keys])
+        a = one.denoise(xT[2 * d:2 * d + 2].cuda(), schedule.embedded_time(t_first), sampler.feat_mode_for(t_first, 2, True),
+                        zeros[:2], dither_step=0).clone()
+        b = one.denoise(xT[2 * d:2 * d + 2].cuda(), schedule.embedded_time(t_mid), 2, x0_first[2 * d:2 * d + 2].contiguous(),
+                        dither_step=1)
+        assert torch.equal(a, x0_first[2 * d:2 * d + 2]), d
+        assert torch.equal(b, x0_mid[2 * d:2 * d + 2]), d
+    del one
+    # (a) against the oracle (document 0, hypothesis 0)
+    orc = O.Oracle(sd, G)
+    with torch.no_grad():
+        inv = orc.prepare(*[doc_t[k][:1] for k in keys])
+        x = xT[:1]
+        ref_first, _ = orc.forward(x, float(t_first), inv, torch.zeros_like(x), inv["feat"])
+        e1 = float((ref_first - x0_first[:1].cpu()).pow(2).mean().sqrt())
+        flow = x0_first[:1].cpu()
+        init_feat = O.grid_sample_ref(inv["feat"], (flow + O.base_grid(G, G)) * 2 - 1)
+        ref_mid, _ = orc.forward(x, float(t_mid), inv, flow, init_feat)
+        e2 = float((ref_mid - x0_mid[:1].cpu()).pow(2).mean().sqrt())
+    print(f"G=288 engine vs oracle: first step {e1:.2e}, warped-feature branch {e2:.2e}")
+    assert e1 < 1.6e-4 and e2 < 1.6e-4, (e1, e2)     # measured 5.2e-5 (x3); north_star's bar is 1e-3

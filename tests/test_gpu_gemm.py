@@ -262,3 +262,76 @@ def test_gemm_f32_narrow_outputs(ops, M, N, K):
     out2 = torch.zeros(M, N, device="cuda")
     ops.gemm_nt(a.cuda(), b.cuda(), out32=out2)
     assert (out2.cpu().double() - (ref - bias.double())).abs().max().item() < 2e-7 * K * 4
+
+
+# ---------------------------------------------------------------------------------------------------------
+# temporal dithering of the f16 weight rounding (dvd_dither_f16)
+# ---------------------------------------------------------------------------------------------------------
+def dither_ref(hi16: np.ndarray, lo16: np.ndarray, elem0: int, step: int) -> np.ndarray:
+    """numpy restatement of dither.hip (integer hash + one correctly rounded fp32 division): bit-exact."""
+    hb = hi16.view(np.uint16).astype(np.uint32).ravel()
+    lb = lo16.view(np.uint16).astype(np.uint32).ravel()
+    with np.errstate(over="ignore"):
+        g = (np.uint32(elem0) + np.arange(hb.size, dtype=np.uint32)).astype(np.uint32)
+        h = (g * np.uint32(0x9E3779B1)).astype(np.uint32)
+        h ^= h >> np.uint32(15)
+        h = (h * np.uint32(0x85EBCA77)).astype(np.uint32)
+        h ^= h >> np.uint32(13)
+        h = (h * np.uint32(0xC2B2AE3D)).astype(np.uint32)
+        h ^= h >> np.uint32(16)
+        u = (h + np.uint32((step * 0x9E3779B9) & 0xFFFFFFFF)).astype(np.uint32)
+    lo_zero = (lb & 0x7FFF) == 0
+    hi_zero = (hb & 0x7FFF) == 0
+    opposite = ((hb ^ lb) & 0x8000) != 0
+    nb = np.where(hi_zero, (lb & 0x8000) | 1, np.where(opposite, hb - 1, hb + 1)) & 0xFFFF
+    is_inf = (nb & 0x7C00) == 0x7C00
+    f = lambda b: b.astype(np.uint16).view(np.float16).astype(np.float32)  # noqa: E731
+    hf, lf, nf = f(hb), f(lb), f(nb)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        frac = np.abs(lf) / np.abs(nf - hf)
+    frac = np.minimum(np.nan_to_num(frac, nan=0.0, posinf=0.99999994), np.float32(0.99999994)).astype(np.float32)
+    thr = (frac * np.float32(4294967296.0)).astype(np.uint64).astype(np.uint32)
+    out = np.where(lo_zero | is_inf, hb, np.where(u < thr, nb, hb))
+    return out.astype(np.uint16).view(np.float16).reshape(hi16.shape)
+
+
+@pytest.mark.parametrize("family", ["weights", "tiny", "edge"])
+def test_dither_bit_exact_vs_numpy(family):
+    from dvd_amd import ops
+    n = 1 << 16
+    if family == "weights":
+        w = synth.uniform("dith/w", (n,), -0.05, 0.05, 3)
+    elif family == "tiny":                                 # subnormal f16 range and exact zeros
+        w = synth.uniform("dith/t", (n,), -1e-6, 1e-6, 3)
+        w[::7] = 0.0
+    else:                                                  # powers of two (the gap halves below), exact f16 values, large
+        w = synth.uniform("dith/e", (n,), -4.0, 4.0, 3)
+        w[::5] = np.float32(0.5) - np.float32(1e-5)
+        w[1::5] = np.float16(0.3).astype(np.float32)
+        w[2::5] = -np.float32(2.0) + np.float32(3e-4)
+    hi = w.astype(np.float16)
+    lo = (w - hi.astype(np.float32)).astype(np.float16)
+    for step, elem0 in ((0, 0), (1, 0), (17, 123456), (49, 4096)):
+        got = ops.dither_f16(torch.from_numpy(hi).cuda(), torch.from_numpy(lo).cuda(), step, elem0).cpu().numpy()
+        want = dither_ref(hi, lo, elem0, step)
+        assert np.array_equal(got.view(np.uint16), want.view(np.uint16)), (family, step, elem0)
+
+
+def test_dither_mean_converges_to_the_weight():
+    """The point of the dithering: the mean of the re-rounded weight over S consecutive steps approaches hi + lo like
+    log(S)/S, where the fixed rounding (hi alone) keeps its full error at every step."""
+    from dvd_amd import ops
+    n = 1 << 16
+    w = synth.uniform("dith/m", (n,), -0.05, 0.05, 5)
+    hi = w.astype(np.float16)
+    lo = (w - hi.astype(np.float32)).astype(np.float16)
+    target = hi.astype(np.float64) + lo.astype(np.float64)
+    h, l = torch.from_numpy(hi).cuda(), torch.from_numpy(lo).cuda()
+    fixed = float(np.sqrt(np.mean((hi.astype(np.float64) - target) ** 2)))
+    for S, factor in ((10, 4.0), (50, 15.0), (250, 60.0)):
+        acc = torch.zeros(n, dtype=torch.float64, device="cuda")
+        for s in range(S):
+            acc += ops.dither_f16(h, l, s).double()
+        err = float(np.sqrt(np.mean((acc.cpu().numpy() / S - target) ** 2)))
+        print(f"dither mean over {S} steps: rms error {err:.3e} vs fixed rounding {fixed:.3e} ({fixed / err:.1f}x)")
+        assert err * factor < fixed, (S, err, fixed)
