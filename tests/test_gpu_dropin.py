@@ -183,7 +183,7 @@ def test_plugin_run_from_checkpoint_files(tmp_path, monkeypatch):
     torch.manual_seed(0)
     want = val_TDiff.run(s)            # no files: synthetic weights (denoiser seed 7, nets seeds 11 / 13 / 22) in memory
 
-    os.makedirs("checkpoints")
+    os.makedirs("checkpoints", exist_ok=True)
     torch.save({"model." + k: v for k, v in tt(synth.synth_convnet_state_dict("u2netp", 11)).items()}, "checkpoints/seg.pth")
     torch.save({"model": tt(synth.synth_convnet_state_dict("unet", 13))}, "checkpoints/line_model2.pth")
     torch.save({"model": tt(synth.synth_convnet_state_dict("u2netp", 22, prefix="msk."))}, "checkpoints/seg_model.pth")

@@ -177,7 +177,7 @@ def test_long_loop_vs_oracle(grid, steps, hyp, family):
     assert per[-1] < 1e-3, per[-1]          # un-clamped, un-averaged x0 of the last step
     if family == "tame":
         assert sat < 0.01, sat              # the family does what it is for
-        assert per[-1] < 3e-4, per[-1]      # PROVISIONAL until measured on MI355X
+        assert per[-1] < 6e-5, per[-1]      # measured 1.3e-5 .. 2.1e-5 on MI355X (x3), dithered or split alike
     assert err < 3.8e-4, (err, per[-1])
 
 
@@ -204,7 +204,7 @@ def test_ddpm_loop_vs_oracle(steps):
           f"{float(tr_ref[-1].std()):.3f}, saturated pixels {sat:.4f}, per-step[::25]", per[::25])
     assert sat < 0.01, sat
     assert per[-1] < 1e-3 and err < 1e-3, (err, per[-1])
-    assert per[-1] < 5e-4, per[-1]          # PROVISIONAL until measured on MI355X
+    assert per[-1] < 6e-5, per[-1]          # measured 2.1e-5 (25 steps) / 1.1e-5 (250 steps) on MI355X (x3)
 
 
 def test_ddpm_250_steps_plain_family_vs_oracle():
@@ -322,4 +322,6 @@ def test_engine_at_the_baseline_grid_vs_oracle():
         ref_mid, _ = orc.forward(x, float(t_mid), inv, flow, init_feat)
         e2 = float((ref_mid - x0_mid[:1].cpu()).pow(2).mean().sqrt())
     print(f"G=288 engine vs oracle: first step {e1:.2e}, warped-feature branch {e2:.2e}")
-    assert e1 < 1.6e-4 and e2 < 1.6e-4, (e1, e2)     # measured 5.2e-5 (x3); north_star's bar is 1e-3
+    # ONE evaluation sees the whole f16 rounding of the dithered weights (the dither only averages out over steps):
+    # measured 1.05e-4 / 1.25e-4 (5.2e-5 with the split in every GEMM); north_star's bar is 1e-3
+    assert e1 < 3e-4 and e2 < 3e-4, (e1, e2)
