@@ -202,6 +202,212 @@ __global__ void __launch_bounds__(256) grid_sample_rows_kernel(const float* __re
 }
 
 // ---------------------------------------------------------------------------------------
+// Drop-in grid_sample through LDS-staged source tiles (win % 4 == 0, planes < 4 GiB).
+//
+// The direct gathers above issue, per wave instruction, 64 eight-byte loads whose addresses follow the warp: under
+// shear they fall into up to ~45 different source rows, i.e. ~45 L1 line accesses for 512 useful bytes - the address
+// path, not HBM, bounds them (46-50 % of the 8 TB/s figure).  Here a workgroup owns a 32 x 32 OUTPUT tile:
+//   1. every thread reads the grid for its 4 pixels (streaming, row-contiguous) and builds their pair taps;
+//   2. the tile's source footprint - the bounding box of all tap rows / columns - is reduced over the workgroup;
+//   3. the box is copied into LDS with fully coalesced 16-byte loads along source rows (x origin aligned down to 4 px);
+//   4. the taps are gathered from LDS (two adjacent dwords per tap row) and the outputs streamed out.
+// A tile whose box exceeds the LDS budget (shear beyond ~35 degrees, or a wildly non-smooth grid) takes the direct
+// gather for that tile; arithmetic (make_ptaps / blend) is shared with the row kernels, so all paths give the same bits.
+// Workgroup ids are mapped to tiles in XCD BANDS: id % 8 is the XCD the hardware places a workgroup on, and each XCD
+// walks a contiguous row-major range of tiles, so the halo rows / columns neighbouring tiles share are re-read from
+// that XCD's own L2 instead of being fetched over the fabric by eight different L2s.
+// ---------------------------------------------------------------------------------------
+constexpr int LT = 32;            // output tile edge
+constexpr int LP = 64;            // LDS row pitch in floats (16 float4): box width <= 64 px after 4-px alignment
+constexpr int LBH = 56;           // box rows held in LDS:  32 * (1 + 0.7) + 2
+constexpr int LCG = 3;            // planes staged together:  3 * 56 * 64 * 4 B = 43 008 B  ->  3 workgroups per CU
+
+struct PTapsB {
+  int bx, yc0, yc1;               // left tap column (pair base), upper / lower tap row - all clamped in range
+  float a00, a01, a10, a11;
+};
+
+__device__ __forceinline__ PTapsB make_ptaps_box(float gx, float gy, int hin, int win) {
+  // identical arithmetic to make_ptaps (the weights must be the same bits); returns the coordinates un-flattened
+  PTapsB t;
+  const float ix = unnorm(gx, win), iy = unnorm(gy, hin);
+  float fx = floorf(ix), fy = floorf(iy);
+  const float ex = fx + 1.f, ey = fy + 1.f;
+  const float wx0 = ex - ix, wx1 = ix - fx, wy0 = ey - iy, wy1 = iy - fy;
+  fx = fminf(fmaxf(fx, -2.f), (float)win);
+  fy = fminf(fmaxf(fy, -2.f), (float)hin);
+  if (!(ix == ix)) fx = -2.f;
+  if (!(iy == iy)) fy = -2.f;
+  const int x0 = (int)fx, y0 = (int)fy;
+  const int bx = min(max(x0, 0), win - 2);
+  const float cl = (x0 == bx) ? wx0 : ((x0 + 1 == bx) ? wx1 : 0.f);
+  const float cr = (x0 == bx) ? wx1 : ((x0 == bx + 1) ? wx0 : 0.f);
+  const bool y0ok = y0 >= 0 && y0 < hin, y1ok = y0 + 1 >= 0 && y0 + 1 < hin;
+  t.a00 = y0ok ? cl * wy0 : 0.f;
+  t.a01 = y0ok ? cr * wy0 : 0.f;
+  t.a10 = y1ok ? cl * wy1 : 0.f;
+  t.a11 = y1ok ? cr * wy1 : 0.f;
+  if (!(fabsf(ix) < __builtin_inff()) || !(fabsf(iy) < __builtin_inff()))
+    t.a00 = t.a01 = t.a10 = t.a11 = __builtin_nanf("");
+  t.bx = bx;
+  t.yc0 = min(max(y0, 0), hin - 1);
+  t.yc1 = min(max(y0 + 1, 0), hin - 1);
+  return t;
+}
+
+__device__ __forceinline__ float blend_b(f32x2 u, f32x2 d, const PTapsB& t) {
+  return ((u[0] * t.a00 + u[1] * t.a01) + d[0] * t.a10) + d[1] * t.a11;
+}
+
+__device__ __forceinline__ int wave_min(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ int wave_max(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+__device__ __forceinline__ float4 load_f4(const float* base, uint32_t byte_off) {
+  // 16-byte load: wave-uniform base (SGPR pair) + 32-bit lane byte offset
+  return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+
+__device__ __forceinline__ float load_f1_nt(const float* base, uint32_t byte_off) {
+  return __builtin_nontemporal_load(reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off));
+}
+__device__ __forceinline__ void store_f1_nt(float* base, uint32_t byte_off, float v) {
+  __builtin_nontemporal_store(v, reinterpret_cast<float*>(reinterpret_cast<char*>(base) + byte_off));
+}
+
+// every global access below is "wave-uniform 64-bit base (SGPR pair) + 32-bit lane byte offset"
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) grid_sample_lds_kernel(
+    const float* __restrict__ src, const float* __restrict__ grid, float* __restrict__ out, int c, int hin, int win, int h,
+    int w, int src_batch_div, int ntx, int nty, unsigned tiles_total, unsigned tiles_per_xcd) {
+  __shared__ __attribute__((aligned(16))) float box[LCG * LBH * LP];
+  __shared__ int red[4][4];
+  // ---- tile of this workgroup (XCD bands) ----
+  const unsigned seq = blockIdx.x >> 3, xcd = blockIdx.x & 7u;
+  const unsigned tile = xcd * tiles_per_xcd + seq;
+  if (seq >= tiles_per_xcd || tile >= tiles_total) return;                  // workgroup-uniform
+  const unsigned per_img = (unsigned)ntx * (unsigned)nty;
+  const int n = (int)(tile / per_img);
+  const unsigned rem = tile - (unsigned)n * per_img;
+  const int ty = (int)(rem / (unsigned)ntx), tx = (int)(rem - (unsigned)ty * (unsigned)ntx);
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int lx = tid & 31, ly = tid >> 5;                                    // 32 columns x 8 thread rows, 4 px each
+  const int x = tx * LT + lx, y0 = ty * LT + ly * 4;
+  const size_t hw = (size_t)h * w;
+  const size_t plane = (size_t)hin * win;
+  const float* g = grid + (size_t)n * 2 * hw;                               // uniform
+  // byte offset of this thread's pixel k inside one [h, w] plane (grid and output share it); dead pixels are clamped
+  // onto a live one for the loads and skipped at the store
+  uint32_t poff[4];
+  bool live[4];
+  PTapsB t[4];
+  int xmin = win, xmax = 0, ymin = hin, ymax = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    live[k] = x < w && y0 + k < h;
+    poff[k] = ((uint32_t)min(y0 + k, h - 1) * (uint32_t)w + (uint32_t)min(x, w - 1)) * 4u;
+    const float gx = load_f1_nt(g, poff[k]), gy = load_f1_nt(g + hw, poff[k]);
+    t[k] = make_ptaps_box(gx, gy, hin, win);
+    xmin = min(xmin, t[k].bx); xmax = max(xmax, t[k].bx + 1);
+    ymin = min(ymin, t[k].yc0); ymax = max(ymax, t[k].yc1);
+  }
+  xmin = wave_min(xmin); xmax = wave_max(xmax); ymin = wave_min(ymin); ymax = wave_max(ymax);
+  if (lane == 0) { red[wv][0] = xmin; red[wv][1] = xmax; red[wv][2] = ymin; red[wv][3] = ymax; }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    xmin = min(xmin, red[i][0]); xmax = max(xmax, red[i][1]);
+    ymin = min(ymin, red[i][2]); ymax = max(ymax, red[i][3]);
+  }
+  // wave-uniform from here on (SGPRs): the box geometry and every plane base derived from it
+  xmin = __builtin_amdgcn_readfirstlane(xmin); xmax = __builtin_amdgcn_readfirstlane(xmax);
+  ymin = __builtin_amdgcn_readfirstlane(ymin); ymax = __builtin_amdgcn_readfirstlane(ymax);
+  const int x0a = xmin & ~3;                           // 16-byte aligned box origin (win % 4 == 0)
+  const int bw4 = ((xmax - x0a) >> 2) + 1;             // float4 per box row
+  const int bh = ymax - ymin + 1;
+  const bool staged = bw4 * 4 <= LP && bh <= LBH;      // workgroup-uniform
+  const float* s = src + (size_t)(n / src_batch_div) * c * plane;
+  float* o = out + (size_t)n * c * hw;
+
+  if (staged) {
+    // tap positions inside the LDS image (floats), and the copy pattern: thread i moves float4 number i, i + 256, ...
+    // of each plane's [bh][16-float4] image
+    constexpr int ITER = (LBH * (LP / 4) + 255) / 256;                       // 4
+    int l0[4], l1[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      l0[k] = (t[k].yc0 - ymin) * LP + (t[k].bx - x0a);
+      l1[k] = (t[k].yc1 - ymin) * LP + (t[k].bx - x0a);
+    }
+    const int nvec = bh * (LP / 4);
+    uint32_t voff[ITER];
+    bool vok[ITER];
+#pragma unroll
+    for (int it = 0; it < ITER; ++it) {
+      const int idx = tid + 256 * it, row = idx >> 4, c4 = idx & 15;
+      vok[it] = idx < nvec && c4 < bw4;
+      voff[it] = vok[it] ? ((uint32_t)row * (uint32_t)win + 4u * (uint32_t)c4) * 4u : 0u;
+    }
+    const float* s0 = s + (size_t)ymin * win + x0a;                           // uniform
+    for (int ch0 = 0; ch0 < c; ch0 += LCG) {
+      float4 v[LCG][ITER];
+#pragma unroll
+      for (int j = 0; j < LCG; ++j) {
+        const float* pc = s0 + (size_t)min(ch0 + j, c - 1) * plane;           // uniform
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) v[j][it] = load_f4(pc, voff[it]);
+      }
+      if (ch0) __syncthreads();                        // the previous channel group's taps have been read
+#pragma unroll
+      for (int j = 0; j < LCG; ++j)
+#pragma unroll
+        for (int it = 0; it < ITER; ++it)
+          if (vok[it]) *reinterpret_cast<float4*>(&box[j * LBH * LP + (tid + 256 * it) * 4]) = v[j][it];
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < LCG; ++j) {
+        if (ch0 + j >= c) break;
+        float* oc = o + (size_t)(ch0 + j) * hw;                               // uniform
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float* b0 = &box[j * LBH * LP + l0[k]];
+          const float* b1 = &box[j * LBH * LP + l1[k]];
+          const f32x2 u{b0[0], b0[1]}, d{b1[0], b1[1]};
+          if (live[k]) store_f1_nt(oc, poff[k], blend_b(u, d, t[k]));
+        }
+      }
+    }
+  } else {
+    // ---- footprint too large for LDS: direct gather for this tile ----
+    uint32_t g0[4], g1[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      g0[k] = ((uint32_t)t[k].yc0 * (uint32_t)win + (uint32_t)t[k].bx) * 4u;
+      g1[k] = ((uint32_t)t[k].yc1 * (uint32_t)win + (uint32_t)t[k].bx) * 4u;
+    }
+    for (int ch = 0; ch < c; ++ch) {
+      const float* pc = s + (size_t)ch * plane;                               // uniform
+      float* oc = o + (size_t)ch * hw;
+      f32x2 u[4], d[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        u[k] = load_pair(pc, g0[k]);
+        d[k] = load_pair(pc, g1[k]);
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (live[k]) store_f1_nt(oc, poff[k], blend_b(u[k], d[k], t[k]));
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------
 // Fused unwarp tail.  grid(i,j) is computed on the fly from the coarse flow (L2-resident:
 // 2*G*G floats), so HBM traffic is src taps + output only.
 // ---------------------------------------------------------------------------------------
@@ -449,6 +655,16 @@ static bool scalar_warp() {
   return false;
 #endif
 }
+// drop-in grid_sample: 0 = shape-chosen kernel (product), 1 = skip the LDS-tile kernel (row kernel), 2 = scalar kernel
+static int warp_variant() {
+#ifdef DVD_LAB
+  if (scalar_warp()) return 2;
+  const char* e = getenv("DVD_WARP_NOLDS");
+  return (e && e[0] == '1') ? 1 : 0;
+#else
+  return 0;
+#endif
+}
 
 extern "C" int dvd_grid_sample_bilinear_zeros_ac(const float* src, const float* grid, float* out, int n, int c,
                                                  int hin, int win, int h, int w, int src_batch_div, void* stream) {
@@ -458,7 +674,19 @@ extern "C" int dvd_grid_sample_bilinear_zeros_ac(const float* src, const float* 
   if (n == 0) return DVD_OK;
   DVD_REQUIRE(h <= 65535 && n <= 65535, "grid_sample: h or n exceeds the 65535 grid limit");
   DVD_REQUIRE(cdiv(h, 4) <= 65535, "grid_sample: h too large");
-  if (win >= 2 && (size_t)hin * win * 4 < (1ull << 32) && (size_t)w * 4 < (1ull << 32) && !scalar_warp()) {
+  const bool planes32 = (size_t)hin * win * 4 < (1ull << 32) && (size_t)w * 4 < (1ull << 32);
+  const bool out32 = (size_t)h * w * 4 < (1ull << 32);
+  // LDS-staged tiles: 16-byte row loads need win % 4 == 0 and a 16-byte aligned source; chosen from the SHAPE only
+  if (win >= 4 && win % 4 == 0 && ((uintptr_t)src % 16) == 0 && planes32 && out32 && warp_variant() == 0) {
+    const int ntx = cdiv(w, LT), nty = cdiv(h, LT);
+    const size_t total = (size_t)ntx * nty * n;
+    DVD_REQUIRE(total < (1ull << 31) - 8, "grid_sample: too many tiles");
+    const unsigned per_xcd = (unsigned)((total + 7) / 8);
+    grid_sample_lds_kernel<<<per_xcd * 8u, 256, 0, (hipStream_t)stream>>>(src, grid, out, c, hin, win, h, w, src_batch_div,
+                                                                         ntx, nty, (unsigned)total, per_xcd);
+    return check_launch("grid_sample(lds)");
+  }
+  if (win >= 2 && planes32 && warp_variant() != 2) {
     dim3 grd(cdiv(w, 64), cdiv(h, 4 * KR), n);
     grid_sample_rows_kernel<<<grd, 256, 0, (hipStream_t)stream>>>(src, grid, out, c, hin, win, h, w, src_batch_div);
     return check_launch("grid_sample");

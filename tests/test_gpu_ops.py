@@ -171,10 +171,63 @@ def test_unwarp_full_size_fast_equals_fallback(ops, lab):
     assert torch.equal(u_fast, u_slow)
     srcf = src8.permute(2, 0, 1)[None].float().contiguous()
     grid = ops.unwarp_grid(flow, H, W)
-    g_fast, g_slow = _both_paths(lambda: ops.grid_sample(srcf, grid))
-    assert torch.equal(g_fast, g_slow)
+    g_fast, g_rows, g_slow = _three_paths(lambda: ops.grid_sample(srcf, grid))
+    assert torch.equal(g_fast, g_slow) and torch.equal(g_fast, g_rows)
     f_fast = ops.unwarp_f32(flow, srcf)
     assert torch.equal(f_fast.permute(2, 0, 1)[None], g_fast)    # fused tail == materialised grid + drop-in
+
+
+def _three_paths(fn):
+    """Drop-in grid_sample: the LDS-tile kernel (product choice when win % 4 == 0), the row kernel (DVD_WARP_NOLDS=1) and
+    the scalar kernel (DVD_WARP_SCALAR=1) - switches of the LAB build only."""
+    outs = []
+    for env in ({}, {"DVD_WARP_NOLDS": "1"}, {"DVD_WARP_SCALAR": "1"}):
+        for k in ("DVD_WARP_NOLDS", "DVD_WARP_SCALAR"):
+            os.environ.pop(k, None)
+        os.environ.update(env)
+        try:
+            outs.append(fn())
+        finally:
+            for k in env:
+                os.environ.pop(k, None)
+    return outs
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 40, 52, 41, 129), (1, 7, 64, 4, 5, 200), (3, 1, 33, 64, 70, 33), (1, 4, 96, 128, 97, 131),
+                                   (1, 2, 300, 260, 64, 64)])
+@pytest.mark.parametrize("kind", ["smooth", "wild"])
+def test_grid_sample_lds_tiles_equal_row_and_scalar_kernels(ops, lab, shape, kind):
+    """The LDS-staged tile kernel (source footprint of a 32x32 output tile copied with coalesced row loads, taps gathered
+    from LDS) gives the same bits as the direct-gather kernels and matches the oracle: 'smooth' grids (every tile staged:
+    identity + sheared sinusoid reaching outside the image on all sides -> zero padding, clamped box edges), 'wild'
+    uniform-random grids (footprint = whole image: large images take the per-tile direct fallback, small ones still
+    stage), with non-finite coordinates, more than 3 channels (several staging rounds) and batched sources."""
+    from oracle import dvd_oracle as O
+    n, c, hin, win, h, w = shape
+    src = torch.from_numpy(synth.uniform("gsl/src", (n, c, hin, win), -1, 1, 5))
+    if kind == "smooth":
+        ys, xs = torch.meshgrid(torch.linspace(-1.1, 1.1, h), torch.linspace(-1.1, 1.1, w), indexing="ij")
+        gx = xs + 0.25 * ys + 0.05 * torch.sin(7 * ys)
+        gy = ys - 0.3 * xs + 0.05 * torch.cos(5 * xs)
+        grid = torch.stack([gx, gy])[None].repeat(n, 1, 1, 1).contiguous()
+    else:
+        grid = torch.from_numpy(synth.uniform("gsl/grid", (n, 2, h, w), -1.4, 1.4, 5))
+        flat = grid.view(-1)
+        flat[0], flat[1], flat[2], flat[3], flat[4], flat[5] = 1.0, -1.0, 1e30, float("inf"), -1e30, float("nan")
+    ref = O.grid_sample_ref(src, grid).numpy()
+    lds, rows, scalar = _three_paths(lambda: ops.grid_sample(src.cuda(), grid.cuda()).cpu().numpy())
+    assert np.array_equal(lds, rows, equal_nan=True) and np.array_equal(lds, scalar, equal_nan=True)
+    assert np.array_equal(np.isnan(lds), np.isnan(ref))
+    np.testing.assert_allclose(lds, ref, rtol=0, atol=2e-6, equal_nan=True)
+
+
+def test_grid_sample_lds_tiles_shared_source_and_batch(ops, lab):
+    """src_batch_div (hypotheses sharing one source) and several images per launch through the XCD-banded tile order."""
+    src = torch.from_numpy(synth.uniform("gsl/src2", (2, 3, 48, 64), -1, 1, 6))
+    grid = torch.from_numpy(synth.uniform("gsl/grid2", (6, 2, 50, 70), -1.05, 1.05, 6)) * 0.2
+    grid += torch.stack(torch.meshgrid(torch.linspace(-1, 1, 50), torch.linspace(-1, 1, 70), indexing="ij")[::-1])[None]
+    lds, rows, scalar = _three_paths(lambda: ops.grid_sample(src.cuda(), grid.cuda(), src_batch_div=3).cpu().numpy())
+    assert np.array_equal(lds, rows) and np.array_equal(lds, scalar)
 
 
 def test_sched_step_golden(ops):
