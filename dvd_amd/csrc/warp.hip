@@ -206,21 +206,23 @@ __global__ void __launch_bounds__(256) grid_sample_rows_kernel(const float* __re
 //
 // The direct gathers above issue, per wave instruction, 64 eight-byte loads whose addresses follow the warp: under
 // shear they fall into up to ~45 different source rows, i.e. ~45 L1 line accesses for 512 useful bytes - the address
-// path, not HBM, bounds them (46-50 % of the 8 TB/s figure).  Here a workgroup owns a 32 x 32 OUTPUT tile:
-//   1. every thread reads the grid for its 4 pixels (streaming, row-contiguous) and builds their pair taps;
+// path, not HBM, bounds them (46-50 % of the 8 TB/s figure).  Here a workgroup owns a 32 x 16 OUTPUT tile:
+//   1. every thread reads the grid for its 2 pixels (streaming, row-contiguous) and builds their pair taps;
 //   2. the tile's source footprint - the bounding box of all tap rows / columns - is reduced over the workgroup;
 //   3. the box is copied into LDS with fully coalesced 16-byte loads along source rows (x origin aligned down to 4 px);
 //   4. the taps are gathered from LDS (two adjacent dwords per tap row) and the outputs streamed out.
-// A tile whose box exceeds the LDS budget (shear beyond ~35 degrees, or a wildly non-smooth grid) takes the direct
+// A tile whose box exceeds the LDS budget (2048 px per plane: shear beyond ~35 degrees at unit scale, or a wildly
+// non-smooth grid) takes the direct
 // gather for that tile; arithmetic (make_ptaps / blend) is shared with the row kernels, so all paths give the same bits.
 // Workgroup ids are mapped to tiles in XCD BANDS: id % 8 is the XCD the hardware places a workgroup on, and each XCD
 // walks a contiguous row-major range of tiles, so the halo rows / columns neighbouring tiles share are re-read from
 // that XCD's own L2 instead of being fetched over the fabric by eight different L2s.
 // ---------------------------------------------------------------------------------------
-constexpr int LT = 32;            // output tile edge
-constexpr int LP = 64;            // LDS row pitch in floats (16 float4): box width <= 64 px after 4-px alignment
-constexpr int LBH = 56;           // box rows held in LDS:  32 * (1 + 0.7) + 2
-constexpr int LCG = 3;            // planes staged together:  3 * 56 * 64 * 4 B = 43 008 B  ->  3 workgroups per CU
+constexpr int LTW = 32;             // output tile: 32 x (8 * LPX) pixels, 256 threads x LPX vertically adjacent pixels
+constexpr int LCG = 3;              // planes staged together
+// product shape: LPX = 2 (32 x 16 tile), LCAP = 2048 floats per plane held in LDS (rows x 4-px-aligned width of the
+// footprint, stored compactly):  3 * 2048 * 4 B = 24 KiB  ->  6 workgroups (24 waves) per CU
+constexpr int LPX_P = 2, LCAP_P = 2048;
 
 struct PTapsB {
   int bx, yc0, yc1;               // left tap column (pair base), upper / lower tap row - all clamped in range
@@ -283,10 +285,11 @@ __device__ __forceinline__ void store_f1_nt(float* base, uint32_t byte_off, floa
 }
 
 // every global access below is "wave-uniform 64-bit base (SGPR pair) + 32-bit lane byte offset"
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) grid_sample_lds_kernel(
+template <int LPX, int LCAP>
+__global__ void __launch_bounds__(256) grid_sample_lds_kernel(
     const float* __restrict__ src, const float* __restrict__ grid, float* __restrict__ out, int c, int hin, int win, int h,
     int w, int src_batch_div, int ntx, int nty, unsigned tiles_total, unsigned tiles_per_xcd) {
-  __shared__ __attribute__((aligned(16))) float box[LCG * LBH * LP];
+  __shared__ __attribute__((aligned(16))) float box[LCG * LCAP];
   __shared__ int red[4][4];
   // ---- tile of this workgroup (XCD bands) ----
   const unsigned seq = blockIdx.x >> 3, xcd = blockIdx.x & 7u;
@@ -297,19 +300,20 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
   const unsigned rem = tile - (unsigned)n * per_img;
   const int ty = (int)(rem / (unsigned)ntx), tx = (int)(rem - (unsigned)ty * (unsigned)ntx);
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int lx = tid & 31, ly = tid >> 5;                                    // 32 columns x 8 thread rows, 4 px each
-  const int x = tx * LT + lx, y0 = ty * LT + ly * 4;
+  const int lx = tid & 31, ly = tid >> 5;                                    // 32 columns x 8 thread rows, 2 px each
+  constexpr int LTH = 8 * LPX;
+  const int x = tx * LTW + lx, y0 = ty * LTH + ly * LPX;
   const size_t hw = (size_t)h * w;
   const size_t plane = (size_t)hin * win;
   const float* g = grid + (size_t)n * 2 * hw;                               // uniform
   // byte offset of this thread's pixel k inside one [h, w] plane (grid and output share it); dead pixels are clamped
   // onto a live one for the loads and skipped at the store
-  uint32_t poff[4];
-  bool live[4];
-  PTapsB t[4];
+  uint32_t poff[LPX];
+  bool live[LPX];
+  PTapsB t[LPX];
   int xmin = win, xmax = 0, ymin = hin, ymax = 0;
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
+  for (int k = 0; k < LPX; ++k) {
     live[k] = x < w && y0 + k < h;
     poff[k] = ((uint32_t)min(y0 + k, h - 1) * (uint32_t)w + (uint32_t)min(x, w - 1)) * 4u;
     const float gx = load_f1_nt(g, poff[k]), gy = load_f1_nt(g + hw, poff[k]);
@@ -331,28 +335,31 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
   const int x0a = xmin & ~3;                           // 16-byte aligned box origin (win % 4 == 0)
   const int bw4 = ((xmax - x0a) >> 2) + 1;             // float4 per box row
   const int bh = ymax - ymin + 1;
-  const bool staged = bw4 * 4 <= LP && bh <= LBH;      // workgroup-uniform
+  const int bw = bw4 * 4;                              // LDS row pitch (floats): the box is stored compactly
+  const int nvec = bh * bw4;
+  const bool staged = nvec * 4 <= LCAP && bw4 <= 64;   // workgroup-uniform
   const float* s = src + (size_t)(n / src_batch_div) * c * plane;
   float* o = out + (size_t)n * c * hw;
 
   if (staged) {
-    // tap positions inside the LDS image (floats), and the copy pattern: thread i moves float4 number i, i + 256, ...
-    // of each plane's [bh][16-float4] image
-    constexpr int ITER = (LBH * (LP / 4) + 255) / 256;                       // 4
-    int l0[4], l1[4];
+    // tap positions inside the LDS image (floats), and the copy pattern: thread i moves float4 number i, i + 256 of
+    // each plane's [bh][bw4] image (row = i / bw4 by an exact reciprocal multiply: i < 512, bw4 <= 64)
+    constexpr int ITER = LCAP / 4 / 256;                                     // 2 (product shape)
+    int l0[LPX], l1[LPX];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      l0[k] = (t[k].yc0 - ymin) * LP + (t[k].bx - x0a);
-      l1[k] = (t[k].yc1 - ymin) * LP + (t[k].bx - x0a);
+    for (int k = 0; k < LPX; ++k) {
+      l0[k] = (t[k].yc0 - ymin) * bw + (t[k].bx - x0a);
+      l1[k] = (t[k].yc1 - ymin) * bw + (t[k].bx - x0a);
     }
-    const int nvec = bh * (LP / 4);
+    const uint32_t inv = (65536u + (uint32_t)bw4 - 1u) / (uint32_t)bw4;      // uniform
     uint32_t voff[ITER];
     bool vok[ITER];
 #pragma unroll
     for (int it = 0; it < ITER; ++it) {
-      const int idx = tid + 256 * it, row = idx >> 4, c4 = idx & 15;
-      vok[it] = idx < nvec && c4 < bw4;
-      voff[it] = vok[it] ? ((uint32_t)row * (uint32_t)win + 4u * (uint32_t)c4) * 4u : 0u;
+      const uint32_t idx = (uint32_t)tid + 256u * it;
+      const uint32_t row = (idx * inv) >> 16, c4 = idx - row * (uint32_t)bw4;
+      vok[it] = (int)idx < nvec;
+      voff[it] = vok[it] ? (row * (uint32_t)win + 4u * c4) * 4u : 0u;
     }
     const float* s0 = s + (size_t)ymin * win + x0a;                           // uniform
     for (int ch0 = 0; ch0 < c; ch0 += LCG) {
@@ -368,16 +375,16 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
       for (int j = 0; j < LCG; ++j)
 #pragma unroll
         for (int it = 0; it < ITER; ++it)
-          if (vok[it]) *reinterpret_cast<float4*>(&box[j * LBH * LP + (tid + 256 * it) * 4]) = v[j][it];
+          if (vok[it]) *reinterpret_cast<float4*>(&box[j * LCAP + (tid + 256 * it) * 4]) = v[j][it];
       __syncthreads();
 #pragma unroll
       for (int j = 0; j < LCG; ++j) {
         if (ch0 + j >= c) break;
         float* oc = o + (size_t)(ch0 + j) * hw;                               // uniform
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const float* b0 = &box[j * LBH * LP + l0[k]];
-          const float* b1 = &box[j * LBH * LP + l1[k]];
+        for (int k = 0; k < LPX; ++k) {
+          const float* b0 = &box[j * LCAP + l0[k]];
+          const float* b1 = &box[j * LCAP + l1[k]];
           const f32x2 u{b0[0], b0[1]}, d{b1[0], b1[1]};
           if (live[k]) store_f1_nt(oc, poff[k], blend_b(u, d, t[k]));
         }
@@ -385,23 +392,23 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))
     }
   } else {
     // ---- footprint too large for LDS: direct gather for this tile ----
-    uint32_t g0[4], g1[4];
+    uint32_t g0[LPX], g1[LPX];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < LPX; ++k) {
       g0[k] = ((uint32_t)t[k].yc0 * (uint32_t)win + (uint32_t)t[k].bx) * 4u;
       g1[k] = ((uint32_t)t[k].yc1 * (uint32_t)win + (uint32_t)t[k].bx) * 4u;
     }
     for (int ch = 0; ch < c; ++ch) {
       const float* pc = s + (size_t)ch * plane;                               // uniform
       float* oc = o + (size_t)ch * hw;
-      f32x2 u[4], d[4];
+      f32x2 u[LPX], d[LPX];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
+      for (int k = 0; k < LPX; ++k) {
         u[k] = load_pair(pc, g0[k]);
         d[k] = load_pair(pc, g1[k]);
       }
 #pragma unroll
-      for (int k = 0; k < 4; ++k)
+      for (int k = 0; k < LPX; ++k)
         if (live[k]) store_f1_nt(oc, poff[k], blend_b(u[k], d[k], t[k]));
     }
   }
@@ -655,6 +662,14 @@ static bool scalar_warp() {
   return false;
 #endif
 }
+static int lds_tile_variant() {     // lab only: 1 = 32 x 32 tiles (4 px per thread, 36 KiB of LDS: 4 workgroups per CU)
+#ifdef DVD_LAB
+  const char* e = getenv("DVD_WARP_LDSVAR");
+  return (e && e[0] == '1') ? 1 : 0;
+#else
+  return 0;
+#endif
+}
 // drop-in grid_sample: 0 = shape-chosen kernel (product), 1 = skip the LDS-tile kernel (row kernel), 2 = scalar kernel
 static int warp_variant() {
 #ifdef DVD_LAB
@@ -678,12 +693,20 @@ extern "C" int dvd_grid_sample_bilinear_zeros_ac(const float* src, const float* 
   const bool out32 = (size_t)h * w * 4 < (1ull << 32);
   // LDS-staged tiles: 16-byte row loads need win % 4 == 0 and a 16-byte aligned source; chosen from the SHAPE only
   if (win >= 4 && win % 4 == 0 && ((uintptr_t)src % 16) == 0 && planes32 && out32 && warp_variant() == 0) {
-    const int ntx = cdiv(w, LT), nty = cdiv(h, LT);
+    const int lpx = lds_tile_variant() ? 4 : LPX_P;
+    const int ntx = cdiv(w, LTW), nty = cdiv(h, 8 * lpx);
     const size_t total = (size_t)ntx * nty * n;
     DVD_REQUIRE(total < (1ull << 31) - 8, "grid_sample: too many tiles");
     const unsigned per_xcd = (unsigned)((total + 7) / 8);
-    grid_sample_lds_kernel<<<per_xcd * 8u, 256, 0, (hipStream_t)stream>>>(src, grid, out, c, hin, win, h, w, src_batch_div,
-                                                                         ntx, nty, (unsigned)total, per_xcd);
+#ifdef DVD_LAB
+    if (lpx == 4) {
+      grid_sample_lds_kernel<4, 3072><<<per_xcd * 8u, 256, 0, (hipStream_t)stream>>>(src, grid, out, c, hin, win, h, w,
+                                                                                     src_batch_div, ntx, nty, (unsigned)total, per_xcd);
+      return check_launch("grid_sample(lds 32x32)");
+    }
+#endif
+    grid_sample_lds_kernel<LPX_P, LCAP_P><<<per_xcd * 8u, 256, 0, (hipStream_t)stream>>>(src, grid, out, c, hin, win, h, w,
+                                                                                         src_batch_div, ntx, nty, (unsigned)total, per_xcd);
     return check_launch("grid_sample(lds)");
   }
   if (win >= 2 && planes32 && warp_variant() != 2) {

@@ -207,6 +207,34 @@ def test_ddpm_loop_vs_oracle(steps):
     assert per[-1] < 6e-5, per[-1]          # measured 2.1e-5 (25 steps) / 1.1e-5 (250 steps) on MI355X (x3)
 
 
+def test_ddpm_250_steps_large_grid_vs_oracle():
+    """BASELINE configs[3] runs its 250 ancestral steps at G = 288, where the weights of the 256-wide GEMMs are
+    dithered: the same sampler at full length on a LARGE-tile grid (G = 72: T = 1296 > 1024 tokens, ragged), one
+    hypothesis, tame family - un-clamped last x0 against the oracle, dithered and split."""
+    from dvd_amd import sampler, schedule
+    from oracle import dvd_oracle as O
+    grid, steps = 72, 250
+    eng, orc, doc_t, inv1 = setup(grid, 1, 1, synth.tame_gain(steps))
+    tab = schedule.Tables(schedule.named_betas("cosine", steps))
+    xT = torch.from_numpy(synth.synth_noise(0, 1, grid, SEED_IN))
+    noises = {i: torch.from_numpy(synth.synth_noise(0, 1, grid, SEED_IN, step=i)) for i in range(steps)}
+    tr_ref = []
+    orc.sample_loop(O.Schedule(steps), xT, {k: v[:1] for k, v in doc_t.items()}, sampler="ddpm", noises=noises, trace=tr_ref)
+    res = {}
+    try:
+        for name, dither in (("dither", 1), ("split", 0)):
+            eng.set_option("dither", dither)
+            tr = []
+            sampler.sample(eng, tab, xT.cuda(), sampler="ddpm", noise_fn=lambda i: noises[i].cuda(), trace=tr)
+            res[name] = float((tr[-1].cpu() - tr_ref[-1]).pow(2).mean().sqrt())
+    finally:
+        eng.set_option("dither", 1)
+    print(f"ddpm 250 at G=72: un-clamped last x0 rmse {res}, last x0 std {float(tr_ref[-1].std()):.3f}, saturated "
+          f"{_saturated(tr_ref[-1]):.4f}")
+    assert _saturated(tr_ref[-1]) < 0.01
+    assert res["dither"] < 1e-3 and res["split"] < 1e-3, res
+
+
 def test_ddpm_250_steps_plain_family_vs_oracle():
     """The same 250-step ancestral loop on the PLAIN weight family (x0 grows to |x0| >> 1: most pixels saturate the
     final clamp, so only the clamped map is comparable with round 2's record)."""
