@@ -7,6 +7,10 @@ import sys
 sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
 import torch  # noqa: E402
 
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _lab  # noqa: E402
+
+LIBSEL = _lab.which()                   # --lab: the lab build (DVD_WARP_NOLDS=1 / DVD_WARP_LDSVAR=1 pick the gather variant)
 from dvd_amd import ops, synth  # noqa: E402
 
 which = sys.argv[1]
@@ -45,4 +49,19 @@ elif which == "unwarp":
         ops.unwarp_f32(flow, srcf)
         ops.unwarp_u8(flow, src8)
         ops.grid_sample(srcf, grid)
+elif which == "gridsample8":             # the bench's roofline_unwarp leg: 8 documents per launch, drop-in f32 contract
+    H, W, G, B = 3508, 2480, 288, 8
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    ctrl = (torch.rand(B, 2, 6, 6, device="cuda", generator=gen) - 0.5) * 0.1
+    flow = torch.nn.functional.interpolate(ctrl, size=(G, G), mode="bicubic", align_corners=True).contiguous()
+    srcf = torch.rand(B, 3, H, W, device="cuda", generator=gen) * 255.0
+    grid = torch.cat([ops.unwarp_grid(flow[d:d + 1].contiguous(), H, W) for d in range(B)])
+    for _ in range(4):
+        ops.grid_sample(srcf, grid)
+elif which == "copy8":                   # the same byte count through torch's copy kernel, for the copy ceiling
+    n = 8 * 32 * 3508 * 2480 // 8
+    a = torch.rand(n, device="cuda")
+    b = torch.empty_like(a)
+    for _ in range(4):
+        b.copy_(a)
 torch.cuda.synchronize()

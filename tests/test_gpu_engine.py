@@ -207,13 +207,15 @@ def test_ddpm_loop_vs_oracle(steps):
     assert per[-1] < 6e-5, per[-1]          # measured 2.1e-5 (25 steps) / 1.1e-5 (250 steps) on MI355X (x3)
 
 
-def test_ddpm_250_steps_large_grid_vs_oracle():
-    """BASELINE configs[3] runs its 250 ancestral steps at G = 288, where the weights of the 256-wide GEMMs are
-    dithered: the same sampler at full length on a LARGE-tile grid (G = 72: T = 1296 > 1024 tokens, ragged), one
-    hypothesis, tame family - un-clamped last x0 against the oracle, dithered and split."""
+def test_ddpm_large_grid_vs_oracle(steps=60):
+    """BASELINE configs[3] runs its ancestral steps at G = 288, where the weights of the 256-wide GEMMs are dithered:
+    the same sampler on a LARGE-tile grid (G = 72: T = 1296 > 1024 tokens, ragged), one hypothesis, tame family -
+    un-clamped last x0 against the oracle, dithered and split.  60 steps here (the oracle costs 2 s per step); the full
+    250 steps are run once per round by tests/tools/ddpm250_large_grid.py (8.5 minutes; profiles/r3_ddpm250_g72.txt:
+    6.5e-6 dithered, 6.2e-6 split)."""
     from dvd_amd import sampler, schedule
     from oracle import dvd_oracle as O
-    grid, steps = 72, 250
+    grid = 72
     eng, orc, doc_t, inv1 = setup(grid, 1, 1, synth.tame_gain(steps))
     tab = schedule.Tables(schedule.named_betas("cosine", steps))
     xT = torch.from_numpy(synth.synth_noise(0, 1, grid, SEED_IN))
@@ -229,10 +231,11 @@ def test_ddpm_250_steps_large_grid_vs_oracle():
             res[name] = float((tr[-1].cpu() - tr_ref[-1]).pow(2).mean().sqrt())
     finally:
         eng.set_option("dither", 1)
-    print(f"ddpm 250 at G=72: un-clamped last x0 rmse {res}, last x0 std {float(tr_ref[-1].std()):.3f}, saturated "
+    print(f"ddpm {steps} steps at G=72: un-clamped last x0 rmse {res}, last x0 std {float(tr_ref[-1].std()):.3f}, saturated "
           f"{_saturated(tr_ref[-1]):.4f}")
     assert _saturated(tr_ref[-1]) < 0.01
-    assert res["dither"] < 1e-3 and res["split"] < 1e-3, res
+    assert res["dither"] < 1e-4 and res["split"] < 1e-4, res     # measured 6.5e-6 / 6.2e-6 at 250 steps
+    return res
 
 
 def test_ddpm_250_steps_plain_family_vs_oracle():
