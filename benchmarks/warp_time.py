@@ -7,9 +7,11 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__))); import _lab; LIB
 import torch
 from dvd_amd import ops
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+AMP = float(sys.argv[2]) if len(sys.argv) > 2 else 0.1          # control-point range: 0.1 = the bench's +-0.05; 0 = identity
+ONLY = sys.argv[3] if len(sys.argv) > 3 else ""                 # "gs": time the drop-in grid_sample only
 H, W, G = 3508, 2480, 288
 gen = torch.Generator(device="cuda").manual_seed(3)
-ctrl = (torch.rand(B, 2, 6, 6, device="cuda", generator=gen) - 0.5) * 0.1
+ctrl = (torch.rand(B, 2, 6, 6, device="cuda", generator=gen) - 0.5) * AMP
 flow = torch.nn.functional.interpolate(ctrl, size=(G, G), mode="bicubic", align_corners=True).contiguous()
 src8 = torch.randint(0, 256, (B, H, W, 3), device="cuda", dtype=torch.uint8, generator=gen)
 srcf = src8.permute(0, 3, 1, 2).float().contiguous()
@@ -26,5 +28,7 @@ lib = LIBSEL
 for name, f, bpp in (("grid_sample f32 (32 B/px)", lambda: ops.grid_sample(srcf, grid), 32),
                      ("unwarp_f32 fused (24 B/px)", lambda: ops.unwarp_f32_batch(flow, srcf), 24),
                      ("unwarp_u8 fused (6 B/px)", lambda: ops.unwarp_u8_batch(flow, src8), 6)):
+    if ONLY == "gs" and not name.startswith("grid_sample"):
+        continue
     ms = t(f)
-    print(f"{name:28s} B={B}: {ms:.3f} ms  {bpp * H * W * B / ms / 1e6:.0f} GB/s   lib={lib}")
+    print(f"{name:28s} B={B}: {ms:.3f} ms  {bpp * H * W * B / ms / 1e6:.0f} GB/s   lib={lib} amp={AMP} var={os.environ.get('DVD_WARP_LDSVAR', '-')} wgs={os.environ.get('DVD_WARP_WGS', '-')} nolds={os.environ.get('DVD_WARP_NOLDS', '-')}")

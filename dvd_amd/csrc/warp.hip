@@ -206,23 +206,32 @@ __global__ void __launch_bounds__(256) grid_sample_rows_kernel(const float* __re
 //
 // The direct gathers above issue, per wave instruction, 64 eight-byte loads whose addresses follow the warp: under
 // shear they fall into up to ~45 different source rows, i.e. ~45 L1 line accesses for 512 useful bytes - the address
-// path, not HBM, bounds them (46-50 % of the 8 TB/s figure).  Here a workgroup owns a 32 x 16 OUTPUT tile:
-//   1. every thread reads the grid for its 2 pixels (streaming, row-contiguous) and builds their pair taps;
+// path, not HBM, bounds them (46-50 % of the 8 TB/s figure).  Here a workgroup owns a 32 x 32 OUTPUT tile:
+//   1. every thread reads the grid for its 4 consecutive pixels (one 16-byte streaming load per plane) and builds
+//      their pair taps;
 //   2. the tile's source footprint - the bounding box of all tap rows / columns - is reduced over the workgroup;
 //   3. the box is copied into LDS with fully coalesced 16-byte loads along source rows (x origin aligned down to 4 px);
 //   4. the taps are gathered from LDS (two adjacent dwords per tap row) and the outputs streamed out.
-// A tile whose box exceeds the LDS budget (2048 px per plane: shear beyond ~35 degrees at unit scale, or a wildly
+// A tile whose box exceeds the LDS budget (2048 px per plane: ~8 % of the tiles of the bench's flow; shear beyond ~35 degrees at unit scale, or a wildly
 // non-smooth grid) takes the direct
 // gather for that tile; arithmetic (make_ptaps / blend) is shared with the row kernels, so all paths give the same bits.
+// Measured on MI355X (8 documents of 3508 x 2480 per launch, the bench's flow; benchmarks/warp_time.py): 4.2-4.4 TB/s
+// against 3.8 for the row kernel and 5.1 for a device copy of the same 2.2 GB - and the same with an identity flow: the
+// gather no longer costs anything, what remains is the streaming rate of eight interleaved planes.  What mattered, in
+// order: 16 bytes per lane on every streaming access (the first version read the grid and wrote the output 4 bytes per
+// lane like the row kernel and ran at 3.0-3.7 TB/s whatever the tile shape), workgroups per CU (cap 2048 / 6 per CU
+// beats cap 3072 / 4 per CU by 3 %), square tiles (64 x 16: -8 %, 128 x 8: -25 %: larger footprints, fewer workgroups);
+// a persistent variant that prefetched the next tile's grid values was slower than one tile per workgroup.
 // Workgroup ids are mapped to tiles in XCD BANDS: id % 8 is the XCD the hardware places a workgroup on, and each XCD
 // walks a contiguous row-major range of tiles, so the halo rows / columns neighbouring tiles share are re-read from
 // that XCD's own L2 instead of being fetched over the fabric by eight different L2s.
 // ---------------------------------------------------------------------------------------
-constexpr int LTW = 32;             // output tile: 32 x (8 * LPX) pixels, 256 threads x LPX vertically adjacent pixels
+constexpr int LTW = 32, LTH = 32;   // output tile: 32 x 32 pixels = 256 threads x 4 CONSECUTIVE x (one 16-byte grid load
+                                    // per plane and one 16-byte store per channel per thread: every streaming access of
+                                    // the kernel is 16 bytes per lane, 8 lanes per 128-byte row segment)
 constexpr int LCG = 3;              // planes staged together
-// product shape: LPX = 2 (32 x 16 tile), LCAP = 2048 floats per plane held in LDS (rows x 4-px-aligned width of the
-// footprint, stored compactly):  3 * 2048 * 4 B = 24 KiB  ->  6 workgroups (24 waves) per CU
-constexpr int LPX_P = 2, LCAP_P = 2048;
+constexpr int LCAP_P = 2048;        // floats per plane held in LDS (rows x 4-px-aligned width of the footprint, compact):
+                                    // 3 * 2048 * 4 B = 24 KiB, 72 VGPRs  ->  6 workgroups (24 waves) per CU
 
 struct PTapsB {
   int bx, yc0, yc1;               // left tap column (pair base), upper / lower tap row - all clamped in range
@@ -284,8 +293,18 @@ __device__ __forceinline__ void store_f1_nt(float* base, uint32_t byte_off, floa
   __builtin_nontemporal_store(v, reinterpret_cast<float*>(reinterpret_cast<char*>(base) + byte_off));
 }
 
-// every global access below is "wave-uniform 64-bit base (SGPR pair) + 32-bit lane byte offset"
-template <int LPX, int LCAP>
+__device__ __forceinline__ float4 load_f4_nt(const float* base, uint32_t byte_off) {
+  typedef float v4 __attribute__((ext_vector_type(4)));
+  const v4 v = __builtin_nontemporal_load(reinterpret_cast<const v4*>(reinterpret_cast<const char*>(base) + byte_off));
+  return make_float4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ void store_f4_nt(float* base, uint32_t byte_off, float4 q) {
+  typedef float v4 __attribute__((ext_vector_type(4)));
+  __builtin_nontemporal_store(v4{q.x, q.y, q.z, q.w}, reinterpret_cast<v4*>(reinterpret_cast<char*>(base) + byte_off));
+}
+
+// every global access below is "wave-uniform 64-bit base (SGPR pair) + 32-bit lane byte offset", 16 bytes per lane
+template <int TW, int LCAP, int NT>
 __global__ void __launch_bounds__(256) grid_sample_lds_kernel(
     const float* __restrict__ src, const float* __restrict__ grid, float* __restrict__ out, int c, int hin, int win, int h,
     int w, int src_batch_div, int ntx, int nty, unsigned tiles_total, unsigned tiles_per_xcd) {
@@ -300,24 +319,22 @@ __global__ void __launch_bounds__(256) grid_sample_lds_kernel(
   const unsigned rem = tile - (unsigned)n * per_img;
   const int ty = (int)(rem / (unsigned)ntx), tx = (int)(rem - (unsigned)ty * (unsigned)ntx);
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int lx = tid & 31, ly = tid >> 5;                                    // 32 columns x 8 thread rows, 2 px each
-  constexpr int LTH = 8 * LPX;
-  const int x = tx * LTW + lx, y0 = ty * LTH + ly * LPX;
+  constexpr int TPR = TW / 4, TH = 256 / TPR;                               // threads per tile row, tile rows
+  const int x = tx * TW + 4 * (tid % TPR), y = ty * TH + (tid / TPR);       // 4 consecutive pixels of one row
   const size_t hw = (size_t)h * w;
   const size_t plane = (size_t)hin * win;
   const float* g = grid + (size_t)n * 2 * hw;                               // uniform
-  // byte offset of this thread's pixel k inside one [h, w] plane (grid and output share it); dead pixels are clamped
-  // onto a live one for the loads and skipped at the store
-  uint32_t poff[LPX];
-  bool live[LPX];
-  PTapsB t[LPX];
+  // byte offset of this thread's 4 pixels inside one [h, w] plane (grid and output share it); a dead thread (beyond the
+  // right / bottom edge: w % 4 == 0, so a thread is live or dead as a whole) is clamped onto live pixels for the loads
+  const bool live = x < w && y < h;
+  const uint32_t poff = ((uint32_t)min(y, h - 1) * (uint32_t)w + (uint32_t)min(x, w - 4)) * 4u;
+  const float4 gx4 = NT ? load_f4_nt(g, poff) : load_f4(g, poff), gy4 = NT ? load_f4_nt(g + hw, poff) : load_f4(g + hw, poff);
+  const float gxs[4] = {gx4.x, gx4.y, gx4.z, gx4.w}, gys[4] = {gy4.x, gy4.y, gy4.z, gy4.w};
+  PTapsB t[4];
   int xmin = win, xmax = 0, ymin = hin, ymax = 0;
 #pragma unroll
-  for (int k = 0; k < LPX; ++k) {
-    live[k] = x < w && y0 + k < h;
-    poff[k] = ((uint32_t)min(y0 + k, h - 1) * (uint32_t)w + (uint32_t)min(x, w - 1)) * 4u;
-    const float gx = load_f1_nt(g, poff[k]), gy = load_f1_nt(g + hw, poff[k]);
-    t[k] = make_ptaps_box(gx, gy, hin, win);
+  for (int k = 0; k < 4; ++k) {
+    t[k] = make_ptaps_box(gxs[k], gys[k], hin, win);
     xmin = min(xmin, t[k].bx); xmax = max(xmax, t[k].bx + 1);
     ymin = min(ymin, t[k].yc0); ymax = max(ymax, t[k].yc1);
   }
@@ -342,12 +359,12 @@ __global__ void __launch_bounds__(256) grid_sample_lds_kernel(
   float* o = out + (size_t)n * c * hw;
 
   if (staged) {
-    // tap positions inside the LDS image (floats), and the copy pattern: thread i moves float4 number i, i + 256 of
-    // each plane's [bh][bw4] image (row = i / bw4 by an exact reciprocal multiply: i < 512, bw4 <= 64)
-    constexpr int ITER = LCAP / 4 / 256;                                     // 2 (product shape)
-    int l0[LPX], l1[LPX];
+    // tap positions inside the LDS image (floats), and the copy pattern: thread i moves float4 number i, i + 256, ... of
+    // each plane's [bh][bw4] image (row = i / bw4 by an exact reciprocal multiply: i < 1024, bw4 <= 64)
+    constexpr int ITER = (LCAP / 4 + 255) / 256;
+    int l0[4], l1[4];
 #pragma unroll
-    for (int k = 0; k < LPX; ++k) {
+    for (int k = 0; k < 4; ++k) {
       l0[k] = (t[k].yc0 - ymin) * bw + (t[k].bx - x0a);
       l1[k] = (t[k].yc1 - ymin) * bw + (t[k].bx - x0a);
     }
@@ -380,36 +397,35 @@ __global__ void __launch_bounds__(256) grid_sample_lds_kernel(
 #pragma unroll
       for (int j = 0; j < LCG; ++j) {
         if (ch0 + j >= c) break;
-        float* oc = o + (size_t)(ch0 + j) * hw;                               // uniform
+        float r[4];
 #pragma unroll
-        for (int k = 0; k < LPX; ++k) {
+        for (int k = 0; k < 4; ++k) {
           const float* b0 = &box[j * LCAP + l0[k]];
           const float* b1 = &box[j * LCAP + l1[k]];
           const f32x2 u{b0[0], b0[1]}, d{b1[0], b1[1]};
-          if (live[k]) store_f1_nt(oc, poff[k], blend_b(u, d, t[k]));
+          r[k] = blend_b(u, d, t[k]);
+        }
+        if (live) {
+          float* oc = o + (size_t)(ch0 + j) * hw;                             // uniform
+          if (NT) store_f4_nt(oc, poff, make_float4(r[0], r[1], r[2], r[3]));
+          else *reinterpret_cast<float4*>(reinterpret_cast<char*>(oc) + poff) = make_float4(r[0], r[1], r[2], r[3]);
         }
       }
     }
   } else {
     // ---- footprint too large for LDS: direct gather for this tile ----
-    uint32_t g0[LPX], g1[LPX];
+    uint32_t g0[4], g1[4];
 #pragma unroll
-    for (int k = 0; k < LPX; ++k) {
+    for (int k = 0; k < 4; ++k) {
       g0[k] = ((uint32_t)t[k].yc0 * (uint32_t)win + (uint32_t)t[k].bx) * 4u;
       g1[k] = ((uint32_t)t[k].yc1 * (uint32_t)win + (uint32_t)t[k].bx) * 4u;
     }
     for (int ch = 0; ch < c; ++ch) {
       const float* pc = s + (size_t)ch * plane;                               // uniform
-      float* oc = o + (size_t)ch * hw;
-      f32x2 u[LPX], d[LPX];
+      float r[4];
 #pragma unroll
-      for (int k = 0; k < LPX; ++k) {
-        u[k] = load_pair(pc, g0[k]);
-        d[k] = load_pair(pc, g1[k]);
-      }
-#pragma unroll
-      for (int k = 0; k < LPX; ++k)
-        if (live[k]) store_f1_nt(oc, poff[k], blend_b(u[k], d[k], t[k]));
+      for (int k = 0; k < 4; ++k) r[k] = blend_b(load_pair(pc, g0[k]), load_pair(pc, g1[k]), t[k]);
+      if (live) store_f4_nt(o + (size_t)ch * hw, poff, make_float4(r[0], r[1], r[2], r[3]));
     }
   }
 }
@@ -662,10 +678,10 @@ static bool scalar_warp() {
   return false;
 #endif
 }
-static int lds_tile_variant() {     // lab only: 1 = 32 x 32 tiles (4 px per thread, 36 KiB of LDS: 4 workgroups per CU)
+static int lds_tile_variant() {     // lab only: 1 = 32 x 32 tiles (4 px per thread, 36 KiB of LDS: 4 workgroups per CU), ...
 #ifdef DVD_LAB
   const char* e = getenv("DVD_WARP_LDSVAR");
-  return (e && e[0] == '1') ? 1 : 0;
+  return e ? atoi(e) : 0;
 #else
   return 0;
 #endif
@@ -692,21 +708,29 @@ extern "C" int dvd_grid_sample_bilinear_zeros_ac(const float* src, const float* 
   const bool planes32 = (size_t)hin * win * 4 < (1ull << 32) && (size_t)w * 4 < (1ull << 32);
   const bool out32 = (size_t)h * w * 4 < (1ull << 32);
   // LDS-staged tiles: 16-byte row loads need win % 4 == 0 and a 16-byte aligned source; chosen from the SHAPE only
-  if (win >= 4 && win % 4 == 0 && ((uintptr_t)src % 16) == 0 && planes32 && out32 && warp_variant() == 0) {
-    const int lpx = lds_tile_variant() ? 4 : LPX_P;
-    const int ntx = cdiv(w, LTW), nty = cdiv(h, 8 * lpx);
-    const size_t total = (size_t)ntx * nty * n;
-    DVD_REQUIRE(total < (1ull << 31) - 8, "grid_sample: too many tiles");
-    const unsigned per_xcd = (unsigned)((total + 7) / 8);
+  if (win >= 4 && win % 4 == 0 && w % 4 == 0 && ((uintptr_t)src % 16) == 0 && ((uintptr_t)grid % 16) == 0 &&
+      ((uintptr_t)out % 16) == 0 && planes32 && out32 && warp_variant() == 0) {
+#define LDS_LAUNCH(TW_, CAP_, NT_)                                                                                    \
+  {                                                                                                                   \
+    const int ntx = cdiv(w, TW_), nty = cdiv(h, 1024 / TW_);                                                          \
+    const size_t total = (size_t)ntx * nty * n;                                                                       \
+    DVD_REQUIRE(total < (1ull << 31) - 8, "grid_sample: too many tiles");                                             \
+    const unsigned per_xcd = (unsigned)((total + 7) / 8);                                                             \
+    grid_sample_lds_kernel<TW_, CAP_, NT_><<<per_xcd * 8u, 256, 0, (hipStream_t)stream>>>(                             \
+        src, grid, out, c, hin, win, h, w, src_batch_div, ntx, nty, (unsigned)total, per_xcd);                        \
+  }
 #ifdef DVD_LAB
-    if (lpx == 4) {
-      grid_sample_lds_kernel<4, 3072><<<per_xcd * 8u, 256, 0, (hipStream_t)stream>>>(src, grid, out, c, hin, win, h, w,
-                                                                                     src_batch_div, ntx, nty, (unsigned)total, per_xcd);
-      return check_launch("grid_sample(lds 32x32)");
+    switch (lds_tile_variant()) {      // lab: tile shapes / LDS budgets / streaming hints that were measured
+      case 1: LDS_LAUNCH(32, 3072, 1) return check_launch("grid_sample(lds 32x32 cap 3072 nt)");
+      case 2: LDS_LAUNCH(32, 3072, 0) return check_launch("grid_sample(lds 32x32 cap 3072)");
+      case 3: LDS_LAUNCH(64, 4096, 0) return check_launch("grid_sample(lds 64x16 cap 4096)");
+      case 4: LDS_LAUNCH(64, 3072, 0) return check_launch("grid_sample(lds 64x16 cap 3072)");
+      case 5: LDS_LAUNCH(128, 4096, 0) return check_launch("grid_sample(lds 128x8 cap 4096)");
+      default: break;
     }
 #endif
-    grid_sample_lds_kernel<LPX_P, LCAP_P><<<per_xcd * 8u, 256, 0, (hipStream_t)stream>>>(src, grid, out, c, hin, win, h, w,
-                                                                                         src_batch_div, ntx, nty, (unsigned)total, per_xcd);
+    LDS_LAUNCH(LTW, LCAP_P, 0)
+#undef LDS_LAUNCH
     return check_launch("grid_sample(lds)");
   }
   if (win >= 2 && planes32 && warp_variant() != 2) {

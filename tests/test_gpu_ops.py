@@ -193,12 +193,12 @@ def _three_paths(fn):
     return outs
 
 
-@pytest.mark.parametrize("shape", [(2, 3, 40, 52, 41, 129), (1, 7, 64, 4, 5, 200), (3, 1, 33, 64, 70, 33), (1, 4, 96, 128, 97, 131),
-                                   (1, 2, 300, 260, 64, 64)])
+@pytest.mark.parametrize("shape", [(2, 3, 40, 52, 41, 128), (1, 7, 64, 4, 5, 200), (3, 1, 33, 64, 70, 36), (1, 4, 96, 128, 97, 132),
+                                   (1, 2, 300, 260, 64, 64), (1, 2, 24, 32, 20, 30)])
 @pytest.mark.parametrize("kind", ["smooth", "wild"])
 def test_grid_sample_lds_tiles_equal_row_and_scalar_kernels(ops, lab, shape, kind):
-    """The LDS-staged tile kernel (source footprint of a 32x32 output tile copied with coalesced row loads, taps gathered
-    from LDS) gives the same bits as the direct-gather kernels and matches the oracle: 'smooth' grids (every tile staged:
+    """The LDS-staged tile kernel (win % 4 == 0 and w % 4 == 0 - the last shape has w = 30 and takes the row kernel: source
+    footprint of a 32x32 output tile copied with coalesced row loads, taps gathered from LDS) gives the same bits as the direct-gather kernels and matches the oracle: 'smooth' grids (every tile staged:
     identity + sheared sinusoid reaching outside the image on all sides -> zero padding, clamped box edges), 'wild'
     uniform-random grids (footprint = whole image: large images take the per-tile direct fallback, small ones still
     stage), with non-finite coordinates, more than 3 channels (several staging rounds) and batched sources."""
@@ -224,8 +224,8 @@ def test_grid_sample_lds_tiles_equal_row_and_scalar_kernels(ops, lab, shape, kin
 def test_grid_sample_lds_tiles_shared_source_and_batch(ops, lab):
     """src_batch_div (hypotheses sharing one source) and several images per launch through the XCD-banded tile order."""
     src = torch.from_numpy(synth.uniform("gsl/src2", (2, 3, 48, 64), -1, 1, 6))
-    grid = torch.from_numpy(synth.uniform("gsl/grid2", (6, 2, 50, 70), -1.05, 1.05, 6)) * 0.2
-    grid += torch.stack(torch.meshgrid(torch.linspace(-1, 1, 50), torch.linspace(-1, 1, 70), indexing="ij")[::-1])[None]
+    grid = torch.from_numpy(synth.uniform("gsl/grid2", (6, 2, 50, 72), -1.05, 1.05, 6)) * 0.2
+    grid += torch.stack(torch.meshgrid(torch.linspace(-1, 1, 50), torch.linspace(-1, 1, 72), indexing="ij")[::-1])[None]
     lds, rows, scalar = _three_paths(lambda: ops.grid_sample(src.cuda(), grid.cuda(), src_batch_div=3).cpu().numpy())
     assert np.array_equal(lds, rows) and np.array_equal(lds, scalar)
 
