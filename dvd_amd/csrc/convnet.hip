@@ -32,18 +32,20 @@ struct ConvNet {
   size_t col_off = 0, col_bytes = 0, need_bytes = 0;
   long weight_floats = 0;
   int in_c, in_h, in_w;
+  int batch = 1;                // images per run: every slot holds [batch * h * w, c] rows (image-major)
 };
 
 static inline size_t al256(size_t b) { return (b + 255) & ~(size_t)255; }
 
-// in: planar [C,H,W] -> out: [H*W, C]
+// in: planar [B,C,H,W] -> out: [B*H*W, C]
 __global__ void __launch_bounds__(256) nchw_to_nhwc_kernel(const float* __restrict__ in, float* __restrict__ out, int c,
-                                                          long hw) {
+                                                          long hw, long total) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= hw * c) return;
+  if (i >= total) return;
   const long p = i / c;
   const int ch = (int)(i - p * c);
-  out[i] = in[(long)ch * hw + p];
+  const long b = p / hw, q = p - b * hw;
+  out[i] = in[(b * c + ch) * hw + q];
 }
 
 // col[p, tap * (ca + cb) + ch] = src(ch)[y + (ky - r) * dil, x + (kx - r) * dil] (zero outside); columns >= ks*ks*(ca+cb)
@@ -56,7 +58,10 @@ __global__ void __launch_bounds__(256) im2col_cat_kernel(const float* __restrict
   const int kq = kp / 4;
   const long p = i / kq;
   const int k0 = (int)(i - p * kq) * 4;
-  const int y = (int)(p / w), x = (int)(p - (long)y * w);
+  const long hw = (long)h * w;
+  const long img0 = (p / hw) * hw;                       // first row of this pixel's image
+  const long pl = p - img0;
+  const int y = (int)(pl / w), x = (int)(pl - (long)y * w);
   const int cc = ca + cb, kreal = ks * ks * cc, r = ks / 2;
   float v[4];
 #pragma unroll
@@ -67,7 +72,7 @@ __global__ void __launch_bounds__(256) im2col_cat_kernel(const float* __restrict
       const int tap = k / cc, ch = k - tap * cc;
       const int yy = y + (tap / ks - r) * dil, xx = x + (tap % ks - r) * dil;
       if (yy >= 0 && yy < h && xx >= 0 && xx < w) {
-        const long q = (long)yy * w + xx;
+        const long q = img0 + (long)yy * w + xx;
         val = ch < ca ? a[q * ca + ch] : b[q * cb + (ch - ca)];
       }
     }
@@ -90,14 +95,17 @@ __global__ void __launch_bounds__(256) conv_f32_narrow_kernel(const float* __res
                                                               const float* __restrict__ b, int cb,
                                                               const float* __restrict__ wgt, int kp,
                                                               const float* __restrict__ bias, float* __restrict__ out,
-                                                              int cout, int ks, int dil, int h, int w, int act) {
+                                                              int cout, int ks, int dil, int h, int w, int act,
+                                                              long rows) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, hh = lane >> 5;
   const long hw = (long)h * w;
-  const long m0 = ((long)blockIdx.x * 4 + wave) * 32;
-  if (m0 >= hw) return;
-  const long pix = min(m0 + r, hw - 1);
-  const int y = (int)(pix / w), x = (int)(pix - (long)y * w);
+  const long m0 = ((long)blockIdx.x * 4 + wave) * 32;     // rows = batch * hw, image-major: a wave may straddle two images
+  if (m0 >= rows) return;
+  const long pix = min(m0 + r, rows - 1);
+  const long img0 = (pix / hw) * hw;
+  const long pl = pix - img0;
+  const int y = (int)(pl / w), x = (int)(pl - (long)y * w);
   const int cc = ca + cb, rad = ks / 2;
   const float* wp[NT];
 #pragma unroll
@@ -112,7 +120,7 @@ __global__ void __launch_bounds__(256) conv_f32_narrow_kernel(const float* __res
   for (int tap = 0; tap < ks * ks; ++tap) {
     const int yy = y + (tap / ks - rad) * dil, xx = x + (tap % ks - rad) * dil;
     const bool ok = yy >= 0 && yy < h && xx >= 0 && xx < w;
-    const long q = ok ? (long)yy * w + xx : 0;
+    const long q = ok ? img0 + (long)yy * w + xx : 0;
     for (int c0 = 0; c0 < cc; c0 += 16, k0 += 16) {
       // channels c0 + 4 hh .. + 3 and c0 + 8 + 4 hh .. + 3 (ca % 8 == 0: a chunk never straddles the two sources)
       const int c1 = c0 + 4 * hh, c2 = c0 + 8 + 4 * hh;
@@ -142,7 +150,7 @@ __global__ void __launch_bounds__(256) conv_f32_narrow_kernel(const float* __res
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       const long row = m0 + (i & 3) + 8 * (i >> 2) + 4 * hh;
-      if (row >= hw) continue;
+      if (row >= rows) continue;
       float v = acc[t][i] + bcol;
       if (act == 2) v = fmaxf(v, 0.f);
       out[row * cout + col] = v;
@@ -157,10 +165,12 @@ __global__ void __launch_bounds__(256) maxpool2_ceil_kernel(const float* __restr
   if (i >= total) return;
   const int ch = (int)(i % c);
   const long p = i / c;
-  const int x = (int)(p % wo), y = (int)(p / wo);
+  const long img = p / ((long)ho * wo), pl = p - img * ((long)ho * wo);
+  const int x = (int)(pl % wo), y = (int)(pl / wo);
   const int y0 = 2 * y, x0 = 2 * x, y1 = min(y0 + 1, h - 1), x1 = min(x0 + 1, w - 1);
-  const float m0 = fmaxf(in[((long)y0 * w + x0) * c + ch], in[((long)y0 * w + x1) * c + ch]);
-  const float m1 = fmaxf(in[((long)y1 * w + x0) * c + ch], in[((long)y1 * w + x1) * c + ch]);
+  const float* s = in + img * (long)h * w * c;
+  const float m0 = fmaxf(s[((long)y0 * w + x0) * c + ch], s[((long)y0 * w + x1) * c + ch]);
+  const float m1 = fmaxf(s[((long)y1 * w + x0) * c + ch], s[((long)y1 * w + x1) * c + ch]);
   out[i] = fmaxf(m0, m1);
 }
 
@@ -186,14 +196,16 @@ __global__ void __launch_bounds__(256) resize_nhwc_kernel(const float* __restric
   if (i >= total) return;
   const int ch = (int)(i % c);
   const long p = i / c;
-  const int x = (int)(p % wout), y = (int)(p / wout);
+  const long img = p / ((long)hout * wout), pl = p - img * ((long)hout * wout);
+  const int x = (int)(pl % wout), y = (int)(pl / wout);
   int y0, y1, x0, x1;
   float ly, lx;
   bil_index(y, hin, hout, align, y0, y1, ly);
   bil_index(x, win, wout, align, x0, x1, lx);
   const float hy = 1.f - ly, hx = 1.f - lx;
-  const float v00 = in[((long)y0 * win + x0) * c + ch], v01 = in[((long)y0 * win + x1) * c + ch];
-  const float v10 = in[((long)y1 * win + x0) * c + ch], v11 = in[((long)y1 * win + x1) * c + ch];
+  const float* s = in + img * (long)hin * win * c;
+  const float v00 = s[((long)y0 * win + x0) * c + ch], v01 = s[((long)y0 * win + x1) * c + ch];
+  const float v10 = s[((long)y1 * win + x0) * c + ch], v11 = s[((long)y1 * win + x1) * c + ch];
   out[i] = hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11);
 }
 
@@ -233,8 +245,10 @@ __global__ void __launch_bounds__(256) mask_mul_kernel(const float* __restrict__
                                                        long hw, float thr) {
   const long i = (long)blockIdx.x * 256 + threadIdx.x;
   if (i >= hw) return;
+  const long img = blockIdx.y;                            // one image per grid row: d0 [N,1,hw], x / out [N,c,hw]
+  d0 += img * hw; x += img * c * hw; out += img * c * hw;
   const float m = d0[i] > thr ? 1.f : 0.f;
-  if (mask_out) mask_out[i] = m;
+  if (mask_out) mask_out[img * hw + i] = m;
   for (int ch = 0; ch < c; ++ch) out[(long)ch * hw + i] = m * x[(long)ch * hw + i];
 }
 
@@ -258,9 +272,18 @@ extern "C" int dvd_nhwc_to_nchw(const float*, float*, int, int, int, void*);
 
 extern "C" int dvd_convnet_create(const dvd_cn_op* ops, int n_ops, int n_slots, int in_c, int in_h, int in_w,
                                   void** handle) {
+  return dvd_convnet_create_batched(ops, n_ops, n_slots, in_c, in_h, in_w, 1, handle);
+}
+
+// `batch` images per run: every activation slot holds the images one after the other ([batch * h * w, c] rows), so each
+// op is ONE launch over the whole batch (a conv's GEMM has M = batch * h * w).  Kernel choices and the split-K factor
+// are functions of the per-image shape only, so an image gives the same bits alone or in a batch.
+extern "C" int dvd_convnet_create_batched(const dvd_cn_op* ops, int n_ops, int n_slots, int in_c, int in_h, int in_w,
+                                          int batch, void** handle) {
   DVD_REQUIRE(ops && handle && n_ops > 0 && n_slots > 1, "convnet_create: bad arguments");
-  DVD_REQUIRE(in_c > 0 && in_h > 0 && in_w > 0, "convnet_create: bad input shape");
+  DVD_REQUIRE(in_c > 0 && in_h > 0 && in_w > 0 && batch > 0 && batch <= 1024, "convnet_create: bad input shape / batch");
   ConvNet* n = new ConvNet();
+  n->batch = batch;
   n->ops.assign(ops, ops + n_ops);
   n->slots.resize(n_slots);
   n->kpad.assign(n_ops, 0);
@@ -270,7 +293,8 @@ extern "C" int dvd_convnet_create(const dvd_cn_op* ops, int n_ops, int n_slots, 
   n->slots[0].h = in_h; n->slots[0].w = in_w; n->slots[0].c = in_c; n->slots[0].set = true;
   size_t off = 0, colmax = 0;
   n->slots[0].off = 0;
-  off = al256((size_t)in_h * in_w * in_c * 4);
+  const size_t nb = (size_t)batch;
+  off = al256(nb * in_h * in_w * in_c * 4);
   long wf = 0;
   auto fail = [&](const char* msg, int i) {
     set_error("convnet_create: op %d: %s", i, msg);
@@ -298,7 +322,7 @@ extern "C" int dvd_convnet_create(const dvd_cn_op* ops, int n_ops, int n_slots, 
         n->kpad[i] = kp;
         if (o.w_off != wf) return fail("weights must be packed in op order (w_off mismatch)", i);
         wf += (long)o.cout * kp + (o.cout + 3) / 4 * 4;   // bias padded to 16 bytes: every conv's weights stay 16-byte aligned
-        colmax = std::max(colmax, (size_t)a.h * a.w * kp * 4);
+        colmax = std::max(colmax, nb * a.h * a.w * kp * 4);
         d.h = a.h; d.w = a.w; d.c = o.cout;
         {
           // Small maps with wide channels (the UNet's deep layers: 324 ... 1296 pixels, K up to 9216) give the 128 x 128
@@ -313,7 +337,7 @@ extern "C" int dvd_convnet_create(const dvd_cn_op* ops, int n_ops, int n_slots, 
               if (units % c == 0 && kp / c >= 128) S = c;
           }
           n->ksplit[i] = S;
-          if (S > 1) partmax = std::max(partmax, (size_t)S * a.h * a.w * o.cout * 4);
+          if (S > 1) partmax = std::max(partmax, nb * S * a.h * a.w * o.cout * 4);
         }
         break;
       }
@@ -340,7 +364,7 @@ extern "C" int dvd_convnet_create(const dvd_cn_op* ops, int n_ops, int n_slots, 
         return fail("unknown op", i);
     }
     d.off = off;
-    off += al256((size_t)d.h * d.w * d.c * 4);
+    off += al256(nb * d.h * d.w * d.c * 4);
     n->slots[o.dst] = d;
   }
   n->col_off = off; n->col_bytes = al256(colmax);
@@ -380,44 +404,47 @@ extern "C" int dvd_convnet_run(void* handle, const float* in_nchw, const float* 
   char* ws = (char*)workspace;
   auto P = [&](int slot) { return (float*)(ws + n->slots[slot].off); };
   float* col = (float*)(ws + n->col_off);
+  const long B = n->batch;
   {
-    const long hw = (long)n->in_h * n->in_w;
-    nchw_to_nhwc_kernel<<<cdiv(hw * n->in_c, 256), 256, 0, st>>>(in_nchw, P(0), n->in_c, hw);
+    const long hw = (long)n->in_h * n->in_w, total = B * hw * n->in_c;
+    nchw_to_nhwc_kernel<<<cdiv(total, 256), 256, 0, st>>>(in_nchw, P(0), n->in_c, hw, total);
   }
   for (size_t i = 0; i < n->ops.size(); ++i) {
     const dvd_cn_op& o = n->ops[i];
     const CnSlot& a = n->slots[o.a];
     const CnSlot& d = n->slots[o.dst];
-    const long nd = (long)d.h * d.w * d.c;
+    const long nd = B * d.h * d.w * d.c;
+    const long rows = B * a.h * a.w;                      // GEMM rows of a conv over slot a
     switch (o.op) {
       case DVD_CN_CONV: {
         const int kp = n->kpad[i];
         const int cb = o.b >= 0 ? n->slots[o.b].c : 0;
         if (o.cout <= 64 && a.c % 8 == 0 && cb % 8 == 0 && (a.c + cb) % 16 == 0 && n->ksplit[i] == 1) {
           // narrow output over 16-aligned channels: implicit GEMM, no im2col matrix
-          const dim3 grd(cdiv((long)a.h * a.w, 128));
+          const dim3 grd(cdiv(rows, 128));
           const float* wgt = weights + o.w_off;
           if (o.cout <= 32)
             conv_f32_narrow_kernel<1><<<grd, 256, 0, st>>>(P(o.a), a.c, o.b >= 0 ? P(o.b) : nullptr, cb, wgt, kp,
                                                            wgt + (long)o.cout * kp, P(o.dst), o.cout, o.ks, o.dil, a.h, a.w,
-                                                           o.act);
+                                                           o.act, rows);
           else
             conv_f32_narrow_kernel<2><<<grd, 256, 0, st>>>(P(o.a), a.c, o.b >= 0 ? P(o.b) : nullptr, cb, wgt, kp,
                                                            wgt + (long)o.cout * kp, P(o.dst), o.cout, o.ks, o.dil, a.h, a.w,
-                                                           o.act);
+                                                           o.act, rows);
           break;
         }
         const float* A = P(o.a);
         int lda = a.c;
         if (!(o.ks == 1 && o.b < 0 && a.c == kp)) {   // a 1x1 conv over a 16-aligned single source reads the slot directly
-          const long total4 = (long)a.h * a.w * (kp / 4);
+          const long total4 = rows * (kp / 4);
           im2col_cat_kernel<<<cdiv(total4, 256), 256, 0, st>>>(P(o.a), a.c, o.b >= 0 ? P(o.b) : nullptr, cb, col, kp,
                                                               o.ks, o.dil, a.h, a.w, total4);
           A = col; lda = kp;
         }
         dvd_gemm_desc g;
         memset(&g, 0, sizeof(g));
-        g.dtype = 1; g.M = a.h * a.w; g.N = o.cout; g.K = kp; g.batch = 1;
+        DVD_REQUIRE(rows < (1l << 31), "convnet_run: batch too large for one GEMM");
+        g.dtype = 1; g.M = (int)rows; g.N = o.cout; g.K = kp; g.batch = 1;
         g.A = A; g.lda = lda; g.B = weights + o.w_off; g.ldb = kp;
         g.C32 = P(o.dst); g.ldc = o.cout;
         g.bias = weights + o.w_off + (long)o.cout * kp; g.act = o.act;
@@ -453,7 +480,10 @@ extern "C" int dvd_convnet_run(void* handle, const float* in_nchw, const float* 
   for (int k = 0; k < n_out; ++k) {
     const int s = out_slots[k];
     DVD_REQUIRE(s >= 0 && s < (int)n->slots.size() && n->slots[s].set && out_nchw[k], "convnet_run: bad output %d", k);
-    if (int e = dvd_nhwc_to_nchw(P(s), out_nchw[k], n->slots[s].c, n->slots[s].h, n->slots[s].w, stream)) return e;
+    const long per = (long)n->slots[s].c * n->slots[s].h * n->slots[s].w;
+    for (long b = 0; b < B; ++b)
+      if (int e = dvd_nhwc_to_nchw(P(s) + b * per, out_nchw[k] + b * per, n->slots[s].c, n->slots[s].h, n->slots[s].w, stream))
+        return e;
   }
   return check_launch("convnet_run");
 }
@@ -471,7 +501,12 @@ extern "C" int dvd_resize_bilinear_nchw(const float* in, float* out, long planes
 
 extern "C" int dvd_threshold_mask_mul(const float* d0, const float* x_nchw, float* out_nchw, float* mask_out, int c,
                                       long hw, float thr, void* stream) {
-  DVD_REQUIRE(d0 && x_nchw && out_nchw && c > 0 && hw > 0, "threshold_mask_mul: bad arguments");
-  mask_mul_kernel<<<cdiv(hw, 256), 256, 0, (hipStream_t)stream>>>(d0, x_nchw, out_nchw, mask_out, c, hw, thr);
+  return dvd_threshold_mask_mul_batch(d0, x_nchw, out_nchw, mask_out, 1, c, hw, thr, stream);
+}
+
+extern "C" int dvd_threshold_mask_mul_batch(const float* d0, const float* x_nchw, float* out_nchw, float* mask_out, int n,
+                                            int c, long hw, float thr, void* stream) {
+  DVD_REQUIRE(d0 && x_nchw && out_nchw && c > 0 && hw > 0 && n > 0 && n <= 65535, "threshold_mask_mul: bad arguments");
+  mask_mul_kernel<<<dim3(cdiv(hw, 256), n), 256, 0, (hipStream_t)stream>>>(d0, x_nchw, out_nchw, mask_out, c, hw, thr);
   return check_launch("threshold_mask_mul");
 }

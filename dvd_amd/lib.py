@@ -111,11 +111,13 @@ SIGNATURES = {
     "dvd_resize_bilinear_nhwc": [c_void, c_void, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_void],
     "dvd_nhwc_to_nchw": [c_void, c_void, C.c_int, C.c_int, C.c_int, c_void],
     "dvd_convnet_create": [C.POINTER(CnOp), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(c_void)],
+    "dvd_convnet_create_batched": [C.POINTER(CnOp), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(c_void)],
     "dvd_convnet_destroy": [c_void],
     "dvd_convnet_slot_shape": [c_void, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)],
     "dvd_convnet_run": [c_void, c_void, c_void, c_void, C.c_long, C.c_int, C.POINTER(C.c_int), C.POINTER(c_void), c_void],
     "dvd_resize_bilinear_nchw": [c_void, c_void, C.c_long, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_void],
     "dvd_threshold_mask_mul": [c_void, c_void, c_void, c_void, C.c_int, C.c_long, C.c_float, c_void],
+    "dvd_threshold_mask_mul_batch": [c_void, c_void, c_void, c_void, C.c_int, C.c_int, C.c_long, C.c_float, c_void],
     "dvd_ingest_u8": [c_void, C.c_int, C.c_int, C.c_int, c_void, C.c_int, c_void, c_void, c_void],
     "dvd_dither_f16": [c_void, c_void, c_void, C.c_long, C.c_uint, C.c_uint, c_void],
     "dvd_engine_create": [C.c_int, C.c_int, C.c_int, C.POINTER(c_void)],

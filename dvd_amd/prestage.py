@@ -213,12 +213,13 @@ def build_unet():
 class ConvNet:
     """One net at one input size on one device: op list -> library handle, workspace, packed weights."""
 
-    def __init__(self, program: Program, outputs, in_hw, device="cuda"):
+    def __init__(self, program: Program, outputs, in_hw, device="cuda", batch: int = 1):
         self.program, self.outputs, self.device = program, list(outputs), torch.device(device)
-        self.in_c, (self.in_h, self.in_w) = program.ch[0], in_hw
+        self.in_c, (self.in_h, self.in_w), self.batch = program.ch[0], in_hw, int(batch)
         ops = program.c_ops()
         h = C.c_void_p()
-        lib.call("dvd_convnet_create", ops, len(program.ops), len(program.ch), self.in_c, self.in_h, self.in_w, C.byref(h))
+        lib.call("dvd_convnet_create_batched", ops, len(program.ops), len(program.ch), self.in_c, self.in_h, self.in_w,
+                 self.batch, C.byref(h))
         self._h = h
         if lib.raw().dvd_convnet_weight_floats(h) != program.w_floats:
             raise lib.DvdError("conv-net weight layout mismatch between the host builder and the library")
@@ -253,7 +254,8 @@ class ConvNet:
         self.bind_weights(self.program.pack(sd).to(self.device))
 
     def run(self, x: torch.Tensor):
-        """x [N, C, H, W] f32 on the device -> list (one per requested output) of [N, c, h, w] tensors."""
+        """x [N, C, H, W] f32 on the device (N = the batch this executor was built for) -> list (one per requested output)
+        of [N, c, h, w] tensors.  ONE pass of the op list for the whole batch."""
         if self.weights is None:
             raise lib.DvdError("conv net has no weights bound")
         from .engine import _is_dev
@@ -262,12 +264,13 @@ class ConvNet:
             raise lib.DvdError(f"conv net expects a contiguous f32 device tensor [N,{self.in_c},{self.in_h},{self.in_w}], "
                                f"got {tuple(x.shape)}")
         n = x.shape[0]
+        if n != self.batch:
+            raise lib.DvdError(f"conv net executor built for a batch of {self.batch}, got {n} images")
         outs = [torch.empty((n, *shp), dtype=torch.float32, device=self.device) for shp in self.shapes]
         slots = (C.c_int * len(self.outputs))(*self.outputs)
-        for i in range(n):
-            ptrs = (C.c_void_p * len(outs))(*[o[i].data_ptr() for o in outs])
-            lib.call("dvd_convnet_run", self._h, ptr(x[i]), ptr(self.weights), C.c_void_p(self._ws), self._ws_bytes,
-                     len(outs), slots, ptrs, stream_ptr())
+        ptrs = (C.c_void_p * len(outs))(*[o.data_ptr() for o in outs])
+        lib.call("dvd_convnet_run", self._h, ptr(x), ptr(self.weights), C.c_void_p(self._ws), self._ws_bytes,
+                 len(outs), slots, ptrs, stream_ptr())
         return outs
 
 
@@ -284,9 +287,7 @@ def threshold_mask_mul(d0: torch.Tensor, x: torch.Tensor, thr: float = 0.5):
     """(d0 > thr).float() * x per sample (geotr_core.py:989-990): d0 [N,1,H,W], x [N,C,H,W] -> (mskx, mask)."""
     n, c, h, w = x.shape
     out, mask = torch.empty_like(x), torch.empty_like(d0)
-    for i in range(n):
-        lib.call("dvd_threshold_mask_mul", ptr(d0[i]), ptr(x[i]), ptr(out[i]), ptr(mask[i]), c, h * w, C.c_float(thr),
-                 stream_ptr())
+    lib.call("dvd_threshold_mask_mul_batch", ptr(d0), ptr(x), ptr(out), ptr(mask), n, c, h * w, C.c_float(thr), stream_ptr())
     return out, mask
 
 
@@ -341,13 +342,16 @@ class _RefNet(nn.Module):
     def bind_blob(self, view_u8: torch.Tensor):
         self._blob, self._blob_version = view_u8.view(torch.float32), self._version
 
-    def _net(self, h, w) -> ConvNet:
+    def _net(self, h, w, batch=1) -> ConvNet:
+        """The executor for (batch, h, w): one per batch size - its activation slots hold all the images of a batch, so the
+        net's ~500 ops are enqueued once per BATCH of documents, not once per document."""
         from .cross_model import _require_gpu
         dev = self.device
         _require_gpu(dev)
-        net = self._nets.get((h, w, dev.index))
+        key = (batch, h, w, dev.index)
+        net = self._nets.get(key)
         if net is None:
-            net = self._nets[(h, w, dev.index)] = ConvNet(self._program, self._outputs, (h, w), device=dev)
+            net = self._nets[key] = ConvNet(self._program, self._outputs, (h, w), device=dev, batch=batch)
             net._bound = -1
         if net._bound != self._version:
             if self._blob is None or self._blob_version != self._version:
@@ -362,7 +366,7 @@ class _RefNet(nn.Module):
 
     def _run(self, x):
         x = x.to(self.device, torch.float32).contiguous()
-        return self._net(x.shape[2], x.shape[3]).run(x)
+        return self._net(x.shape[2], x.shape[3], x.shape[0]).run(x)
 
 
 class U2NETP(_RefNet):

@@ -243,12 +243,17 @@ typedef struct {
 } dvd_cn_op;
 
 int dvd_convnet_create(const dvd_cn_op* ops, int n_ops, int n_slots, int in_c, int in_h, int in_w, void** handle);
+/* The same net for `batch` images per run (the documents of a batch, evaluation.py:162-216 is called per document in the
+ * reference): every op is ONE launch over all images (a conv's GEMM has M = batch * h * w rows).  Kernel choices depend on
+ * the per-image shape only: an image gives the same bits alone or in a batch. */
+int dvd_convnet_create_batched(const dvd_cn_op* ops, int n_ops, int n_slots, int in_c, int in_h, int in_w, int batch,
+                               void** handle);
 int dvd_convnet_destroy(void* handle);
 long dvd_convnet_workspace_bytes(void* handle);
 long dvd_convnet_weight_floats(void* handle);
 int dvd_convnet_slot_shape(void* handle, int slot, int* h, int* w, int* c);
-/* One forward pass: in_nchw [in_c, in_h, in_w] f32 planar; the requested slots are written to out_nchw[k]
- * as planar [c, h, w].  workspace: >= dvd_convnet_workspace_bytes, 256-byte aligned. */
+/* One forward pass: in_nchw [batch, in_c, in_h, in_w] f32 planar (batch = 1 for dvd_convnet_create); the requested slots
+ * are written to out_nchw[k] as planar [batch, c, h, w].  workspace: >= dvd_convnet_workspace_bytes, 256-byte aligned. */
 int dvd_convnet_run(void* handle, const float* in_nchw, const float* weights, void* workspace, long workspace_bytes,
                     int n_out, const int* out_slots, float* const* out_nchw, void* stream);
 /* F.interpolate(mode='bilinear', align_corners=...) on `planes` independent [hin, win] f32 images
@@ -259,6 +264,9 @@ int dvd_resize_bilinear_nchw(const float* in, float* out, long planes, int hin, 
  * mask_out (optional) receives the 0/1 mask. */
 int dvd_threshold_mask_mul(const float* d0, const float* x_nchw, float* out_nchw, float* mask_out, int c, long hw,
                            float thr, void* stream);
+/* the same for n images in one launch: d0 [n, hw], x / out [n, c, hw], mask_out [n, hw] */
+int dvd_threshold_mask_mul_batch(const float* d0, const float* x_nchw, float* out_nchw, float* mask_out, int n, int c,
+                                 long hw, float thr, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Image ingest (datasets/doc_dataset/doc_benchmark.py:75-97 after the decode):

@@ -129,3 +129,31 @@ def test_plugin_run_from_images(tmp_path, monkeypatch):
     assert len(results) == 3
     for path, img in results:
         assert img.dtype == torch.uint8 and tuple(img.shape) == (320, 240, 3)
+
+
+@pytest.mark.parametrize("size", [(288, 288), (70, 50)])
+def test_batched_nets_equal_per_image(models, size):
+    """A batch of images goes through each net's op list ONCE (every conv is one GEMM over batch * H * W rows): every
+    output equals the per-image run bit for bit (kernel choices and the split-K factor depend on the per-image shape only),
+    at the production size and at one whose pooled sizes are odd."""
+    dewarp, seg, line, sds = models
+    imgs = torch.stack([F.interpolate(torch.from_numpy(synth.smooth_image(f"bt/src{i}", 512, 512, 7 + i))[None], size=size,
+                                      mode="bilinear", align_corners=True)[0] for i in range(3)]).cuda()
+    for net in (seg.msk, line):
+        both = net(imgs)
+        for i in range(3):
+            one = net(imgs[i:i + 1].contiguous())
+            for b, o in zip(both, one):
+                assert torch.equal(b[i:i + 1], o)
+
+
+def test_batched_conditioning_equals_per_document(models):
+    """prestage.conditioning for 3 documents at once == each document alone, bit for bit (mask threshold included)."""
+    from dvd_amd import prestage
+    dewarp, seg, line, sds = models
+    src = torch.stack([torch.from_numpy(synth.smooth_image(f"bt/doc{i}", 512, 512, 100 + i)) for i in range(3)]).cuda()
+    both = prestage.conditioning(dewarp, seg, line, src, 16)
+    for i in range(3):
+        one = prestage.conditioning(dewarp, seg, line, src[i:i + 1].contiguous(), 16)
+        for k in ("mask_cat", "mask_y512", "line_msk"):
+            assert torch.equal(both[k][i:i + 1], one[k]), (i, k)
