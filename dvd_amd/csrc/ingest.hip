@@ -6,7 +6,7 @@
 // cv2 (opencv-python, un-pinned in the reference's requirements.txt) is absent from this image, so the resize
 // restates OpenCV's published 8-bit INTER_LINEAR algorithm (imgproc/src/resize.cpp: half-pixel centres, 11-bit
 // fixed-point coefficients rounded to nearest-even, horizontal pass into int32, vertical pass
-// ((b0*(S0>>4))>>16) + ((b1*(S1>>4))>>16) + 2) >> 2).  Integer arithmetic throughout: bit-exact against
+// ((b0*(S0>>4))>>16) + ((b1*(S1>>4))>>16) + 2) >> 2; an exactly-2x downscale takes cv::resize's INTER_AREA switch).  Integer arithmetic throughout: bit-exact against
 // oracle/ingest_oracle.py; parity with a real cv2 build is UNPINNED.
 #include "common.h"
 
@@ -39,6 +39,19 @@ __global__ void __launch_bounds__(256) ingest_resize_kernel(const uint8_t* __res
                                                             int osize) {
   const int dx = blockIdx.x * blockDim.x + threadIdx.x, dy = blockIdx.y;
   if (dx >= osize) return;
+  if (h == 2 * osize && w == 2 * osize) {
+    // exactly 2x in both axes: cv::resize switches INTER_LINEAR to INTER_AREA, whose 8-bit fast path is the rounded
+    // mean of the 2x2 block (resizeAreaFast_: (S00 + S01 + S10 + S11 + 2) >> 2)
+    const uint8_t* r0 = src + ((size_t)(2 * dy) * w + 2 * dx) * 3;
+    const uint8_t* r1 = r0 + (size_t)w * 3;
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+      const int sc = swap_rb ? 2 - ch : ch;
+      const int u = ((int)r0[sc] + (int)r0[3 + sc] + (int)r1[sc] + (int)r1[3 + sc] + 2) >> 2;
+      out[((size_t)ch * osize + dy) * osize + dx] = __fdiv_rn((float)u, 255.f);
+    }
+    return;
+  }
   const ResizeAxis ax = tx[dx], ay = ty[dy];
   const int x0 = ax.s, x1 = min(ax.s + 1, w - 1), y0 = ay.s, y1 = min(ay.s + 1, h - 1);
   const uint8_t* r0 = src + ((size_t)y0 * w) * 3;

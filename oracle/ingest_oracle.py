@@ -25,8 +25,14 @@ def _axis(ssize: int, dsize: int):
 
 
 def cv2_resize_linear_u8(img: np.ndarray, out_size: int) -> np.ndarray:
-    """img [H,W,3] uint8 -> [out,out,3] uint8, OpenCV INTER_LINEAR fixed-point arithmetic."""
+    """img [H,W,3] uint8 -> [out,out,3] uint8, OpenCV INTER_LINEAR fixed-point arithmetic.  cv::resize switches
+    INTER_LINEAR to INTER_AREA when both scale factors are EXACTLY 2 (resize.cpp: `if (interpolation == INTER_LINEAR &&
+    is_area_fast && iscale_x == 2 && iscale_y == 2) interpolation = INTER_AREA`), whose 8-bit fast path is the rounded
+    2x2 mean (S00 + S01 + S10 + S11 + 2) >> 2 (resizeAreaFast_, ResizeAreaFastVec)."""
     h, w, _ = img.shape
+    if h == 2 * out_size and w == 2 * out_size:
+        s = img.astype(np.int32)
+        return ((s[0::2, 0::2] + s[0::2, 1::2] + s[1::2, 0::2] + s[1::2, 1::2] + 2) >> 2).astype(np.uint8)
     sx, ax0, ax1 = _axis(w, out_size)
     sy, ay0, ay1 = _axis(h, out_size)
     x1 = np.minimum(sx + 1, w - 1)

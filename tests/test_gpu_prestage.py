@@ -101,7 +101,7 @@ def test_conditioning_vs_reference_golden(models):
         np.testing.assert_allclose(got["line_msk"][0].cpu().numpy(), g["line_msk"], rtol=0, atol=5e-5)
 
 
-@pytest.mark.parametrize("hw", [(1024, 768), (3508, 2480), (300, 700), (512, 512), (97, 131)])
+@pytest.mark.parametrize("hw", [(1024, 768), (3508, 2480), (300, 700), (512, 512), (97, 131), (1024, 1024)])
 @pytest.mark.parametrize("swap", [False, True])
 def test_ingest_bit_exact_vs_oracle(hw, swap):
     """cv2.resize(INTER_LINEAR, uint8) / 255 restated in integer arithmetic: the kernel equals the oracle bit for bit."""

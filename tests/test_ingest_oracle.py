@@ -25,3 +25,15 @@ def test_ingest_layout_and_channel_swap():
     assert y.shape == (3, 16, 16) and y.dtype == np.float32
     assert np.allclose(y[0], 200 / 255.0) and np.allclose(y[2], 10 / 255.0)
     assert rgb[0, 0, 0] == 200 and rgb[0, 0, 2] == 10
+
+
+def test_exact_2x_downscale_takes_the_area_mean():
+    """cv::resize switches INTER_LINEAR to INTER_AREA when both scales are exactly 2: rounded mean of each 2x2 block."""
+    rng = np.random.RandomState(1)
+    img = rng.randint(0, 256, (64, 64, 3)).astype(np.uint8)
+    out = IO.cv2_resize_linear_u8(img, 32)
+    s = img.astype(np.int32)
+    assert np.array_equal(out, ((s[0::2, 0::2] + s[0::2, 1::2] + s[1::2, 0::2] + s[1::2, 1::2] + 2) >> 2).astype(np.uint8))
+    # one axis at 2x only: the bilinear path (no switch)
+    out2 = IO.cv2_resize_linear_u8(img[:, :48], 32)
+    assert out2.shape == (32, 32, 3)
