@@ -140,6 +140,11 @@ __device__ __forceinline__ void epilogue_tile(const GemmArgs& p, const floatx16&
 // iteration's global store to be acknowledged (~1300 cycles): the epilogue took 23 000 cycles per 256 x 256 tile, a
 // quarter of the kernel, 16 stores x 1300 (s_memtime stamps, identical to the cycle with and without other CUs storing).
 template <int EPI>
+__device__ __forceinline__ void epilogue_readback(const GemmArgs& p, float* stage, int row0, int col0, int lane,
+                                                  float* C32, _Float16* C16, const float* bias, const float* res,
+                                                  const float* gate);
+
+template <int EPI>
 __device__ __forceinline__ void epilogue_block64(const GemmArgs& p, float* stage, const floatx16& t00,
                                                  const floatx16& t01, const floatx16& t10, const floatx16& t11,
                                                  int row0, int col0, int lane, float* C32, _Float16* C16,
@@ -158,6 +163,29 @@ __device__ __forceinline__ void epilogue_block64(const GemmArgs& p, float* stage
     __builtin_amdgcn_s_waitcnt(0xC07F);
     *tmid = __builtin_amdgcn_s_memtime();
   }
+  epilogue_readback<EPI>(p, stage, row0, col0, lane, C32, C16, bias, res, gate);
+}
+
+// The same 64 x 64 block held as 4 x 4 accumulator tiles of v_mfma_f32_16x16x32_f16 (register e of lane l = row
+// 4 (l >> 4) + e, column l & 15 of its tile): staged into the same LDS image, then the shared read-back.
+template <int EPI>
+__device__ __forceinline__ void epilogue_block64_m16(const GemmArgs& p, float* stage, const floatx4 (&t)[8][4], int mt0,
+                                                     int row0, int col0, int lane, float* C32, _Float16* C16,
+                                                     const float* bias, const float* res, const float* gate) {
+  const int c16 = lane & 15, q = lane >> 4;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) stage[(16 * i + 4 * q + e) * 64 + 16 * j + c16] = t[mt0 + i][j][e];
+  epilogue_readback<EPI>(p, stage, row0, col0, lane, C32, C16, bias, res, gate);
+}
+
+template <int EPI>
+__device__ __forceinline__ void epilogue_readback(const GemmArgs& p, float* stage, int row0, int col0, int lane,
+                                                  float* C32, _Float16* C16, const float* bias, const float* res,
+                                                  const float* gate) {
   // same-wave LDS accesses execute in order; the compiler inserts the lgkmcnt wait for the reads below.
   // Read back 8 consecutive columns per lane: 8 rows x 256 B (f32, two 16-B stores) / 128 B (f16, one 16-B store)
   // per wave-instruction (guide T21).
@@ -786,6 +814,141 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_big_kernel(GemmArgs p) {
 
 
 // ================================================================================================
+// The same 256 x 256 x 64 kernel on v_mfma_f32_16x16x32_f16.  Both MFMA shapes do the same FLOPs per cycle, read the
+// same number of fragments per FLOP on this wave tile (12 ds_read_b128 per 32-deep step) and use the same LDS image; but
+// these loops run power-limited (1.3-1.5 GHz of the 2.4 GHz the peak assumes), and the clock the chip holds under a
+// matrix-dense loop depends on the MFMA shape: MI355X_MICROARCH.md 'DVFS give-back' (7) measures the 16x16x32 loop at
+// 1.12-1.15x the FLOP/s of the 32x32x16 loop at equal cycles, operands re-read from LDS included.
+//   A / B fragment of lane l (c = l & 15, q = l >> 4): row c of a 16-row tile, k = 32 s + 8 q .. + 7  ->  16-byte chunk
+//   4 s + q of the 128-byte LDS row, XOR-swizzled by (row >> 1) & 7 like every other reader of this image (a
+//   ds_read_b128 lane group {0-3, 12-15, 20-27} covers rows 0-3 and 12-15 at chunk q0 and rows 4-11 at chunk q0 ^ 1: all
+//   sixteen 16-byte bank slots).  Accumulator register e of lane l = row 4 q + e, column c of its 16 x 16 tile.
+// Plain (un-split) operands only: the engine's dithered weights (one f16 per weight, re-rounded every evaluation).
+// ================================================================================================
+__device__ __forceinline__ floatx4 mfma16_f16(half8 a, half8 b, floatx4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+
+__global__ void __launch_bounds__(512, 2) gemm_nt_big16_kernel(GemmArgs p) {
+  constexpr int BK = 64, TILE = 256 * 128;   // bytes of one operand tile (256 rows x 64 halfs)
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 stages][A | B]
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  const int nwg = p.ntm * p.ntn;
+  const int z = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  for (int vid = blockIdx.x; vid < nwg; vid += gridDim.x) {
+  int tm, tn;
+  tile_coords(vid, p.ntm, p.ntn, tm, tn);
+  tm = __builtin_amdgcn_readfirstlane(tm); tn = __builtin_amdgcn_readfirstlane(tn);
+  const int bm0 = tm * 256, bn0 = tn * 256;
+  const _Float16* A = (const _Float16*)p.A + z * p.sA;
+  const _Float16* B = (const _Float16*)p.B + z * p.sB;
+
+  unsigned aoff[4], boff[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = 8 * (4 * wave + i) + (lane >> 3), pos = lane & 7;
+    const int logical = pos ^ ((row >> 1) & 7);
+    const int ra = min(bm0 + row, p.M - 1) - bm0, rb = min(bn0 + row, p.N - 1) - bn0;
+    aoff[i] = (unsigned)ra * (unsigned)(p.lda * 2) + logical * 16;
+    boff[i] = (unsigned)rb * (unsigned)(p.ldb * 2) + logical * 16;
+  }
+  const char* Atile = (const char*)(A + (size_t)bm0 * p.lda);
+  const char* Btile = (const char*)(B + (size_t)bn0 * p.ldb);
+  const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t)smem;
+
+  const int c16 = lane & 15, q = lane >> 4;
+  int frag[2];
+#pragma unroll
+  for (int s2 = 0; s2 < 2; ++s2) frag[s2] = c16 * 128 + (((4 * s2 + q) ^ ((c16 >> 1) & 7)) * 16);
+  const int a_base = wr * 128 * 128;            // this wave's first A row, bytes
+  const int b_base = TILE + wc * 64 * 128;      // this wave's first B row
+
+  floatx4 acc[8][4];
+#pragma unroll
+  for (int m = 0; m < 8; ++m)
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[m][n][i] = 0.f;
+  const int nk = p.K / BK;
+
+#define BIG_ISSUE(t_, stage_)                                                                      \
+  {                                                                                                \
+    const size_t kb_ = (size_t)(t_) * (BK * 2);                                                    \
+    glds_group4<4>(Atile + kb_, aoff, lds0 + (stage_) * 2 * TILE + (4 * wave) * 1024);             \
+    glds_group4<4>(Btile + kb_, boff, lds0 + (stage_) * 2 * TILE + TILE + (4 * wave) * 1024);      \
+  }
+#define SB() __builtin_amdgcn_sched_barrier(0)
+  BIG_ISSUE(0, 0)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int cur = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    // waves 0-3 (one per SIMD) issue their burst here, waves 4-7 after the first of the two k-steps (see gemm_nt_big_kernel)
+    if (kt + 1 < nk && wave < 4) BIG_ISSUE(kt + 1, cur ^ 1)
+    const char* base = smem + cur * 2 * TILE;
+    half8 fa[2][8], fb[2][4];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) fa[0][m] = *(const half8*)(base + a_base + m * 16 * 128 + frag[0]);
+#pragma unroll
+    for (int n = 0; n < 4; ++n) fb[0][n] = *(const half8*)(base + b_base + n * 16 * 128 + frag[0]);
+    SB();
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      // 32 MFMAs of one 32-deep k-step; the 12 fragment reads of the next step are spread between the first 8 groups
+#pragma unroll
+      for (int m = 0; m < 8; ++m) {
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[m][n] = mfma16_f16(fa[s2][m], fb[s2][n], acc[m][n]);
+        if (s2 == 0) {
+          fa[1][m] = *(const half8*)(base + a_base + m * 16 * 128 + frag[1]);
+          if (m < 4) fb[1][m] = *(const half8*)(base + b_base + m * 16 * 128 + frag[1]);
+        }
+        SB();
+      }
+      if (s2 == 0) {
+        if (kt + 1 < nk && wave >= 4) BIG_ISSUE(kt + 1, cur ^ 1)
+        SB();
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    cur ^= 1;
+  }
+#undef BIG_ISSUE
+#undef SB
+
+  // ---------------- epilogue (same semantics as gemm_nt_big_kernel) ----------------
+  float* C32 = p.C32 ? p.C32 + z * p.sC32 : nullptr;
+  _Float16* C16 = p.C16 ? p.C16 + z * p.sC16 : nullptr;
+  const float* bias = p.bias ? p.bias + z * p.sBias : nullptr;
+  const float* res = p.res ? p.res + z * p.sRes : nullptr;
+  const float* gate = p.gate ? p.gate + z * p.sGate : nullptr;
+  {
+    float* stage = (float*)smem + wave * (64 * 64);                  // 8 x 16 KiB = the whole 128 KiB
+    const int row0 = bm0 + 128 * wr, col0 = bn0 + 64 * wc;
+    int lane_e = lane;
+    asm volatile("" : "+v"(lane_e));                                 // see gemm_nt_big_kernel
+    if (res) {
+      epilogue_block64_m16<1>(p, stage, acc, 0, row0, col0, lane_e, C32, C16, bias, res, gate);
+      epilogue_block64_m16<1>(p, stage, acc, 4, row0 + 64, col0, lane_e, C32, C16, bias, res, gate);
+    } else if (bias && p.bias_row) {
+      epilogue_block64_m16<3>(p, stage, acc, 0, row0, col0, lane_e, C32, C16, bias, res, gate);
+      epilogue_block64_m16<3>(p, stage, acc, 4, row0 + 64, col0, lane_e, C32, C16, bias, res, gate);
+    } else {
+      epilogue_block64_m16<0>(p, stage, acc, 0, row0, col0, lane_e, C32, C16, bias, res, gate);
+      epilogue_block64_m16<0>(p, stage, acc, 4, row0 + 64, col0, lane_e, C32, C16, bias, res, gate);
+    }
+  }
+  __syncthreads();   // every wave has read its staging region back: the next tile's LDS-DMA may overwrite it
+  }  // persistent tile loop
+}
+
+
+// ================================================================================================
 // Split-weight GEMM in ONE pass over K:  C = A . (B + Blo)^T  with Blo stored UNSCALED (f16 subnormals allowed: the
 // f16 MFMA honours them on gfx950, checked in benchmarks/lab/denorm_lab.hip), so both products go into the same fp32
 // accumulators and no second sweep / rescale is needed.  Per 32-deep K slab a workgroup loads three 16-KiB tiles
@@ -1229,6 +1392,23 @@ extern "C" int dvd_gemm_nt(const dvd_gemm_desc* d, void* stream) {
     if (nblk > 256) nblk = 256;
     gemm_nt_split_kernel<<<dim3(nblk, d->batch), 512, LDS, (hipStream_t)stream>>>(p);
     return check_launch("gemm_nt(split)");
+  }
+  bool m16 = big && !d->B_lo && !d->A_lo && p.vec_epilogue && !d->pos && !d->gate;
+#ifdef DVD_LAB
+  if (getenv("DVD_GEMM_M32")) m16 = false;        // lab: the 32x32x16 kernel for A/B runs
+#endif
+  if (m16) {
+    p.ntm = cdiv(d->M, 256); p.ntn = d->N / 256;
+    constexpr int LDS = 2 * 2 * 256 * 128;
+    static DeviceOnce once16;
+    if (const auto bit = DeviceOnce::current_bit(); once16.need(bit)) {
+      (void)hipFuncSetAttribute((const void*)gemm_nt_big16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+      once16.done(bit);
+    }
+    int nblk = p.ntm * p.ntn;
+    if (nblk > 256) nblk = 256;
+    gemm_nt_big16_kernel<<<dim3(nblk, d->batch), 512, LDS, (hipStream_t)stream>>>(p);
+    return check_launch("gemm_nt(big16)");
   }
   if (big) {
     p.ntm = cdiv(d->M, 256); p.ntn = d->N / 256;
