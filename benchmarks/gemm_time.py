@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Time the decoder's GEMMs at the bench's shapes (M = 331 776 rows): plain f16 weights (what the dithered engine runs;
-product = the 16x16x32 kernel, `--lab` with DVD_GEMM_M32=1 = the 32x32x16 kernel) and, with `split`, the (hi, lo) pairs.
+product = the 32x32x16 kernel, `--lab` with DVD_GEMM_M16=1 = the rejected 16x16x32 variant) and, with `split`, the (hi, lo) pairs.
 usage: python benchmarks/gemm_time.py [reps=5] [plain|split]"""
 import os, sys
 sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
@@ -9,6 +9,8 @@ import torch
 from dvd_amd import ops
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 MODE = sys.argv[2] if len(sys.argv) > 2 else "plain"
+EXE = 4.0 if MODE == "split" else 2.0
+M32 = os.environ.get("DVD_GEMM_M16", "-")
 M = 331776
 for name, N, K in (("qk  N=3072 K=1536", 3072, 1536), ("c1  N=2048 K=1536", 2048, 1536), ("fc  N=1536 K=1536", 1536, 1536),
                    ("c2  N=1536 K=2048", 1536, 2048)):
@@ -24,5 +26,5 @@ for name, N, K in (("qk  N=3072 K=1536", 3072, 1536), ("c1  N=2048 K=1536", 2048
         x.record(); f(); y.record()
     torch.cuda.synchronize()
     ms = sorted(x.elapsed_time(y) for x, y in ev)[len(ev) // 2]
-    print(f"{name}: {ms:.3f} ms  algorithmic {2.0 * M * N * K / ms / 1e9:.0f} TF/s  executed {(4.0 if MODE == "split" else 2.0) * M * N * K / ms / 1e9:.0f} TF/s   {MODE} lib={LIBSEL} m32={os.environ.get("DVD_GEMM_M32", "-")}")
+    print(f"{name}: {ms:.3f} ms  algorithmic {2.0 * M * N * K / ms / 1e9:.0f} TF/s  executed {EXE * M * N * K / ms / 1e9:.0f} TF/s   {MODE} lib={LIBSEL} m16={M32}")
     del a, w, hi, lo, out

@@ -813,6 +813,7 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_big_kernel(GemmArgs p) {
 }
 
 
+#ifdef DVD_LAB
 // ================================================================================================
 // The same 256 x 256 x 64 kernel on v_mfma_f32_16x16x32_f16.  Both MFMA shapes do the same FLOPs per cycle, read the
 // same number of fragments per FLOP on this wave tile (12 ds_read_b128 per 32-deep step) and use the same LDS image; but
@@ -823,7 +824,9 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_big_kernel(GemmArgs p) {
 //   4 s + q of the 128-byte LDS row, XOR-swizzled by (row >> 1) & 7 like every other reader of this image (a
 //   ds_read_b128 lane group {0-3, 12-15, 20-27} covers rows 0-3 and 12-15 at chunk q0 and rows 4-11 at chunk q0 ^ 1: all
 //   sixteen 16-byte bank slots).  Accumulator register e of lane l = row 4 q + e, column c of its 16 x 16 tile.
-// Plain (un-split) operands only: the engine's dithered weights (one f16 per weight, re-rounded every evaluation).
+// Plain (un-split) operands only.  MEASURED AND REJECTED (round 3, M = 331 776, benchmarks/gemm_time.py): 990-1043 TF/s
+// against 1030-1095 TF/s for gemm_nt_big_kernel on the same box and shapes - 1 to 7 % SLOWER: the clock advantage of the
+// bare loop does not survive 64 instead of 32 MFMA issues per slab and per wave.  Lab build only (DVD_GEMM_M16=1).
 // ================================================================================================
 __device__ __forceinline__ floatx4 mfma16_f16(half8 a, half8 b, floatx4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
@@ -947,6 +950,8 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_big16_kernel(GemmArgs p) {
   }  // persistent tile loop
 }
 
+
+#endif  // DVD_LAB
 
 // ================================================================================================
 // Split-weight GEMM in ONE pass over K:  C = A . (B + Blo)^T  with Blo stored UNSCALED (f16 subnormals allowed: the
@@ -1393,11 +1398,9 @@ extern "C" int dvd_gemm_nt(const dvd_gemm_desc* d, void* stream) {
     gemm_nt_split_kernel<<<dim3(nblk, d->batch), 512, LDS, (hipStream_t)stream>>>(p);
     return check_launch("gemm_nt(split)");
   }
-  bool m16 = big && !d->B_lo && !d->A_lo && p.vec_epilogue && !d->pos && !d->gate;
 #ifdef DVD_LAB
-  if (getenv("DVD_GEMM_M32")) m16 = false;        // lab: the 32x32x16 kernel for A/B runs
-#endif
-  if (m16) {
+  if (big && !d->B_lo && !d->A_lo && p.vec_epilogue && !d->pos && !d->gate && getenv("DVD_GEMM_M16")) {
+    // lab: the 16x16x32-MFMA variant of the 256 x 256 kernel (measured 1-7 % slower, see gemm_nt_big16_kernel)
     p.ntm = cdiv(d->M, 256); p.ntn = d->N / 256;
     constexpr int LDS = 2 * 2 * 256 * 128;
     static DeviceOnce once16;
@@ -1410,6 +1413,7 @@ extern "C" int dvd_gemm_nt(const dvd_gemm_desc* d, void* stream) {
     gemm_nt_big16_kernel<<<dim3(nblk, d->batch), 512, LDS, (hipStream_t)stream>>>(p);
     return check_launch("gemm_nt(big16)");
   }
+#endif
   if (big) {
     p.ntm = cdiv(d->M, 256); p.ntn = d->N / 256;
     constexpr int LDS = 2 * 2 * 256 * 128;
