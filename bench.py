@@ -34,7 +34,7 @@ import torch.distributed as dist  # noqa: E402
 
 PEAK_F16_TFLOPS = 2500.0      # dense f16/bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0         # HBM3E, same guide
-PROFILE_ROUND = "r2"          # which profiles/<round>_pmc_*.json this bench.py's kernels were measured for
+PROFILE_ROUND = "r3"          # which profiles/<round>_pmc_*.json this bench.py's kernels were measured for
 HID, DEC, FFN = 384, 1536, 2048
 
 
@@ -278,8 +278,9 @@ def main(argv=None):
             ms = sum(a.elapsed_time(b) for a, b in evs) / len(evs)
             ms_u8_doc = sum(a.elapsed_time(b) for a, b in ev8[1:]) / (len(ev8) - 1)
             bytes_alg = 32 * FH * FW * B
-            roof_unwarp = {"kernel": f"grid_sample_rows_kernel (drop-in register_model2 contract, f32, {B} documents per "
-                                     "launch)", "bound": "hbm", "achieved": round(bytes_alg / (ms * 1e-3) / 1e9, 1),
+            gs_kernel = "grid_sample_lds_kernel<32, 2048, 0>"
+            roof_unwarp = {"kernel": f"{gs_kernel} (drop-in register_model2 contract, f32, LDS-staged 32x32 tiles, {B} "
+                                     "documents per launch)", "bound": "hbm", "achieved": round(bytes_alg / (ms * 1e-3) / 1e9, 1),
                            "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(bytes_alg / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
                            "traffic": None, "algorithmic_bytes_per_launch": bytes_alg, "launches_timed": len(evs),
                            "avg_launch_ms": round(ms, 4),
@@ -293,6 +294,17 @@ def main(argv=None):
                                              "avg_launch_ms": round(ms_u8_doc, 4),
                                              "achieved_GBps": round(6 * FH * FW * B / (ms_u8_doc * 1e-3) / 1e9, 1),
                                              "note": "VALU-bound at 6 B/px (~150 VALU ops per pixel), not HBM-bound"}}
+            # HBM-side bytes of that kernel from the committed PMC passes (FETCH_SIZE / WRITE_SIZE in separate rocprofv3
+            # runs, 2*FETCH + WRITE: every streaming access of the kernel is 16 bytes per lane) - attached only when the
+            # record was taken on this kernel at this launch shape
+            tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", f"{PROFILE_ROUND}_pmc_traffic.json")
+            if os.path.exists(tpath):
+                rec = json.load(open(tpath)).get(gs_kernel)
+                if rec and rec.get("launch_shape") == {"documents": B, "h": FH, "w": FW}:
+                    roof_unwarp["traffic"] = int(rec["hbm_bytes_per_launch"])
+                    roof_unwarp["traffic_unit"] = "bytes/launch"
+                    roof_unwarp["traffic_source"] = (f"profiles/{PROFILE_ROUND}_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE, "
+                                                     "WRITE_SIZE in separate passes; 2*FETCH+WRITE, gfx950 correction)")
             del srcf, grid_full
         flops_total = per_sample_step * n * S * world * args.steps
         if not args.no_split_weights:

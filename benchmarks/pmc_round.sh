@@ -4,13 +4,13 @@
 #   mfma     : matrix-pipe busy / VALU port / wave stall counters + GRBM_GUI_ACTIVE (kernel cycles -> sustained clock)
 #   durations: a --kernel-trace --stats pass of the same probes (never combined with --pmc)
 # run on the GPU box from the repo root:  bash benchmarks/pmc_round.sh r2   -> gpurun_out/pmc_<round>/ , then
-#   python3 benchmarks/pmc_round_json.py gpurun_out/pmc_r2 profiles r2
-round=${1:-r2}
+#   python3 benchmarks/pmc_round_json.py gpurun_out/pmc_r3 profiles r3
+round=${1:-r3}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 out=gpurun_out/pmc_$round
 rm -rf $out; mkdir -p $out
 export PROBE_B=16
-for op in attn256 attn64 gemm_split unwarp; do
+for op in attn256 attn64 gemm gemm_split gridsample8; do
   for c in FETCH_SIZE WRITE_SIZE; do
     timeout 300 rocprofv3 --pmc $c --output-format csv -d $out/traffic_${op}_$c -- python3 benchmarks/pmc_probe.py $op > $out/traffic_${op}_$c.log 2>&1
   done

@@ -16,6 +16,11 @@ from collections import defaultdict
 
 src, dst, rnd = sys.argv[1], sys.argv[2], sys.argv[3]
 SHAPE = {"samples": int(os.environ.get("PROBE_B", "16")), "grid": 288}
+WARP_SHAPE = {"documents": 8, "h": 3508, "w": 2480}          # benchmarks/pmc_probe.py gridsample8
+
+
+def shape_of(kernel):
+    return WARP_SHAPE if ("grid_sample" in kernel or "unwarp" in kernel) else SHAPE
 
 
 def clean(name):
@@ -47,7 +52,7 @@ for k, d in counters("traffic_*").items():
     if "FETCH_SIZE" in d and "WRITE_SIZE" in d:
         fe, wr = mean(d["FETCH_SIZE"]), mean(d["WRITE_SIZE"])
         traffic[k] = {"FETCH_SIZE_KiB": fe, "WRITE_SIZE_KiB": wr, "launches": len(d["FETCH_SIZE"]),
-                      "hbm_bytes_per_launch": (2 * fe + wr) * 1024, "launch_shape": SHAPE, "kernel_ms": dur.get(k)}
+                      "hbm_bytes_per_launch": (2 * fe + wr) * 1024, "launch_shape": shape_of(k), "kernel_ms": dur.get(k)}
 traffic["_how"] = ("benchmarks/pmc_round.sh: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over "
                    "benchmarks/pmc_probe.py <op> with PROBE_B=16 (the bench's launch shape: 16 samples, T = 20736); "
                    "bytes = (2*FETCH + WRITE) KiB (gfx950 FETCH_SIZE correction)")
@@ -60,7 +65,7 @@ for k, d in counters("mfma_*").items():
     rec = {"mfma_busy": round(m["SQ_VALU_MFMA_BUSY_CYCLES"] / (cyc * 1024), 4),
            "valu_port_busy": round(4 * m["SQ_ACTIVE_INST_VALU"] / (cyc * 1024), 4),
            "waves_issue_stalled": round(m["SQ_WAIT_INST_ANY"] / m["SQ_WAVE_CYCLES"], 4),
-           "kernel_cycles": int(cyc), "kernel_ms": dur.get(k), "launch_shape": SHAPE}
+           "kernel_cycles": int(cyc), "kernel_ms": dur.get(k), "launch_shape": shape_of(k)}
     if dur.get(k):
         rec["sustained_clock_ghz"] = round(cyc / (dur[k] * 1e-3) / 1e9, 3)
     mfma[k] = rec

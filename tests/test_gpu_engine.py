@@ -207,10 +207,10 @@ def test_ddpm_loop_vs_oracle(steps):
     assert per[-1] < 6e-5, per[-1]          # measured 2.1e-5 (25 steps) / 1.1e-5 (250 steps) on MI355X (x3)
 
 
-def test_ddpm_large_grid_vs_oracle(steps=60):
+def test_ddpm_large_grid_vs_oracle(steps=40):
     """BASELINE configs[3] runs its ancestral steps at G = 288, where the weights of the 256-wide GEMMs are dithered:
     the same sampler on a LARGE-tile grid (G = 72: T = 1296 > 1024 tokens, ragged), one hypothesis, tame family -
-    un-clamped last x0 against the oracle, dithered and split.  60 steps here (the oracle costs 2 s per step); the full
+    un-clamped last x0 against the oracle, dithered and split.  40 steps here (the oracle costs 2 s per step); the full
     250 steps are run once per round by tests/tools/ddpm250_large_grid.py (8.5 minutes; profiles/r3_ddpm250_g72.txt:
     6.5e-6 dithered, 6.2e-6 split)."""
     from dvd_amd import sampler, schedule
