@@ -89,7 +89,7 @@ def test_two_rank_broadcast_and_sharding():
 # COMPUTE entry points stubbed at the lib.call boundary (there is no GPU here; the host-only entry
 # points - create / tensor_info / bind_workspace / set_tensor - run for real).
 # ------------------------------------------------------------------------------------------------
-COMPUTE = {"dvd_unwarp_grid", "dvd_grid_sample_bilinear_zeros_ac", "dvd_convnet_run", "dvd_resize_bilinear_nchw", "dvd_threshold_mask_mul", "dvd_ingest_u8",
+COMPUTE = {"dvd_unwarp_grid", "dvd_grid_sample_bilinear_zeros_ac", "dvd_convnet_run", "dvd_resize_bilinear_nchw", "dvd_threshold_mask_mul", "dvd_threshold_mask_mul_batch", "dvd_ingest_u8",
            "dvd_unwarp_u8_batch", "dvd_engine_prepare_docs", "dvd_engine_denoise_step", "dvd_engine_feat_nchw", "dvd_sched_step",
            "dvd_hyp_mean_clamp", "dvd_unwarp_u8"}
 
@@ -161,7 +161,43 @@ def test_val_tdiff_run_two_ranks(tmp_path, n_docs):
     for docs, den, prep, unw, cn, ing in ((want0, den0, prep0, unw0, cn0, ing0), (want1, den1, prep1, unw1, cn1, ing1)):
         batches = (len(docs) + 1) // 2
         assert den == 3 * batches and prep == batches and unw == batches      # one batched unwarp launch per batch
-        assert ing == len(docs) and cn == 3 * len(docs)    # ingest + the three pre-stage nets once per document
+        assert ing == len(docs) and cn == 3 * batches      # ingest once per document; each of the three pre-stage nets
+                                                           # runs its op list ONCE per batch of documents (round 3)
+
+
+def _missing_ckpt_worker(rank, world, port, q, tmp):
+    sys.path.insert(0, ROOT)
+    os.chdir(tmp)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    calls = []
+    _stub_compute(calls)
+    import admin.settings as ws
+    from dvd_amd import dist_util, val_TDiff
+    dist_util.setup_dist(backend="gloo")
+    s = ws.Settings()
+    s.env.grid_size, s.env.diffusion_steps, s.env.n_batch = 16, 3, 2
+    s.env.num_synthetic_docs, s.env.batch_docs, s.env.full_res, s.env.visualize = 2, 2, (32, 24), False
+    s.env.synthetic_weights_if_missing = False          # no checkpoint file here: rank 0 (the only reader) must fail ...
+    s.name, s.seed, s.severity, s.corruption_number = f"gloo_missing{rank}", 0, 0, 0
+    try:
+        val_TDiff.run(s)
+        outcome = "returned"
+    except FileNotFoundError:
+        outcome = "FileNotFoundError"
+    except RuntimeError as e:                           # ... and every OTHER rank must raise too, not wait in the broadcast
+        outcome = "RuntimeError" if "another rank" in str(e) else f"unexpected RuntimeError: {e}"
+    q.put((rank, outcome, calls.count("dvd_engine_denoise_step")))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_missing_checkpoint_fails_on_every_rank(tmp_path):
+    """Only rank 0 reads checkpoint files.  When it cannot, the other ranks used to sit in the weight broadcast until the
+    launcher killed them (round-2 ADVICE); now a 4-byte all-reduce in front of the broadcast makes every rank raise."""
+    res = _spawn_ranks(_missing_ckpt_worker, 2, (str(tmp_path),))
+    assert res[0][1] == "FileNotFoundError" and res[1][1] == "RuntimeError", res
+    assert res[0][2] == res[1][2] == 0
 
 
 # ------------------------------------------------------------------------------------------------
