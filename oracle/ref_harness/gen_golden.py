@@ -16,6 +16,7 @@ Fixtures:
   G1 schedule.npz      cosine schedule tables for S in {3,10,50,250}, t_model sequences
   G2 forward_g{G}.npz  one DiT.forward per t-class at G in {16,32,64}, N=2, + checkpoints
   G3 loop_g{G}_s{S}.npz full ddim_sample_loop (G=64: S=3,10) / training-variant loop (G=16,32)
+  G9 loop_g{G}_s{S}_tame.npz the same loops on the TAME weight family (out_gain = 1.6 / S), G=64 S=10,50 and G=32 S=50
   G4 ddim_step.npz     ddim_sample on random (x_t,x0) for every t of S=50; p_mean_variance S=250
   G5 unwarp.npz        upsample+affine+grid_sample+uint8 tail on a small ragged image
   G6 grid_sample.npz   register_model2 on the per-step feature-warp shape
@@ -63,8 +64,9 @@ def import_reference():
     return cross_model, gaussian_diffusion, respace, script_util, dist_util, warping
 
 
-def build_model(cross_model, grid, script_util=None, dist_util=None):
-    """Reference model at coordinate-grid size `grid` with the synthetic state dict."""
+def build_model(cross_model, grid, script_util=None, dist_util=None, out_gain=1.0):
+    """Reference model at coordinate-grid size `grid` with the synthetic state dict (out_gain: synth.tame_gain(S) for the
+    tame family whose S-step roll-out stays inside (-1, 1))."""
     if grid == 64 and script_util is not None:
         # through the reference's own factory (script_util.py:155-162)
         from admin.local import EnvironmentSettings
@@ -85,7 +87,7 @@ def build_model(cross_model, grid, script_util=None, dist_util=None):
         + "\n".join(f"{a} | {b}" for a, b in zip(ref_sd.keys(), spec.keys()) if a != b))
     for k, v in ref_sd.items():
         assert tuple(v.shape) == tuple(spec[k][0]), (k, v.shape, spec[k][0])
-    sd = synth.synth_state_dict(grid, SEED_W)
+    sd = synth.synth_state_dict(grid, SEED_W, out_gain=out_gain)
     # the computed tables must agree with what the reference computes itself
     for k in ("noised_obs_pos_embed", "decoder.position_dec.h_position_encoder",
               "decoder.position_dec.w_position_encoder"):
@@ -210,9 +212,10 @@ def gen_forward(mods, grid):
 
 
 # ------------------------------------------------------------------------------- G3
-def gen_loop(mods, grid, steps, full_blocks):
+def gen_loop(mods, grid, steps, full_blocks, tame=False):
+    """tame=True (G9): the tame weight family, every 7th step's x0 + the last kept (a 50-step file stays ~1 MB)."""
     cross_model, gd, respace, script_util, dist_util, warping = mods
-    model = build_model(cross_model, grid, script_util, dist_util)
+    model = build_model(cross_model, grid, script_util, dist_util, out_gain=synth.tame_gain(steps) if tame else 1.0)
     if not full_blocks:
         # F2: only blocks[-1] is live; bit-identical and 10x cheaper
         model.blocks = torch.nn.ModuleList([model.blocks[-1]])
@@ -263,9 +266,18 @@ def gen_loop(mods, grid, steps, full_blocks):
            "x_T": x_T.numpy(), "t_model": np.asarray(rec["t"], dtype=np.float32),
            "x0_steps": np.stack(rec["x0"]), "x_in_steps": np.stack(rec["x_in"]),
            "sample": sample.numpy(), "ref_seconds": np.float64(dt)}
-    np.savez_compressed(os.path.join(GOLD, f"loop_g{grid}_s{steps}.npz"), **out)
-    print(f"G3 loop_g{grid}_s{steps}.npz  {kind}  {dt:.1f}s  t_model={rec['t']}  "
-          f"sample mean {sample.mean():+.5f} std {sample.std():.5f}")
+    name = f"loop_g{grid}_s{steps}.npz"
+    if tame:
+        keep = sorted(set(range(0, steps, 7)) | {steps - 1})
+        last = rec["x0"][-1]
+        out.update(out_gain=np.float64(synth.tame_gain(steps)), kept_steps=np.asarray(keep, dtype=np.int64),
+                   x0_steps=np.stack([rec["x0"][i] for i in keep]),
+                   last_x0_std=np.float64(last.std()), last_x0_saturated=np.float64((np.abs(last) >= 1).mean()))
+        del out["x_in_steps"]
+        name = f"loop_g{grid}_s{steps}_tame.npz"
+    np.savez_compressed(os.path.join(GOLD, name), **out)
+    print(f"{'G9' if tame else 'G3'} {name}  {kind}  {dt:.1f}s  t_model={rec['t'][:12]}  "
+          f"sample mean {sample.mean():+.5f} std {sample.std():.5f}  last x0 std {rec['x0'][-1].std():.3f}")
 
 
 # ------------------------------------------------------------------------------- G7
@@ -442,7 +454,7 @@ def gen_grid_sample(mods):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--only", default="G1,G2,G3,G4,G5,G6,G7,G8")
+    ap.add_argument("--only", default="G1,G2,G3,G4,G5,G6,G7,G8,G9")
     args = ap.parse_args()
     want = set(args.only.split(","))
     os.makedirs(GOLD, exist_ok=True)
@@ -465,6 +477,10 @@ def main():
         gen_loop(mods, 32, 3, True)
         gen_loop(mods, 64, 3, True)
         gen_loop(mods, 64, 10, False)
+    if "G9" in want:                            # tame family (x0 inside (-1, 1)): un-flattered long loops from the REAL reference
+        gen_loop(mods, 64, 10, False, tame=True)
+        gen_loop(mods, 64, 50, False, tame=True)
+        gen_loop(mods, 32, 50, False, tame=True)
     if "G8" in want:
         gen_prestage(mods, 16)
     if "G7" in want:

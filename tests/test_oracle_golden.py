@@ -170,6 +170,25 @@ def test_loop_s10_vs_reference():
     np.testing.assert_allclose(out.numpy(), g["sample"], rtol=0, atol=1e-4)
 
 
+# ----------------------------------------------------------------------------- G9
+@pytest.mark.parametrize("grid,steps", [(64, 10), (32, 50)])
+def test_tame_family_loop_vs_reference(grid, steps):
+    """The TAME weight family (final linear layer scaled by 1.6 / S: x0 stays inside (-1, 1), nothing hides behind the
+    final clamp) against the REAL reference's roll-out: the un-clamped x0 of every kept step and the final map.  (The
+    50-step G = 64 golden is checked on the GPU only: the oracle needs 3 s per step there.)"""
+    g = load(f"loop_g{grid}_s{steps}_tame.npz")
+    assert float(g["last_x0_saturated"]) < 0.01 and 0.2 < float(g["last_x0_std"]) < 0.6
+    sd = synth.synth_state_dict(grid, int(g["seed_w"]), blocks=[11], out_gain=float(g["out_gain"]))
+    assert float(g["out_gain"]) == synth.tame_gain(steps)
+    orc = O.Oracle(sd, grid)
+    trace = []
+    out = orc.sample_loop(O.Schedule(steps), torch.from_numpy(g["x_T"]), _doc(grid), mean_hyp=(grid == 64), trace=trace)
+    for k, i in enumerate(g["kept_steps"]):
+        err = np.abs(trace[int(i)].numpy() - g["x0_steps"][k]).max()
+        assert err < 2e-5, (int(i), err)
+    np.testing.assert_allclose(out.numpy(), g["sample"], rtol=0, atol=2e-5)
+
+
 # ----------------------------------------------------------------------------- G8
 def test_prestage_oracle_vs_reference():
     """The pre-stage nets' restatement (oracle/prestage_oracle.py) against the reference's own U2NETP / Seg / UNet
