@@ -18,6 +18,13 @@ def use_lab():
 def which(argv=None):
     """`--lab` on the command line selects the lab build; default is the product library."""
     argv = sys.argv if argv is None else argv
+    if "--lib" in argv:                      # any other build of the library (benchmarks/lab/alt/: compile-time variants)
+        i = argv.index("--lib")
+        path = argv[i + 1]
+        del argv[i:i + 2]
+        from dvd_amd import lib
+        lib.use_library(path)
+        return os.path.basename(path)
     if "--lab" in argv:
         argv.remove("--lab")
         return use_lab()

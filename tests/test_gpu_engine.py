@@ -142,7 +142,8 @@ def test_tame_family_loop_vs_reference_golden(grid, steps):
     err = float(np.sqrt(((out.cpu().numpy() - g["sample"]) ** 2).mean()))
     print(f"tame-family loop vs the real reference G={grid} S={steps}: final {err:.2e}, un-clamped x0 per kept step {per}, "
           f"last x0 std {float(g['last_x0_std']):.3f}, saturated {float(g['last_x0_saturated']):.4f}")
-    assert per[steps - 1] < 1e-4 and err < 1e-4, (err, per)     # PROVISIONAL (expected ~1.5e-5); north_star's bar is 1e-3
+    # measured on MI355X: last un-clamped x0 2.8e-5 (S=10, G=64), 1.28e-5 (S=50, G=64), 1.31e-5 (S=50, G=32); bar ~3x
+    assert per[steps - 1] < 9e-5 and err < 9e-5, (err, per)     # north_star's bar is 1e-3
 
 
 def _saturated(x):
