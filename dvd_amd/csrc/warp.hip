@@ -212,10 +212,10 @@ __global__ void __launch_bounds__(256) grid_sample_rows_kernel(const float* __re
 //   2. the tile's source footprint - the bounding box of all tap rows / columns - is reduced over the workgroup;
 //   3. the box is copied into LDS with fully coalesced 16-byte loads along source rows (x origin aligned down to 4 px);
 //   4. the taps are gathered from LDS (two adjacent dwords per tap row) and the outputs streamed out.
-// A tile whose box exceeds the LDS budget (2048 px per plane: ~8 % of the tiles of the bench's flow; shear beyond ~35 degrees at unit scale, or a wildly
-// non-smooth grid) takes the direct
-// gather for that tile; arithmetic (make_ptaps / blend) is shared with the row kernels, so all paths give the same bits.
-// Measured on MI355X (8 documents of 3508 x 2480 per launch, the bench's flow; benchmarks/warp_time.py): 4.2-4.4 TB/s
+// A tile whose box exceeds the LDS budget (2048 px per plane: ~8 % of the tiles of the bench's flow, whose local shear
+// reaches 35 degrees; any wildly non-smooth grid) takes the direct gather for that tile; arithmetic (make_ptaps / blend)
+// is shared with the row kernels, so all paths give the same bits.
+// Measured on MI355X (8 documents of 3508 x 2480 per launch, the bench's flow; benchmarks/warp_time.py): 4.2-4.6 TB/s
 // against 3.8 for the row kernel and 5.1 for a device copy of the same 2.2 GB - and the same with an identity flow: the
 // gather no longer costs anything, what remains is the streaming rate of eight interleaved planes.  What mattered, in
 // order: 16 bytes per lane on every streaming access (the first version read the grid and wrote the output 4 bytes per
