@@ -302,12 +302,14 @@ def test_batched_documents_match_single():
         assert torch.equal(o[0], out2[d]), d
 
 
-def test_graph_replay_equals_eager():
-    """A sampling loop whose denoiser evaluations are replayed as captured hipGraphs (the default for small grids) gives
+@pytest.mark.parametrize("grid", [16, 72])
+def test_graph_replay_equals_eager(grid):
+    """A sampling loop whose denoiser evaluations are replayed as captured hipGraphs (the default for grids <= 128) gives
     the same bits as the eagerly enqueued launch sequence - first use of an address triple runs eagerly, the second
-    captures, later ones replay, so three roll-outs exercise all three."""
+    captures, later ones replay, so three roll-outs exercise all three.  G = 72 is a large-tile grid: the weights are
+    re-rounded (dithered) before every evaluation OUTSIDE the captured graph, whose GEMMs read the re-rounded copy - replay
+    must pick up each step's copy, and a roll-out must be a function of its inputs alone (dither_step = loop index)."""
     from dvd_amd import sampler, schedule
-    grid = 16
     eng, orc, doc_t, inv1 = setup(grid)
     tab = schedule.Tables(schedule.named_betas("cosine", 10))
     xT = torch.from_numpy(synth.synth_noise(0, 2, grid, SEED_IN)).cuda()
