@@ -1135,6 +1135,9 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_split_kernel(GemmArgs p) {
 
 // Same kernel for N % 128 == 0 (the DiT block's N = 384 / 1152 projections): 256 x 128 tiles, a wave owns 64 x 64, the
 // general (pos / gate / residual) staged epilogue is available because only 64 accumulator registers are live.
+// SPLIT = false: the same pipeline on ONE weight tensor (the engine's dithered weights): no Blo tile, no lo MFMAs - a stage
+// is [A | B] and a wave has 8 MFMAs per half slab.
+template <bool SPLIT>
 __global__ void __launch_bounds__(512, 2) gemm_nt_split128_kernel(GemmArgs p) {
   constexpr int BK = 32, TILE = 256 * 64, TILEB = 128 * 64, STAGE = TILE + 2 * TILEB, NST = 3;
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [3 stages][A 16K | B 8K | Blo 8K] (>= 128 KiB for the epilogue)
@@ -1152,7 +1155,7 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_split128_kernel(GemmArgs p) {
   const int bm0 = tm * 256, bn0 = tn * 128;
   const _Float16* A = (const _Float16*)p.A + z * p.sA;
   const _Float16* B = (const _Float16*)p.B + z * p.sB;
-  const _Float16* Blo = (const _Float16*)p.Blo + z * p.sB;
+  const _Float16* Blo = SPLIT ? (const _Float16*)p.Blo + z * p.sB : B;
 
   // per-lane source offsets of this wave's 2 + 1 + 1 loads (1 KiB = 16 rows x 64 B each)
   unsigned aoff[2], boff;
@@ -1194,13 +1197,14 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_split128_kernel(GemmArgs p) {
     const unsigned l_ = lds0 + (stage_) * STAGE;                                                         \
     glds_one4(Atile + kb_, aoff[0], l_ + (2 * wave) * 1024); glds_one4(Atile + kb_, aoff[1], l_ + (2 * wave + 1) * 1024); \
     glds_one4(Btile + kb_, boff, l_ + TILE + wave * 1024);                                               \
-    glds_one4(Ltile + kb_, boff, l_ + TILE + TILEB + wave * 1024);                                       \
+    if constexpr (SPLIT) glds_one4(Ltile + kb_, boff, l_ + TILE + TILEB + wave * 1024);                  \
   }
 #define SB() __builtin_amdgcn_sched_barrier(0)
   // prologue: slabs 0 and 1 (clamped: K = 32 has a single slab)
   SPLIT_ISSUE(0, 0)
   SPLIT_ISSUE(min(1, nk - 1), 1)
-  asm volatile("s_waitcnt vmcnt(4)" ::: "memory");     // slab 0 landed (this wave's part); slab 1 may be in flight
+  if constexpr (SPLIT) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // slab 0 landed (this wave's part); slab 1 may be in flight
+  else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
   __syncthreads();
   // The loop is skewed by half a slab so that no wave ever starts a slab with cold fragment registers: the barrier
   // that publishes slab kt + 1 sits in the MIDDLE of slab kt, and the second half of slab kt already reads the first
@@ -1212,7 +1216,7 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_split128_kernel(GemmArgs p) {
     _Pragma("unroll") for (int m = 0; m < 2; ++m) fa[set_][m] = *(const half8*)((base_) + a_base + m * 32 * 64 + frag[ks_]); \
     _Pragma("unroll") for (int n = 0; n < 2; ++n) {                                                   \
       fh[set_][n] = *(const half8*)((base_) + b_base + n * 32 * 64 + frag[ks_]);                      \
-      fl[set_][n] = *(const half8*)((base_) + l_base + n * 32 * 64 + frag[ks_]);                      \
+      if constexpr (SPLIT) fl[set_][n] = *(const half8*)((base_) + l_base + n * 32 * 64 + frag[ks_]); \
     }                                                                                                 \
   }
   // 16 MFMAs of one k-step (8 hi then 8 lo: an accumulator is revisited after 8 others); the 8 fragment reads of the
@@ -1223,12 +1227,14 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_split128_kernel(GemmArgs p) {
       _Pragma("unroll") for (int n = 0; n < 2; ++n) acc[m][n] = mfma32_f16(fa[set_][m], fh[set_][n], acc[m][n]); \
       fa[nset_][m] = *(const half8*)((nbase_) + a_base + m * 32 * 64 + frag[nks_]);                   \
       fh[nset_][m] = *(const half8*)((nbase_) + b_base + m * 32 * 64 + frag[nks_]);                   \
-      fl[nset_][m] = *(const half8*)((nbase_) + l_base + m * 32 * 64 + frag[nks_]);                   \
+      if constexpr (SPLIT) fl[nset_][m] = *(const half8*)((nbase_) + l_base + m * 32 * 64 + frag[nks_]); \
       SB();                                                                                           \
     }                                                                                                 \
-    _Pragma("unroll") for (int m = 0; m < 2; ++m) {                                                   \
-      _Pragma("unroll") for (int n = 0; n < 2; ++n) acc[m][n] = mfma32_f16(fa[set_][m], fl[set_][n], acc[m][n]); \
-      SB();                                                                                           \
+    if constexpr (SPLIT) {                                                                            \
+      _Pragma("unroll") for (int m = 0; m < 2; ++m) {                                                 \
+        _Pragma("unroll") for (int n = 0; n < 2; ++n) acc[m][n] = mfma32_f16(fa[set_][m], fl[set_][n], acc[m][n]); \
+        SB();                                                                                         \
+      }                                                                                               \
     }                                                                                                 \
   }
   SPLIT_READ(0, smem, 0)
@@ -1254,16 +1260,18 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_split128_kernel(GemmArgs p) {
         for (int n = 0; n < 2; ++n) acc[m][n] = mfma32_f16(fa[1][m], fh[1][n], acc[m][n]);
         fa[0][m] = *(const half8*)(nb + a_base + m * 32 * 64 + frag[0]);
         fh[0][m] = *(const half8*)(nb + b_base + m * 32 * 64 + frag[0]);
-        fl[0][m] = *(const half8*)(nb + l_base + m * 32 * 64 + frag[0]);
+        if constexpr (SPLIT) fl[0][m] = *(const half8*)(nb + l_base + m * 32 * 64 + frag[0]);
         SB();
       }
       if (wave >= 4) SPLIT_ISSUE(min(kt + 2, nk - 1), n2)
       SB();
+      if constexpr (SPLIT) {
 #pragma unroll
-      for (int m = 0; m < 2; ++m) {
+        for (int m = 0; m < 2; ++m) {
 #pragma unroll
-        for (int n = 0; n < 2; ++n) acc[m][n] = mfma32_f16(fa[1][m], fl[1][n], acc[m][n]);
-        SB();
+          for (int n = 0; n < 2; ++n) acc[m][n] = mfma32_f16(fa[1][m], fl[1][n], acc[m][n]);
+          SB();
+        }
       }
     }
     cur = n1;
@@ -1371,19 +1379,22 @@ extern "C" int dvd_gemm_nt(const dvd_gemm_desc* d, void* stream) {
   // same fp32 summation order - whether it is sampled alone or in a batch (bit-identical results, tested)
   const bool small = d->small_tiles != 0;      // the caller's problem family is small: 128x128 tiles everywhere
   const bool big = d->dtype == 0 && d->N % 256 == 0 && !lab_v1 && !small;
-  if (d->dtype == 0 && d->N % 128 == 0 && d->N % 256 != 0 && d->B_lo && !d->A_lo && d->lo_scale == 1.f &&
-      !lab_twopass && !lab_v1 && !small) {
+  if (d->dtype == 0 && d->N % 128 == 0 && d->N % 256 != 0 && !d->A_lo && (!d->B_lo || d->lo_scale == 1.f) &&
+      d->K % 32 == 0 && !lab_twopass && !lab_v1 && !small) {
+    // 256 x 128 tiles for the DiT block's 384-wide GEMMs: (hi, lo) in one pass, or ONE (dithered) weight tensor
     p.ntm = cdiv(d->M, 256); p.ntn = d->N / 128;
     constexpr int LDS = 8 * 16384;                    // 3 stages x 32 KiB, rounded up to the epilogue's 8 x 16 KiB
     static DeviceOnce once_s1;
     if (const auto bit = DeviceOnce::current_bit(); once_s1.need(bit)) {
-      (void)hipFuncSetAttribute((const void*)gemm_nt_split128_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+      (void)hipFuncSetAttribute((const void*)gemm_nt_split128_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+      (void)hipFuncSetAttribute((const void*)gemm_nt_split128_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
       once_s1.done(bit);
     }
     int nblk = p.ntm * p.ntn;
     if (nblk > 256) nblk = 256;
-    gemm_nt_split128_kernel<<<dim3(nblk, d->batch), 512, LDS, (hipStream_t)stream>>>(p);
-    return check_launch("gemm_nt(split128)");
+    if (d->B_lo) gemm_nt_split128_kernel<true><<<dim3(nblk, d->batch), 512, LDS, (hipStream_t)stream>>>(p);
+    else gemm_nt_split128_kernel<false><<<dim3(nblk, d->batch), 512, LDS, (hipStream_t)stream>>>(p);
+    return check_launch("gemm_nt(128-wide)");
   }
   if (big && d->B_lo && !d->A_lo && d->lo_scale == 1.f && d->K % 32 == 0 && !lab_twopass) {
     p.ntm = cdiv(d->M, 256); p.ntn = d->N / 256;
