@@ -47,7 +47,7 @@ struct TensorSpec {
   std::string name;
   int dtype;  // 0 f32, 1 f16
   long nelem;
-  bool wide;  // f16 weight whose GEMM runs on ONE re-rounded f16 per weight on large grids (gets a dithered copy, see Engine)
+  bool wide;  // f16 weight of a GEMM that takes the 256-wide kernels on large grids (gets a dithered copy, see Engine)
 };
 
 static const int PYR_CIN[7] = {4, 64, 64, 128, 128, 256, 256};
@@ -58,10 +58,11 @@ static std::vector<TensorSpec> tensor_specs(int G) {
   const long T = (long)(G / 2) * (G / 2), side = G / 2;
   std::vector<TensorSpec> v;
   auto f32 = [&](const std::string& n, long e) { v.push_back({n, 0, e, false}); };
-  // every f16 weight comes as a (hi, lo) pair: W = hi + lo, lo unscaled  (see dvd_gemm_desc.B_lo).  `wide`: on large grids
-  // its GEMM runs a 256-row-tile kernel on ONE f16 per weight (256 x 256 for N % 256 == 0, 256 x 128 for the DiT block's
-  // 384-wide ones), so the weight gets a dithered copy (dvd_dither_f16) - every per-step GEMM weight since round 3
-  auto f16 = [&](const std::string& n, long e, bool wide = true) {
+  // every f16 weight comes as a (hi, lo) pair: W = hi + lo, lo unscaled  (see dvd_gemm_desc.B_lo).  `wide`: its GEMM has
+  // N % 256 == 0 (B-side weights: N = output features; A-side V^T projections: N = tokens) and runs ONE pass on a dithered
+  // copy on large grids.  The DiT block's 384-wide GEMMs keep the (hi, lo) pair: measured (round 3), dithering them too
+  // saves 0.3 % of the step (they are memory-bound) and costs 8-35 % more roll-out error.
+  auto f16 = [&](const std::string& n, long e, bool wide = false) {
     v.push_back({n, 1, e, wide});
     v.push_back({n + "_lo", 1, e, false});
   };
@@ -185,7 +186,7 @@ struct Engine {
   hipStream_t cap_stream = nullptr;
 
   const float* F(int i) const { return (const float*)wptr[i]; }
-  // `wide`: the GEMM that consumes weight i has a one-pass kernel for plain operands on large grids (all of them do)
+  // `wide`: the GEMM that consumes weight i takes the 256-wide kernels (its N is a multiple of 256 on a large grid)
   bool dithered(int i, bool wide) const { return dither && wide && !small_tiles && dith_off[i] >= 0; }
   const void* H(int i, bool wide = false) const {
     return dithered(i, wide) ? (const void*)((const _Float16*)(ws + bufs[bi.w16dith].off) + dith_off[i]) : wptr[i];
@@ -639,14 +640,14 @@ static int enqueue_step(Engine* e, const float* x_t, int feat_mode, const float*
   TRY(dvd_embed_obs_ln(x_t, e->F(e->wi.obs_w), e->F(e->wi.obs_b), e->F(e->wi.pos), xtok32, xq16, N, G, stream));
   TRY(dvd_build_r_rows((const float*)e->B(e->bi.feat), init_feat_nchw, init_flow, arows16, RK, N, G, hyp, feat_mode,
                        stream));
-  TRY(gemm(F16, (int)NT, HID, RK, 1, arows16, RK, 0, e->H(e->wi.r_w16, true), RK, 0, nullptr, 0, 0, rtok16, HID, 0, e->F(e->wi.r_b), 0,
-           0, e->F(e->wi.pos), T, nullptr, 0, nullptr, 0, 0, stream, nullptr, e->L(e->wi.r_w16, true)));
+  TRY(gemm(F16, (int)NT, HID, RK, 1, arows16, RK, 0, e->H(e->wi.r_w16), RK, 0, nullptr, 0, 0, rtok16, HID, 0, e->F(e->wi.r_b), 0,
+           0, e->F(e->wi.pos), T, nullptr, 0, nullptr, 0, 0, stream, nullptr, e->L(e->wi.r_w16)));
 
   // --- parallel cross-attention of the shared query against the 4 streams (:237-265) ---
-  TRY(gemm(F16, (int)NT, HID, HID, 1, xq16, HID, 0, e->H(e->wi.ca_wq16, true), HID, 0, nullptr, 0, 0, q16, HID, 0, e->F(e->wi.ca_bq),
-           0, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0, stream, nullptr, e->L(e->wi.ca_wq16, true)));
-  TRY(gemm(F16, (int)NT, HID, HID, 1, rtok16, HID, 0, e->H(e->wi.ca_wk16, true), HID, 0, nullptr, 0, 0, kr16, HID, 0,
-           e->F(e->wi.ca_bk), 0, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0, stream, nullptr, e->L(e->wi.ca_wk16, true)));
+  TRY(gemm(F16, (int)NT, HID, HID, 1, xq16, HID, 0, e->H(e->wi.ca_wq16), HID, 0, nullptr, 0, 0, q16, HID, 0, e->F(e->wi.ca_bq),
+           0, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0, stream, nullptr, e->L(e->wi.ca_wq16)));
+  TRY(gemm(F16, (int)NT, HID, HID, 1, rtok16, HID, 0, e->H(e->wi.ca_wk16), HID, 0, nullptr, 0, 0, kr16, HID, 0,
+           e->F(e->wi.ca_bk), 0, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0, stream, nullptr, e->L(e->wi.ca_wk16)));
   TRY(gemm(F16, HID, T, HID, N, e->H(e->wi.ca_wv16, true), HID, 0, rtok16, HID, (long)T * HID, nullptr, 0, 0, vtr16, T,
            (long)HID * T, e->F(e->wi.ca_bv), 1, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0, stream, e->L(e->wi.ca_wv16, true), nullptr));
   {
@@ -659,8 +660,8 @@ static int enqueue_step(Engine* e, const float* x_t, int feat_mode, const float*
              att16 + (size_t)3 * NT * HID, HID, (long)T * HID, 0.125f, stream));
   }
   // x_s = x + out_proj(attn_s)  -> z[:, 384 s : 384 (s+1)]   (stream order cond, msk6, line, r == cat order :623)
-  TRY(gemm(F16, (int)NT, HID, HID, 4, att16, HID, NT * HID, e->H(e->wi.ca_wo16, true), HID, 0, z, DEC, HID, nullptr, 0, 0,
-           e->F(e->wi.ca_bo), 0, 0, nullptr, 0, nullptr, 0, xtok32, HID, 0, stream, nullptr, e->L(e->wi.ca_wo16, true)));
+  TRY(gemm(F16, (int)NT, HID, HID, 4, att16, HID, NT * HID, e->H(e->wi.ca_wo16), HID, 0, z, DEC, HID, nullptr, 0, 0,
+           e->F(e->wi.ca_bo), 0, 0, nullptr, 0, nullptr, 0, xtok32, HID, 0, stream, nullptr, e->L(e->wi.ca_wo16)));
 
   if (e->debug_stop == 1) return check_launch("engine_denoise_step(stop 1)");
   // --- per stream: gated self-attention (:268-289) ---
@@ -672,15 +673,15 @@ static int enqueue_step(Engine* e, const float* x_t, int feat_mode, const float*
            (long)HID * T, e->F(e->wi.sa_bv), 1, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0, stream, e->L(e->wi.sa_wv16, true), nullptr));
   TRY(attn(64, 6, 4 * N, T, T, 1, qk16, 2 * HID, (long)T * 2 * HID, qk16 + HID, 2 * HID, (long)T * 2 * HID, vt16, T,
            (long)HID * T, att16, HID, (long)T * HID, 0.125f, stream));
-  TRY(gemm(F16, (int)NT, HID, HID, 4, att16, HID, NT * HID, e->H(e->wi.sa_wp16, true), HID, 0, z, DEC, HID, nullptr, 0, 0,
-           e->F(e->wi.sa_bp), 0, 0, nullptr, 0, g_a, (int)NT, z, DEC, HID, stream, nullptr, e->L(e->wi.sa_wp16, true)));
+  TRY(gemm(F16, (int)NT, HID, HID, 4, att16, HID, NT * HID, e->H(e->wi.sa_wp16), HID, 0, z, DEC, HID, nullptr, 0, 0,
+           e->F(e->wi.sa_bp), 0, 0, nullptr, 0, g_a, (int)NT, z, DEC, HID, stream, nullptr, e->L(e->wi.sa_wp16)));
   // --- per stream: gated MLP (:271-292) ---
   TRY(dvd_layernorm_rows(z, DEC, HID, h16, HID, NT * HID, 4, NT, HID, nullptr, nullptr, sh_m, sc_m, 0, (int)NT, 1e-6f,
                          stream));
   TRY(gemm(F16, (int)(4 * NT), 4 * HID, HID, 1, h16, HID, 0, e->H(e->wi.fc1_w16, true), HID, 0, nullptr, 0, 0, mlp16, 4 * HID, 0,
            e->F(e->wi.fc1_b), 0, /*gelu*/ 1, nullptr, 0, nullptr, 0, nullptr, 0, 0, stream, nullptr, e->L(e->wi.fc1_w16, true)));
-  TRY(gemm(F16, (int)NT, HID, 4 * HID, 4, mlp16, 4 * HID, NT * 4 * HID, e->H(e->wi.fc2_w16, true), 4 * HID, 0, z, DEC, HID,
-           nullptr, 0, 0, e->F(e->wi.fc2_b), 0, 0, nullptr, 0, g_m, (int)NT, z, DEC, HID, stream, nullptr, e->L(e->wi.fc2_w16, true)));
+  TRY(gemm(F16, (int)NT, HID, 4 * HID, 4, mlp16, 4 * HID, NT * 4 * HID, e->H(e->wi.fc2_w16), 4 * HID, 0, z, DEC, HID,
+           nullptr, 0, 0, e->F(e->wi.fc2_b), 0, 0, nullptr, 0, g_m, (int)NT, z, DEC, HID, stream, nullptr, e->L(e->wi.fc2_w16)));
 
   if (e->debug_stop == 2) return check_launch("engine_denoise_step(stop 2)");
   // --- decoder: adaptive 2-D positional encoding (idf/cross_attn.py:143-157) ---

@@ -10,4 +10,4 @@ sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..",
 sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
 import test_gpu_engine as T  # noqa: E402
 
-print(T.test_ddpm_large_grid_vs_oracle(steps=250))
+print(T._ddpm_large_grid(250))
