@@ -1,0 +1,11 @@
+#!/bin/bash
+cd "$GRAFT_REPO_ROOT" || exit 1
+mkdir -p gpurun_out/c13
+export TMPDIR=/tmp
+python benchmarks/ring_check.py 2>&1 | grep -v amdgpu
+{
+python benchmarks/gemm_time.py 9 plain 2>&1 | grep -v amdgpu
+DVD_GEMM_RING=1 python benchmarks/gemm_time.py 9 plain --lab 2>&1 | grep -v amdgpu
+python benchmarks/gemm_time.py 9 plain 2>&1 | grep -v amdgpu
+DVD_GEMM_RING=1 python benchmarks/gemm_time.py 9 plain --lab 2>&1 | grep -v amdgpu
+} > gpurun_out/c13/gemm_ring.txt; cat gpurun_out/c13/gemm_ring.txt

@@ -962,6 +962,9 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_big16_kernel(GemmArgs p) {
 // three 48-KiB stages (prefetch distance two slabs) fit the LDS.  Same 256 x 256 tile, wave layout, persistent tile
 // walk and epilogue as gemm_nt_big_kernel.  64-byte LDS rows: 16-byte chunk c of row r lives at c ^ ((r >> 2) & 3).
 // ================================================================================================
+// SPLIT = false (lab build, DVD_GEMM_RING=1): the same 3-stage skewed pipeline on ONE weight tensor - a stage is [A | B], a
+// wave has 8 MFMAs per half slab; measured against gemm_nt_big_kernel for the dithered weights.
+template <bool SPLIT>
 __global__ void __launch_bounds__(512, 2) gemm_nt_split_kernel(GemmArgs p) {
   constexpr int BK = 32, TILE = 256 * 64, STAGE = 3 * TILE, NST = 3;
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [3 stages][A | B | Blo]
@@ -979,7 +982,7 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_split_kernel(GemmArgs p) {
   const int bm0 = tm * 256, bn0 = tn * 256;
   const _Float16* A = (const _Float16*)p.A + z * p.sA;
   const _Float16* B = (const _Float16*)p.B + z * p.sB;
-  const _Float16* Blo = (const _Float16*)p.Blo + z * p.sB;
+  const _Float16* Blo = SPLIT ? (const _Float16*)p.Blo + z * p.sB : B;
 
   // per-lane source offsets of this wave's 2 + 2 + 2 loads (1 KiB = 16 rows x 64 B each)
   unsigned aoff[2], boff[2];
@@ -1018,13 +1021,14 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_split_kernel(GemmArgs p) {
     const unsigned l_ = lds0 + (stage_) * STAGE + (2 * wave) * 1024;                                     \
     glds_one4(Atile + kb_, aoff[0], l_);            glds_one4(Atile + kb_, aoff[1], l_ + 1024);          \
     glds_one4(Btile + kb_, boff[0], l_ + TILE);     glds_one4(Btile + kb_, boff[1], l_ + TILE + 1024);   \
-    glds_one4(Ltile + kb_, boff[0], l_ + 2 * TILE); glds_one4(Ltile + kb_, boff[1], l_ + 2 * TILE + 1024); \
+    if constexpr (SPLIT) { glds_one4(Ltile + kb_, boff[0], l_ + 2 * TILE); glds_one4(Ltile + kb_, boff[1], l_ + 2 * TILE + 1024); } \
   }
 #define SB() __builtin_amdgcn_sched_barrier(0)
   // prologue: slabs 0 and 1 (clamped: K = 32 has a single slab)
   SPLIT_ISSUE(0, 0)
   SPLIT_ISSUE(min(1, nk - 1), 1)
-  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");     // slab 0 landed (this wave's part); slab 1 may be in flight
+  if constexpr (SPLIT) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // slab 0 landed (this wave's part); slab 1 may be in flight
+  else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
   __syncthreads();
   // The loop is skewed by half a slab so that no wave ever starts a slab with cold fragment registers: the barrier
   // that publishes slab kt + 1 sits in the MIDDLE of slab kt, and the second half of slab kt already reads the first
@@ -1036,7 +1040,7 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_split_kernel(GemmArgs p) {
     _Pragma("unroll") for (int m = 0; m < 4; ++m) fa[set_][m] = *(const half8*)((base_) + a_base + m * 32 * 64 + frag[ks_]); \
     _Pragma("unroll") for (int n = 0; n < 2; ++n) {                                                   \
       fh[set_][n] = *(const half8*)((base_) + b_base + n * 32 * 64 + frag[ks_]);                      \
-      fl[set_][n] = *(const half8*)((base_) + l_base + n * 32 * 64 + frag[ks_]);                      \
+      if constexpr (SPLIT) fl[set_][n] = *(const half8*)((base_) + l_base + n * 32 * 64 + frag[ks_]); \
     }                                                                                                 \
   }
   // 16 MFMAs of one k-step (8 hi then 8 lo: an accumulator is revisited after 8 others); the 8 fragment reads of the
@@ -1047,12 +1051,14 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_split_kernel(GemmArgs p) {
       _Pragma("unroll") for (int n = 0; n < 2; ++n) acc[m][n] = mfma32_f16(fa[set_][m], fh[set_][n], acc[m][n]); \
       fa[nset_][m] = *(const half8*)((nbase_) + a_base + m * 32 * 64 + frag[nks_]);                   \
       if (m < 2) fh[nset_][m] = *(const half8*)((nbase_) + b_base + m * 32 * 64 + frag[nks_]);        \
-      else fl[nset_][m - 2] = *(const half8*)((nbase_) + l_base + (m - 2) * 32 * 64 + frag[nks_]);    \
+      else if constexpr (SPLIT) fl[nset_][m - 2] = *(const half8*)((nbase_) + l_base + (m - 2) * 32 * 64 + frag[nks_]); \
       SB();                                                                                           \
     }                                                                                                 \
-    _Pragma("unroll") for (int m = 0; m < 4; ++m) {                                                   \
-      _Pragma("unroll") for (int n = 0; n < 2; ++n) acc[m][n] = mfma32_f16(fa[set_][m], fl[set_][n], acc[m][n]); \
-      SB();                                                                                           \
+    if constexpr (SPLIT) {                                                                            \
+      _Pragma("unroll") for (int m = 0; m < 4; ++m) {                                                 \
+        _Pragma("unroll") for (int n = 0; n < 2; ++n) acc[m][n] = mfma32_f16(fa[set_][m], fl[set_][n], acc[m][n]); \
+        SB();                                                                                         \
+      }                                                                                               \
     }                                                                                                 \
   }
   SPLIT_READ(0, smem, 0)
@@ -1078,16 +1084,18 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_split_kernel(GemmArgs p) {
         for (int n = 0; n < 2; ++n) acc[m][n] = mfma32_f16(fa[1][m], fh[1][n], acc[m][n]);
         fa[0][m] = *(const half8*)(nb + a_base + m * 32 * 64 + frag[0]);
         if (m < 2) fh[0][m] = *(const half8*)(nb + b_base + m * 32 * 64 + frag[0]);
-        else fl[0][m - 2] = *(const half8*)(nb + l_base + (m - 2) * 32 * 64 + frag[0]);
+        else if constexpr (SPLIT) fl[0][m - 2] = *(const half8*)(nb + l_base + (m - 2) * 32 * 64 + frag[0]);
         SB();
       }
       if (wave >= 4) SPLIT_ISSUE(min(kt + 2, nk - 1), n2)
       SB();
+      if constexpr (SPLIT) {
 #pragma unroll
-      for (int m = 0; m < 4; ++m) {
+        for (int m = 0; m < 4; ++m) {
 #pragma unroll
-        for (int n = 0; n < 2; ++n) acc[m][n] = mfma32_f16(fa[1][m], fl[1][n], acc[m][n]);
-        SB();
+          for (int n = 0; n < 2; ++n) acc[m][n] = mfma32_f16(fa[1][m], fl[1][n], acc[m][n]);
+          SB();
+        }
       }
     }
     cur = n1;
@@ -1401,14 +1409,30 @@ extern "C" int dvd_gemm_nt(const dvd_gemm_desc* d, void* stream) {
     constexpr int LDS = 3 * 3 * 256 * 64;
     static DeviceOnce once_s;
     if (const auto bit = DeviceOnce::current_bit(); once_s.need(bit)) {
-      (void)hipFuncSetAttribute((const void*)gemm_nt_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+      (void)hipFuncSetAttribute((const void*)gemm_nt_split_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
       once_s.done(bit);
     }
     int nblk = p.ntm * p.ntn;
     if (nblk > 256) nblk = 256;
-    gemm_nt_split_kernel<<<dim3(nblk, d->batch), 512, LDS, (hipStream_t)stream>>>(p);
+    gemm_nt_split_kernel<true><<<dim3(nblk, d->batch), 512, LDS, (hipStream_t)stream>>>(p);
     return check_launch("gemm_nt(split)");
   }
+#ifdef DVD_LAB
+  if (big && !d->B_lo && !d->A_lo && d->K % 32 == 0 && getenv("DVD_GEMM_RING")) {
+    // lab: the split kernel's 3-stage skewed pipeline on one weight tensor, for A/B runs against gemm_nt_big_kernel
+    p.ntm = cdiv(d->M, 256); p.ntn = d->N / 256;
+    constexpr int LDS = 3 * 3 * 256 * 64;
+    static DeviceOnce once_r;
+    if (const auto bit = DeviceOnce::current_bit(); once_r.need(bit)) {
+      (void)hipFuncSetAttribute((const void*)gemm_nt_split_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+      once_r.done(bit);
+    }
+    int nblk = p.ntm * p.ntn;
+    if (nblk > 256) nblk = 256;
+    gemm_nt_split_kernel<false><<<dim3(nblk, d->batch), 512, LDS, (hipStream_t)stream>>>(p);
+    return check_launch("gemm_nt(ring, lab)");
+  }
+#endif
 #ifdef DVD_LAB
   if (big && !d->B_lo && !d->A_lo && p.vec_epilogue && !d->pos && !d->gate && getenv("DVD_GEMM_M16")) {
     // lab: the 16x16x32-MFMA variant of the 256 x 256 kernel (measured 1-7 % slower, see gemm_nt_big16_kernel)
