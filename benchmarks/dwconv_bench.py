@@ -12,6 +12,12 @@ def t(fn, it=20):
     for _ in range(it): fn()
     e1.record(); torch.cuda.synchronize(); return e0.elapsed_time(e1) / it
 f = lambda: ops.dwconv3x3(x, w, b, n, side)
-print("row4 ms", t(f))
+gb = 2.0 * n * side * side * c * 2 / 1e9          # f16 in + f16 out
+for tx, ty in (("4", "1"), ("4", "2"), ("2", "2"), ("2", "4"), ("2", "8"), ("1", "4"), ("1", "8")):
+    if True:
+        os.environ["DVD_DWCONV_TY"], os.environ["DVD_DWCONV_TX"] = ty, tx
+        ms = t(f)
+        print(f"{tx} x {ty} tokens per thread: {ms:.3f} ms  {gb / ms * 1e3:.0f} GB/s")
 os.environ["DVD_DWCONV_V1"] = "1"
-print("v1   ms", t(f))
+ms = t(f)
+print(f"one token per thread (v1): {ms:.3f} ms  {gb / ms * 1e3:.0f} GB/s")

@@ -269,11 +269,15 @@ __global__ void __launch_bounds__(256) dwconv3x3_kernel(const _Float16* __restri
   *(half8*)(out + tok * c + ch) = o;
 }
 
-// Same op, one thread per (4 consecutive tokens of a grid row, 8 channels): the 3 x 6 input taps and the 9 weight
-// vectors are loaded once for 4 outputs (9 loads per token instead of 27).  Sums in the same tap order as
-// dwconv3x3_kernel, so the results are bit-identical.
-constexpr int DW_TX = 4;
-__global__ void __launch_bounds__(256) dwconv3x3_row4_kernel(const _Float16* __restrict__ in,
+// Same op, one thread per (4 consecutive tokens of a grid row x TY consecutive rows, 8 channels): each input row's 6 taps
+// are loaded ONCE and feed the up-to-three output rows they belong to (a sliding window over y), so a thread issues
+// (TY + 2) x 6 sixteen-byte loads for 4 TY outputs - 4.5 loads per output at TY = 1 (round 1's kernel), 3.0 at TY = 2,
+// 2.25 at TY = 4 (the one-token kernel above: 9).  Every output still sums its taps in the order dy = -1, 0, 1 / dx = -1, 0,
+// 1 of dwconv3x3_kernel, skipping the same out-of-range taps, so the results are bit-identical.
+constexpr int DW_TX_P = 2, DW_TY_P = 4;      // product: 2 x 4 tokens per thread - measured (MI355X, 16 x 144 x 144 x 2048):
+                                             // 4x1 1.26 ms (round 1's kernel), 4x2 1.20, 2x2 1.10, 2x4 1.07, 2x8 1.29, 1x4 1.52
+template <int DW_TX, int TY>
+__global__ void __launch_bounds__(256) dwconv3x3_tile_kernel(const _Float16* __restrict__ in,
                                                              _Float16* __restrict__ out, const float* __restrict__ w,
                                                              const float* __restrict__ b, int side, int c, long total) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -281,56 +285,68 @@ __global__ void __launch_bounds__(256) dwconv3x3_row4_kernel(const _Float16* __r
   const int c8 = c >> 3;
   const int ch = (int)(idx % c8) * 8;
   long rest = idx / c8;
-  const int xg = (side + DW_TX - 1) / DW_TX;
+  const int xg = (side + DW_TX - 1) / DW_TX, yg = (side + TY - 1) / TY;
   const int tx0 = (int)(rest % xg) * DW_TX;
   rest /= xg;
-  const int ty = (int)(rest % side);
-  const long n = rest / side;
-  const long row_tok = (n * side + ty) * side;            // token index of (n, ty, 0)
-  float acc[DW_TX][8];
+  const int ty0 = (int)(rest % yg) * TY;
+  const long n = rest / yg;
+  const long img_tok = n * side * side;                  // token index of (n, 0, 0)
+  float acc[TY][DW_TX][8];
   {
     const floatx4 b0 = *(const floatx4*)(b + ch), b1 = *(const floatx4*)(b + ch + 4);
 #pragma unroll
-    for (int k = 0; k < DW_TX; ++k)
+    for (int j = 0; j < TY; ++j)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) { acc[k][e] = b0[e]; acc[k][4 + e] = b1[e]; }
+      for (int k = 0; k < DW_TX; ++k)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { acc[j][k][e] = b0[e]; acc[j][k][4 + e] = b1[e]; }
   }
 #pragma unroll
-  for (int dy = -1; dy <= 1; ++dy) {
-    const int yy = ty + dy;
+  for (int rr = -1; rr <= TY; ++rr) {                    // input row ty0 + rr feeds output rows j = rr - 1, rr, rr + 1
+    const int yy = ty0 + rr;
     if (yy < 0 || yy >= side) continue;
     half8 v[DW_TX + 2];
 #pragma unroll
-    for (int j = 0; j < DW_TX + 2; ++j) {
-      const int xx = tx0 - 1 + j;
-      if (xx >= 0 && xx < side) v[j] = *(const half8*)(in + (row_tok + (long)dy * side + xx) * c + ch);
+    for (int i = 0; i < DW_TX + 2; ++i) {
+      const int xx = tx0 - 1 + i;
+      if (xx >= 0 && xx < side) v[i] = *(const half8*)(in + (img_tok + (long)yy * side + xx) * c + ch);
       else
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[j][e] = (_Float16)0.f;
+        for (int e = 0; e < 8; ++e) v[i][e] = (_Float16)0.f;
     }
 #pragma unroll
-    for (int dx = -1; dx <= 1; ++dx) {
-      const float* wp = w + ((dy + 1) * 3 + (dx + 1)) * c + ch;
-      const floatx4 w0 = *(const floatx4*)wp, w1 = *(const floatx4*)(wp + 4);
+    for (int j = 0; j < TY; ++j) {
+      const int dy = rr - j;                             // this input row is tap row dy of output row ty0 + j
+      if (dy < -1 || dy > 1) continue;
+      if (ty0 + j >= side) continue;
 #pragma unroll
-      for (int k = 0; k < DW_TX; ++k) {
-        const int xx = tx0 + k + dx;
-        if (xx < 0 || xx >= side) continue;          // same skipped taps as the scalar kernel (keeps -0/+0 identical)
+      for (int dx = -1; dx <= 1; ++dx) {
+        const float* wp = w + ((dy + 1) * 3 + (dx + 1)) * c + ch;
+        const floatx4 w0 = *(const floatx4*)wp, w1 = *(const floatx4*)(wp + 4);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          acc[k][e] += (float)v[k + 1 + dx][e] * w0[e];
-          acc[k][4 + e] += (float)v[k + 1 + dx][4 + e] * w1[e];
+        for (int k = 0; k < DW_TX; ++k) {
+          const int xx = tx0 + k + dx;
+          if (xx < 0 || xx >= side) continue;          // same skipped taps as the scalar kernel (keeps -0/+0 identical)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            acc[j][k][e] += (float)v[k + 1 + dx][e] * w0[e];
+            acc[j][k][4 + e] += (float)v[k + 1 + dx][4 + e] * w1[e];
+          }
         }
       }
     }
   }
 #pragma unroll
-  for (int k = 0; k < DW_TX; ++k) {
-    if (tx0 + k >= side) break;
-    half8 o;
+  for (int j = 0; j < TY; ++j) {
+    if (ty0 + j >= side) break;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = (_Float16)fmaxf(acc[k][e], 0.f);
-    *(half8*)(out + (row_tok + tx0 + k) * c + ch) = o;
+    for (int k = 0; k < DW_TX; ++k) {
+      if (tx0 + k >= side) break;
+      half8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (_Float16)fmaxf(acc[j][k][e], 0.f);
+      *(half8*)(out + (img_tok + (long)(ty0 + j) * side + tx0 + k) * c + ch) = o;
+    }
   }
 }
 
@@ -601,9 +617,27 @@ extern "C" int dvd_dwconv3x3(const void* in16, void* out16, const float* w9c, co
     return check_launch("dwconv3x3(lab v1)");
   }
 #endif
-  const long total = (long)n * side * cdiv(side, DW_TX) * (c / 8);
-  dwconv3x3_row4_kernel<<<cdiv(total, 256), 256, 0, (hipStream_t)stream>>>((const _Float16*)in16, (_Float16*)out16, w9c,
-                                                                           b, side, c, total);
+  int ty = DW_TY_P, tx = DW_TX_P;
+#ifdef DVD_LAB
+  if (const char* e = getenv("DVD_DWCONV_TY")) ty = atoi(e);      // lab: 1 = round 1's row kernel, 2, 4
+  if (const char* e = getenv("DVD_DWCONV_TX")) tx = atoi(e);      // lab: 2 or 4 tokens along the row
+#endif
+  const long total = (long)n * cdiv(side, ty) * cdiv(side, tx) * (c / 8);
+  const dim3 grd(cdiv(total, 256));
+#define DW_LAUNCH(TX_, TY_) dwconv3x3_tile_kernel<TX_, TY_><<<grd, 256, 0, (hipStream_t)stream>>>((const _Float16*)in16, (_Float16*)out16, w9c, b, side, c, total)
+#ifdef DVD_LAB
+  if (tx == 2 && ty == 2) DW_LAUNCH(2, 2);
+  else if (tx == 2 && ty == 4) DW_LAUNCH(2, 4);
+  else if (tx == 2 && ty == 8) DW_LAUNCH(2, 8);
+  else if (tx == 1 && ty == 4) DW_LAUNCH(1, 4);
+  else if (tx == 1 && ty == 8) DW_LAUNCH(1, 8);
+  else if (tx == 2) DW_LAUNCH(2, 1);
+  else if (ty == 1) DW_LAUNCH(4, 1);
+  else if (ty == 4) DW_LAUNCH(4, 4);
+  else
+#endif
+  DW_LAUNCH(DW_TX_P, DW_TY_P);
+#undef DW_LAUNCH
   return check_launch("dwconv3x3");
 }
 

@@ -81,17 +81,25 @@ def test_dwconv_bn_relu(ops, side):
 
 
 @pytest.mark.parametrize("side", [8, 7, 13])
-def test_dwconv_row4_equals_v1(ops, lab, monkeypatch, side):
-    """Lab build: the product kernel (4 tokens per thread along a grid row) against the one-token-per-thread kernel it
-    replaced (DVD_DWCONV_V1=1): same tap order -> bit-identical."""
+def test_dwconv_tile_kernels_equal_v1(ops, lab, monkeypatch, side):
+    """Lab build: the tile kernels (4 tokens along a grid row x TY rows per thread, sliding window over the input rows; the
+    product runs 2 x 4) against the one-token-per-thread kernel (DVD_DWCONV_V1=1): same tap order -> bit-identical, incl.
+    odd sides (ragged last row / column group)."""
     n, c = 2, 2048
     x16 = rnd("dw/x", (n * side * side, c), -1, 2).half().contiguous()
     w9c = rnd("dw/w9", (9, c), -0.5, 0.5)
     b = rnd("dw/b", (c,), -0.3, 0.3)
-    out = ops.dwconv3x3(x16.cuda(), w9c.cuda(), b.cuda(), n, side).float().cpu()
+    outs = {}
+    for tx, ty in (("4", "1"), ("4", "2"), ("4", "4"), ("2", "1"), ("2", "2"), ("2", "4"), ("2", "8"), ("1", "4"), ("1", "8")):
+        monkeypatch.setenv("DVD_DWCONV_TY", ty)
+        monkeypatch.setenv("DVD_DWCONV_TX", tx)
+        outs[tx + "x" + ty] = ops.dwconv3x3(x16.cuda(), w9c.cuda(), b.cuda(), n, side).float().cpu()
+    monkeypatch.delenv("DVD_DWCONV_TY")
+    monkeypatch.delenv("DVD_DWCONV_TX")
     monkeypatch.setenv("DVD_DWCONV_V1", "1")
     out_v1 = ops.dwconv3x3(x16.cuda(), w9c.cuda(), b.cuda(), n, side).float().cpu()
-    assert torch.equal(out, out_v1)
+    for ty, o in outs.items():
+        assert torch.equal(o, out_v1), ty
 
 
 def test_adaptive_posenc(ops):
