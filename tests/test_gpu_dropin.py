@@ -231,3 +231,29 @@ def test_plugin_run_without_prestage_nets_and_from_npz(tmp_path, monkeypatch):
     got = val_TDiff.run(s2)
     for (pa, a), (pb, b) in zip(want, got):
         assert pa == pb and torch.equal(a, b), pa
+
+
+def test_run_sampling_command_line(tmp_path):
+    """The reference's command line itself (run_sampling.py:66-87), as a child process with the working directory laid out
+    like the repository root (the launcher copies train_settings/<module>/<name>.py and writes checkpoints/ and vis_hp/
+    relative to it): `python run_sampling.py --train_module dvd --train_name val_TDiff --name cli` on the default settings
+    (admin/local.py: G = 64, 3 DDIM steps, 2 hypotheses, 4 synthetic page images, pre-stage nets on) writes one dewarped
+    PNG per document where the reference writes them."""
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    for name in ("admin", "train_settings", "dvd_amd"):
+        os.symlink(os.path.join(root, name), tmp_path / name, target_is_directory=True)
+    os.symlink(os.path.join(root, "run_sampling.py"), tmp_path / "run_sampling.py")
+    env = dict(os.environ, PYTHONPATH=str(tmp_path))
+    r = subprocess.run([sys.executable, "run_sampling.py", "--train_module", "dvd", "--train_name", "val_TDiff", "--name", "cli"],
+                       cwd=tmp_path, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "sampling complete" in r.stdout + r.stderr
+    out = tmp_path / "vis_hp" / "synthetic" / "cli" / "dewarped_pred"
+    pngs = sorted(p.name for p in out.glob("warped_*.png"))
+    assert pngs == [f"warped_synthetic_{i:05d}.png" for i in range(4)], pngs
+    from PIL import Image
+    im = Image.open(out / pngs[0])
+    assert im.size == (768, 1024) and im.mode == "RGB"
+    assert (tmp_path / "checkpoints" / "train_settings" / "dvd" / "val_TDiff" / "val_TDiff.py").exists()   # the launcher's copy (:43-46)
