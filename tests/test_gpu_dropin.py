@@ -245,7 +245,13 @@ def test_run_sampling_command_line(tmp_path):
     for name in ("admin", "train_settings", "dvd_amd"):
         os.symlink(os.path.join(root, name), tmp_path / name, target_is_directory=True)
     os.symlink(os.path.join(root, "run_sampling.py"), tmp_path / "run_sampling.py")
-    env = dict(os.environ, PYTHONPATH=str(tmp_path))
+    import socket
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    # its own rendezvous port: this pytest process may still hold the default one from an earlier run() in the session
+    env = dict(os.environ, PYTHONPATH=str(tmp_path), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     r = subprocess.run([sys.executable, "run_sampling.py", "--train_module", "dvd", "--train_name", "val_TDiff", "--name", "cli"],
                        cwd=tmp_path, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
