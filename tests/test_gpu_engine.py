@@ -261,29 +261,6 @@ def test_ddpm_large_grid_vs_oracle():
     _ddpm_large_grid(40)
 
 
-def test_ddpm_250_steps_plain_family_vs_oracle():
-    """The same 250-step ancestral loop on the PLAIN weight family (x0 grows to |x0| >> 1: most pixels saturate the
-    final clamp, so only the clamped map is comparable with round 2's record)."""
-    from dvd_amd import sampler, schedule
-    from oracle import dvd_oracle as O
-    grid, steps = 16, 250
-    eng, orc, doc_t, inv1 = setup(grid)
-    tab = schedule.Tables(schedule.named_betas("cosine", steps))
-    xT = torch.from_numpy(synth.synth_noise(0, 2, grid, SEED_IN))
-    noises = {i: torch.from_numpy(synth.synth_noise(0, 2, grid, SEED_IN, step=i)) for i in range(steps)}
-    tr_ref, tr = [], []
-    ref = orc.sample_loop(O.Schedule(steps), xT, {k: v[:1] for k, v in doc_t.items()}, sampler="ddpm", noises=noises,
-                          trace=tr_ref)
-    out = sampler.sample(eng, tab, xT.cuda(), sampler="ddpm", noise_fn=lambda i: noises[i].cuda(), trace=tr)
-    per = [float((a.cpu() - b).pow(2).mean().sqrt()) for a, b in zip(tr, tr_ref)]
-    err = float((out.cpu() - ref).pow(2).mean().sqrt())
-    rel_last = per[-1] / float(tr_ref[-1].std())
-    print(f"ddpm 250 (plain family): final {err:.2e}, un-clamped last x0 {per[-1]:.2e} on std {float(tr_ref[-1].std()):.2f} "
-          f"(relative {rel_last:.2e}), saturated pixels {_saturated(tr_ref[-1]):.3f}")
-    assert err < 1e-3, (err, per[-1])
-    assert rel_last < 1e-3, rel_last
-
-
 def test_batched_documents_match_single():
     """Two documents x two hypotheses in one engine == each document alone (no cross-document math)."""
     from dvd_amd import sampler, schedule
