@@ -91,10 +91,15 @@ __device__ __forceinline__ void tile_coords(int vid, int ntm, int ntn, int& tm, 
 }
 
 
+// GELU(tanh) (timm Mlp's act layer, idf/cross_model.py:163-174):  0.5 x (1 + tanh u) = x sigmoid(2 u) = x / (1 + exp(-2 u)),
+// u = k0 (x + k1 x^3).  Written with ONE exponential and one reciprocal (v_exp_f32 / v_rcp_f32, ~1 ulp each: 1e-7 relative
+// on a value that is then rounded to f16) instead of tanhf, whose library expansion is ~4x the instructions and a branch:
+// fc1's epilogue applies it to 2 G elements per evaluation and was half of that GEMM's 3.8 ms (K = 384: six K slabs per
+// tile).  x -> -inf gives -0, x -> +inf gives x, NaN propagates - as the tanh form.
 __device__ __forceinline__ float gelu_tanh(float x) {
   const float k0 = 0.7978845608028654f, k1 = 0.044715f;
-  float u = k0 * (x + k1 * x * x * x);
-  return 0.5f * x * (1.f + tanhf(u));
+  const float u = k0 * (x + k1 * x * x * x);
+  return __fdividef(x, 1.f + __expf(-2.f * u));
 }
 
 // Epilogue of one 32x32 accumulator tile (rows row0 + cd_row(i,h), column col).  Kept as a function so the
