@@ -607,6 +607,7 @@ static int enqueue_step(Engine* e, const float* x_t, int feat_mode, const float*
   const int T = (int)e->T;
   const long NT = e->NT;
   const int F16 = e->small_tiles ? 2 : 0;     // gemm() dtype code: f16 operands, 128x128 tiles on small grids
+  constexpr int F16S = 2;                     // ... and 128x128 tiles on every grid (a function of the GEMM, not of the batch)
 
   float* tbuf = (float*)e->B(e->bi.tbuf);
   float* th = (float*)e->B(e->bi.th);
@@ -648,7 +649,10 @@ static int enqueue_step(Engine* e, const float* x_t, int feat_mode, const float*
            0, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0, stream, nullptr, e->L(e->wi.ca_wq16)));
   TRY(gemm(F16, (int)NT, HID, HID, 1, rtok16, HID, 0, e->H(e->wi.ca_wk16), HID, 0, nullptr, 0, 0, kr16, HID, 0,
            e->F(e->wi.ca_bk), 0, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0, stream, nullptr, e->L(e->wi.ca_wk16)));
-  TRY(gemm(F16, HID, T, HID, N, e->H(e->wi.ca_wv16, true), HID, 0, rtok16, HID, (long)T * HID, nullptr, 0, 0, vtr16, T,
+  // (the two 384 x T x 384 V^T projections take the 128 x 128 kernel on every grid: K = 384 is six 64-deep slabs and a
+  //  token panel is read by two row tiles only, so the 256 x 256 kernel - one workgroup per CU, every slab's loads waited
+  //  for at its end - runs them latency-bound: 2.13 vs 0.93 ms and 0.58 vs 0.21 ms at the bench shape, benchmarks/gemm_vt384_time.py)
+  TRY(gemm(F16S, HID, T, HID, N, e->H(e->wi.ca_wv16, true), HID, 0, rtok16, HID, (long)T * HID, nullptr, 0, 0, vtr16, T,
            (long)HID * T, e->F(e->wi.ca_bv), 1, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0, stream, e->L(e->wi.ca_wv16, true), nullptr));
   {
     const int kn[3] = {e->bi.kc16, e->bi.km16, e->bi.kl16};
@@ -669,7 +673,7 @@ static int enqueue_step(Engine* e, const float* x_t, int feat_mode, const float*
                          stream));
   TRY(gemm(F16, (int)(4 * NT), 2 * HID, HID, 1, h16, HID, 0, e->H(e->wi.sa_wqk16, true), HID, 0, nullptr, 0, 0, qk16, 2 * HID, 0,
            e->F(e->wi.sa_bqk), 0, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0, stream, nullptr, e->L(e->wi.sa_wqk16, true)));
-  TRY(gemm(F16, HID, T, HID, 4 * N, e->H(e->wi.sa_wv16, true), HID, 0, h16, HID, (long)T * HID, nullptr, 0, 0, vt16, T,
+  TRY(gemm(F16S, HID, T, HID, 4 * N, e->H(e->wi.sa_wv16, true), HID, 0, h16, HID, (long)T * HID, nullptr, 0, 0, vt16, T,
            (long)HID * T, e->F(e->wi.sa_bv), 1, 0, nullptr, 0, nullptr, 0, nullptr, 0, 0, stream, e->L(e->wi.sa_wv16, true), nullptr));
   TRY(attn(64, 6, 4 * N, T, T, 1, qk16, 2 * HID, (long)T * 2 * HID, qk16 + HID, 2 * HID, (long)T * 2 * HID, vt16, T,
            (long)HID * T, att16, HID, (long)T * HID, 0.125f, stream));
