@@ -305,7 +305,8 @@ int dvd_engine_set_tensor(void* handle, const char* name, const void* dev_ptr, l
  *   "dither"        (default: 1 when the grid takes the 256-wide GEMM kernels, i.e. grid >= 66, else 0): the weights of
  *                                the 256-wide per-step GEMMs are re-rounded to ONE f16 before every evaluation with a
  *                                step-dependent sub-ulp offset (dvd_dither_f16: zero-mean over the steps) and those
- *                                GEMMs run one pass - half the MFMAs of the split; the other GEMMs keep the (hi, lo) pair;
+ *                                GEMMs run one pass - half the MFMAs of the split; the other GEMMs keep the (hi, lo) pair
+ *                                (no effect on small-tile grids, which keep the pair everywhere);
  *   "dither_step"              : the evaluation counter the next denoise_step dithers with (it then increments); the
  *                                sampler sets it to the loop index so a roll-out does not depend on the handle's history;
  *   "ffn_lo"        (default 1): 0 drops the lo pass of the decoder FFN's two 1x1 convs only (-4.8 % step time;
