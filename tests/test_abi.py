@@ -37,8 +37,8 @@ def test_product_library_reads_no_environment_and_ships_no_experiments():
     dyn = subprocess.run(["nm", "-D", so], capture_output=True, text=True, check=True).stdout
     assert "getenv" not in dyn
     blob = open(so, "rb").read()
-    for needle in (b"DVD_ATTN_", b"DVD_GEMM_", b"DVD_WARP_", b"flash_attn_pipe_kernel", b"flash_attn_dsplit_kernel",
-                   b"flash_attn_glds64x2_kernel"):
+    for needle in (b"DVD_ATTN_", b"DVD_GEMM_", b"DVD_WARP_", b"DVD_DWCONV_", b"flash_attn_pipe_kernel", b"flash_attn_dsplit_kernel",
+                   b"flash_attn_glds64x2_kernel", b"gemm_nt_big16_kernel", b"DVD_HIP_LIB"):
         assert needle not in blob, needle
     assert "dvd_attn_debug_stamps" not in dyn and "dvd_gemm_debug_stamps" not in dyn
 
