@@ -2,7 +2,10 @@
 """Headline benchmark: documents/second of the DvD sampling path on MI355X.
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+  N > 1 works both ways: under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...`
+  (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment), and typed bare - `python bench.py --gpus N` with no
+  WORLD_SIZE set starts its own N rank processes (launch_ranks: fresh children, one per GPU, 127.0.0.1 rendezvous;
+  the parent never touches the GPU) and relays rank 0's line.
 
 One "step" = one pass of the hot path over one batch of documents (BASELINE.json configs[1]):
   8 documents x 2 hypotheses per GPU, 50-step DDIM on the 288x288 coordinate grid
@@ -99,6 +102,61 @@ def broadcast_weights(blob, world, sync=None):
     return (time.perf_counter() - t0) * 1e3
 
 
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` typed without a launcher: start N fresh rank processes of this same script (one per
+    GPU, env:// rendezvous on 127.0.0.1 - the reference's own set-up, idf/dist_util.py:21-41, minus MPI), let them print
+    (only rank 0 does), and return the worst exit code.  The parent has not touched the GPU and never will: nothing is
+    re-exec'd, the ranks are children."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get(
+                       "HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+    worst, failed_at = 0, None
+    while any(p.poll() is None for p in procs):
+        for p in procs:
+            rc = p.poll()
+            if rc not in (None, 0) and failed_at is None:
+                failed_at = time.monotonic()            # a rank died: the others would wait in a collective for ever
+        if failed_at is not None and time.monotonic() - failed_at > 20.0:
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()                        # by handle, never by pattern
+        time.sleep(0.2)
+    for p in procs:
+        rc = p.wait()
+        worst = worst if rc == 0 else (rc if worst == 0 else worst)
+    return worst
+
+
+def ranks_seen(world, rank, local, backend):
+    """All-gathered (rank, local rank, current device, device name) of every rank plus the collective library's version:
+    evidence on the line that N distinct GPUs took part and which RCCL carried the broadcast."""
+    me = {"rank": rank, "local_rank": local}
+    if torch.cuda.is_available():
+        me["device"] = int(torch.cuda.current_device())
+        me["name"] = torch.cuda.get_device_name(me["device"])
+    allr = [None] * world
+    if world > 1:
+        dist.all_gather_object(allr, me)
+    else:
+        allr = [me]
+    ver = None
+    if backend == "nccl":
+        try:
+            ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:           # noqa: BLE001 - version query only
+            ver = None
+    return {"ranks": allr, "backend": backend + (" (RCCL)" if backend == "nccl" else ""), "rccl_version": ver}
+
+
 def max_over_ranks(elapsed, world, dev):
     if world == 1:
         return elapsed
@@ -127,14 +185,21 @@ def main(argv=None):
     ap.add_argument("--backend", default="nccl", help="process-group backend (nccl = RCCL; the CPU test of the rank logic uses gloo)")
     args = ap.parse_args(argv)
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # typed bare: be our own launcher (before anything touches the GPU in this process)
+        rc = launch_ranks(args.gpus, sys.argv[1:] if argv is None else argv)
+        if rc != 0:
+            raise SystemExit(rc)
+        return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's world size and --gpus must agree")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     init_dist(world, local, backend=args.backend)
+    seen = ranks_seen(world, rank, local, args.backend)
 
     from dvd_amd import lib, ops, sampler, schedule, synth
     from dvd_amd.engine import Engine, aligned_empty
@@ -315,12 +380,12 @@ def main(argv=None):
             t_first = tab.model_time(S - 1)
             eng.prepare(y512, mask_cat, mask_y512, line_msk)
             x0_first = eng.denoise(x_T, schedule.embedded_time(t_first), sampler.feat_mode_for(t_first, B * H, True),
-                                   torch.zeros_like(x_T)).clone()
+                                   torch.zeros_like(x_T), dither_step=0).clone()
             # a second evaluation on the WARPED-feature branch (feat_mode 2: t_model <= 600, init_flow = previous x0,
             # init_feat = grid_sample(feat, (x0 + base) * 2 - 1)) - the branch every step but the first few takes
             i_mid = max(i for i in range(S) if tab.model_time(i) <= 600.0)
             t_mid = tab.model_time(i_mid)
-            x0_mid = eng.denoise(x_T, schedule.embedded_time(t_mid), 2, x0_first).clone()
+            x0_mid = eng.denoise(x_T, schedule.embedded_time(t_mid), 2, x0_first, dither_step=S - 1 - i_mid).clone()
             check = {"doc": [a[:1].float().cpu() for a in (y512, mask_cat, mask_y512, line_msk)], "x": x_T[:1].cpu(),
                      "t_model": float(t_first), "x0_gpu": x0_first[:1].cpu(),
                      "t_model_warp": float(t_mid), "x0_gpu_warp": x0_mid[:1].cpu()}
@@ -353,6 +418,7 @@ def main(argv=None):
                        "parallelism": f"dp{world} (documents sharded, one weight broadcast)"},
             "algorithmic_tflops": round(flops_total / elapsed / 1e12, 1),
             "weight_broadcast_ms": None if bcast_ms is None else round(bcast_ms, 2),
+            "ranks_seen": seen,
             "roofline": roof, "roofline_unwarp": roof_unwarp, "cpu_baseline": cpu,
             "other_configs": others,
         }

@@ -107,9 +107,12 @@ class DvdDenoiser(nn.Module):
 
     def forward(self, x, t, y=None, y512=None, mask_y512=None, init_flow=None, local_corr=None, trg_feat=None,
                 src_feat=None, src_64=None, mask_x=None, tv=None, source_0=None, tmode=None, line_msk=None,
-                mask_cat=None, init_feat=None, iter=False, mode=None):
+                mask_cat=None, init_feat=None, iter=False, mode=None, dither_step=None):
         """One denoiser evaluation with the reference's keyword surface (idf/cross_model.py:568-570):
-        returns (x0_pred [N,2,G,G], feat [N,256,G,G]).  Each sample is treated as its own document."""
+        returns (x0_pred [N,2,G,G], feat [N,256,G,G]).  Each sample is treated as its own document.
+        Like the reference's forward it is a PURE function of its arguments: on grids whose GEMM weights are dithered the
+        phase is `dither_step` when given (diffusion.ddim_sample / p_mean_variance pass the loop's S-1-i, so a hand-rolled
+        chain reproduces ddim_sample_loop bit for bit), else schedule.dither_phase(t) - never the engine's history."""
         if src_feat is not None or not (tv is True) or not iter:
             raise NotImplementedError("only the src_feat=None, tv=True, iter=True path is live (admin/local.py:27-29)")
         n, _, g, _ = x.shape
@@ -127,7 +130,8 @@ class DvdDenoiser(nn.Module):
             fmode, feat_in = 0, None
         else:
             fmode, feat_in = 3, f32(init_feat)
-        x0 = eng.denoise(f32(x), t_embed, fmode, flow, init_feat=feat_in)
+        phase = schedule.dither_phase(t0) if dither_step is None else int(dither_step)
+        x0 = eng.denoise(f32(x), t_embed, fmode, flow, init_feat=feat_in, dither_step=phase)
         if init_flow is None:
             pass  # the reference only adds init_flow when it is given (:645-646); zeros were used above
         return x0, eng.feat_nchw()

@@ -322,7 +322,6 @@ extern "C" int dvd_convnet_create_batched(const dvd_cn_op* ops, int n_ops, int n
         n->kpad[i] = kp;
         if (o.w_off != wf) return fail("weights must be packed in op order (w_off mismatch)", i);
         wf += (long)o.cout * kp + (o.cout + 3) / 4 * 4;   // bias padded to 16 bytes: every conv's weights stay 16-byte aligned
-        colmax = std::max(colmax, nb * a.h * a.w * kp * 4);
         d.h = a.h; d.w = a.w; d.c = o.cout;
         {
           // Small maps with wide channels (the UNet's deep layers: 324 ... 1296 pixels, K up to 9216) give the 128 x 128
@@ -338,6 +337,13 @@ extern "C" int dvd_convnet_create_batched(const dvd_cn_op* ops, int n_ops, int n
           }
           n->ksplit[i] = S;
           if (S > 1) partmax = std::max(partmax, nb * S * a.h * a.w * o.cout * 4);
+          // the im2col matrix is sized only for the convs that write one (the same two predicates convnet_run takes the
+          // implicit-GEMM kernel / the direct 1x1 read on): the 16 -> 64-channel 3x3 convs at full resolution would
+          // otherwise reserve 382 MB per image that nothing ever touches
+          const int cb = o.b >= 0 ? n->slots[o.b].c : 0;
+          const bool implicit = o.cout <= 64 && a.c % 8 == 0 && cb % 8 == 0 && (a.c + cb) % 16 == 0 && S == 1;
+          const bool direct = o.ks == 1 && o.b < 0 && a.c == kp;
+          if (!implicit && !direct) colmax = std::max(colmax, nb * a.h * a.w * kp * 4);
         }
         break;
       }

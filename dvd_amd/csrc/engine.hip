@@ -168,7 +168,8 @@ struct Engine {
   // temporal dithering of the f16 weight rounding (dither.hip): the 256-wide GEMMs read a per-evaluation re-rounded
   // single-f16 copy of their weight (buffer w16dith) and run ONE pass; everything else keeps the (hi, lo) pair
   bool dither = false;
-  unsigned dither_step = 0;            // evaluation counter fed to the next dvd_dither_f16 (then incremented)
+  unsigned dither_step = 0;            // dithering phase of every evaluation until the option is set again (NO hidden counter:
+                                       // an evaluation is a pure function of its inputs and the handle's options)
   std::vector<long> dith_off;          // per weight index: element offset of its copy inside w16dith, or -1
   std::vector<int> dith_list;          // weight indices that have a copy
   long dith_total = 0;
@@ -757,7 +758,6 @@ extern "C" int dvd_engine_denoise_step(void* handle, const float* x_t, float t_e
     for (int i : e->dith_list)
       TRY(dvd_dither_f16(e->wptr[i], e->wptr[i + 1], dst + e->dith_off[i], e->specs[i].nelem, (unsigned)e->dith_off[i],
                          e->dither_step, stream));
-    e->dither_step += 1;
   }
   if (!e->use_graphs || e->prof_on || e->debug_stop)
     return enqueue_step(e, x_t, feat_mode, init_flow, init_feat_nchw, x0_out, stream);

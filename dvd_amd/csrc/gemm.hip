@@ -95,11 +95,16 @@ __device__ __forceinline__ void tile_coords(int vid, int ntm, int ntn, int& tm, 
 // u = k0 (x + k1 x^3).  Written with ONE exponential and one reciprocal (v_exp_f32 / v_rcp_f32, ~1 ulp each: 1e-7 relative
 // on a value that is then rounded to f16) instead of tanhf, whose library expansion is ~4x the instructions and a branch:
 // fc1's epilogue applies it to 2 G elements per evaluation and was half of that GEMM's 3.8 ms (K = 384: six K slabs per
-// tile).  x -> -inf gives -0, x -> +inf gives x, NaN propagates - as the tanh form.
+// tile).  Range: for x <= -10.5 the tanh form is exactly -0 in fp32 arithmetic (1 + tanh u rounds to 0) while
+// exp(-2u) overflows here (x / inf = -0 for finite x, but -inf / inf would be NaN), so that range returns -0 explicitly -
+// also at -inf, where torch's own formula 0.5 x (1 + tanh u) evaluates -inf * 0 = NaN (no finite activation gets there);
+// x -> +inf gives x, NaN propagates.  tests/test_gpu_gemm.py::test_gelu_epilogue_range checks [-12, 12], the exp-overflow
+// region and +-1e4 / +inf against torch's gelu(approximate='tanh').
 __device__ __forceinline__ float gelu_tanh(float x) {
   const float k0 = 0.7978845608028654f, k1 = 0.044715f;
   const float u = k0 * (x + k1 * x * x * x);
-  return __fdividef(x, 1.f + __expf(-2.f * u));
+  const float y = __fdividef(x, 1.f + __expf(-2.f * u));
+  return x < -10.5f ? -0.f : y;
 }
 
 // Epilogue of one 32x32 accumulator tile (rows row0 + cd_row(i,h), column col).  Kept as a function so the

@@ -20,9 +20,11 @@ def _env_int(name, default):
 def setup_dist(backend=None):
     """Initialise torch.distributed from torchrun's environment (single process: a 1-rank group).
     Returns True when this call created the group (the caller then owns destroying it)."""
-    # the device of this process is chosen HERE, once, for every backend and also when the caller brought its own
-    # process group: dev() reads it back (the reference maps rank % GPUS_PER_NODE, idf/dist_util.py:44-50)
-    if th.cuda.is_available():
+    # The device of this process is chosen HERE when a launcher said which rank this is (LOCAL_RANK, else RANK; the
+    # reference maps rank % GPUS_PER_NODE, idf/dist_util.py:44-50) - for every backend, and also when the caller brought
+    # its own process group - and dev() reads it back.  Without a launcher's rank in the environment the caller's own
+    # torch.cuda.set_device(k) is left alone (a single process that picked GPU k must not be moved to cuda:0).
+    if ("LOCAL_RANK" in os.environ or "RANK" in os.environ) and th.cuda.is_available():
         th.cuda.set_device(_env_int("LOCAL_RANK", _env_int("RANK", 0)) % max(1, th.cuda.device_count()))
     if dist.is_initialized():
         return False

@@ -134,9 +134,10 @@ class Engine:
         lib.call("dvd_engine_feat_nchw", self._h, ptr(out), stream_ptr())
         return out
 
-    def denoise(self, x_t, t_embed: float, feat_mode: int, init_flow, out=None, init_feat=None, dither_step=None):
-        """dither_step: the evaluation index the weight dithering uses (the sampler passes its loop counter so a roll-out
-        is a function of its inputs alone); None keeps the handle's running counter."""
+    def denoise(self, x_t, t_embed: float, feat_mode: int, init_flow, out=None, init_feat=None, dither_step: int = 0):
+        """dither_step: the phase of the weight dithering for THIS evaluation (the sampler passes its loop counter,
+        0 at the first step).  It is always set explicitly - the handle keeps no running counter - so an evaluation is a
+        pure function of its arguments: equal inputs give equal bits whatever the engine ran before."""
         shp = (self.n, 2, self.grid, self.grid)
         for t in (x_t, init_flow):
             if tuple(t.shape) != shp or t.dtype != torch.float32 or not _is_dev(t) or not t.is_contiguous():
@@ -148,8 +149,7 @@ class Engine:
             if init_feat is None or tuple(init_feat.shape) != fs or init_feat.dtype != torch.float32 \
                     or not _is_dev(init_feat) or not init_feat.is_contiguous():
                 raise lib.DvdError(f"denoise: feat_mode 3 needs a contiguous f32 device init_feat of shape {fs}")
-        if dither_step is not None:
-            self.set_option("dither_step", int(dither_step))
+        self.set_option("dither_step", int(dither_step))
         lib.call("dvd_engine_denoise_step", self._h, ptr(x_t), C.c_float(t_embed), feat_mode, ptr(init_flow),
                  ptr(init_feat if feat_mode == 3 else None), ptr(out), stream_ptr())
         return out

@@ -171,6 +171,13 @@ class GaussianDiffusion:
             raise ValueError("the timestep must be identical across the batch (the denoiser's override rule is batch-global)")
         return i
 
+    def _single_call_kwargs(self, model_kwargs, i):
+        """model_kwargs of a single-step call at timestep index i: the weight-dithering phase is the one the sampling
+        loop uses at that index (sampler.sample: k = S-1-i), so chaining ddim_sample by hand gives the loop's bits."""
+        kw = dict(model_kwargs or {})
+        kw.setdefault("dither_step", self.num_timesteps - 1 - i)
+        return kw
+
     def p_mean_variance(self, model, x, t, clip_denoised=True, denoised_fn=None, model_kwargs=None):
         """idf/gaussian_diffusion.py:294-415 for the live configuration (START_X, FIXED_LARGE/SMALL, no clipping):
         {'mean','variance','log_variance','pred_xstart','feat_dict'}; the denoiser runs on the HIP engine, the posterior
@@ -179,7 +186,7 @@ class GaussianDiffusion:
             raise NotImplementedError("clip_denoised / denoised_fn are off on the DvD path")
         i = self._step_index(t)
         t_model = th.full((x.shape[0],), self.tables.model_time(i), device=x.device)
-        x0, feat = model(x, t_model, **(model_kwargs or {}))
+        x0, feat = model(x, t_model, **self._single_call_kwargs(model_kwargs, i))
         c = self.tables.ddpm_coef(i)
         c.sigma = 0.0                                                  # mean only
         mean = ops.sched_step(c, x.float().contiguous(), x0)
@@ -197,7 +204,7 @@ class GaussianDiffusion:
             raise NotImplementedError("clip_denoised / denoised_fn are off on the DvD path")
         i = self._step_index(t)
         t_model = th.full((x.shape[0],), self.tables.model_time(i), device=x.device)
-        x0, feat = model(x, t_model, **(model_kwargs or {}))
+        x0, feat = model(x, t_model, **self._single_call_kwargs(model_kwargs, i))
         coef = self.tables.ddim_coef(i, eta)
         noise = th.randn_like(x0) if coef.sigma != 0.0 else None
         return {"sample": ops.sched_step(coef, x.float().contiguous(), x0, noise), "pred_xstart": x0, "feat_dict": feat}

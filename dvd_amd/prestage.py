@@ -351,6 +351,10 @@ class _RefNet(nn.Module):
         key = (batch, h, w, dev.index)
         net = self._nets.get(key)
         if net is None:
+            # ONE executor (and one workspace) per image size and device: a different batch size - the ragged last batch
+            # of a run - replaces the previous executor instead of keeping a second full set of activation slots alive
+            for old in [k for k in self._nets if k[1:] == key[1:]]:
+                del self._nets[old]
             net = self._nets[key] = ConvNet(self._program, self._outputs, (h, w), device=dev, batch=batch)
             net._bound = -1
         if net._bound != self._version:

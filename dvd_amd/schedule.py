@@ -109,6 +109,13 @@ class Tables:
         return c
 
 
+def dither_phase(t_model: float) -> int:
+    """Dithering phase of a single denoiser call that is NOT part of a roll-out (model(x, t, **kw) called directly):
+    a pure function of the model time, so that equal calls give equal bits.  Roll-outs (sampler.sample, and
+    diffusion.ddim_sample / p_mean_variance, which know the timestep index i) use S-1-i instead."""
+    return int(round(float(t_model))) & 0x7FFFFFFF
+
+
 def embedded_time(t_model: float) -> float:
     """The denoiser's batch-global timestep override (idf/cross_model.py:575-580)."""
     if t_model > 600:

@@ -307,8 +307,12 @@ int dvd_engine_set_tensor(void* handle, const char* name, const void* dev_ptr, l
  *                                step-dependent sub-ulp offset (dvd_dither_f16: zero-mean over the steps) and those
  *                                GEMMs run one pass - half the MFMAs of the split; the other GEMMs keep the (hi, lo) pair
  *                                (no effect on small-tile grids, which keep the pair everywhere);
- *   "dither_step"              : the evaluation counter the next denoise_step dithers with (it then increments); the
- *                                sampler sets it to the loop index so a roll-out does not depend on the handle's history;
+ *   "dither_step"  (default 0) : the dithering phase of every following denoise_step until it is set again.  The engine keeps
+ *                                NO running counter: an evaluation is a pure function of its inputs and the handle's
+ *                                options (the reference's model() is pure, idf/cross_model.py:568-647).  A roll-out sets it
+ *                                to its loop index (0 at the first step: S-1-i at timestep index i) before every
+ *                                evaluation, which is what makes the rounding zero-mean over the steps; left constant the
+ *                                evaluations are still correct, each with plain f16 weight rounding;
  *   "ffn_lo"        (default 1): 0 drops the lo pass of the decoder FFN's two 1x1 convs only (-4.8 % step time;
  *                                measured coordinate error on synthetic weights 1.2e-4 -> 3.3e-4: opt-in);
  *   "graphs"        (default 0): replay each denoiser evaluation as a captured hipGraph (bit-identical results;

@@ -292,3 +292,63 @@ def test_bench_main_two_ranks(tmp_path):
         assert line["weight_broadcast_ms"] is not None
         # whole-job value = documents of ALL ranks / max-over-ranks time (both fields are rounded: loose tolerance)
         assert abs(line["value"] - 2 * 3 * 2 / (line["ms_per_step"] * 2 / 1e3)) < 0.05 * line["value"]
+
+
+# ------------------------------------------------------------------------------------------------
+# `python bench.py --gpus 2` typed WITHOUT a launcher (how the driver types it): bench.py must start its own rank
+# processes, relay rank 0's one JSON line and exit 0.  The ranks are fresh interpreters, so the CPU stubs of the compute
+# entry points are installed through a `sitecustomize` module on PYTHONPATH (bench.py itself knows nothing about it).
+# ------------------------------------------------------------------------------------------------
+_SITECUSTOMIZE = '''
+import os, sys
+if os.environ.get("DVD_TEST_STUB_BENCH") == "1" and "RANK" in os.environ:
+    sys.path.insert(0, os.environ["DVD_TEST_ROOT"])
+    import torch as th
+    from tests.test_distributed_cpu import _stub_compute, _FakeEvent
+    from dvd_amd import engine as eng_mod
+    _stub_compute([])
+    _real_device = th.device
+    th.cuda.set_device = lambda *a, **k: None
+    th.cuda.Event = _FakeEvent
+    th.device = lambda *a, **k: _real_device("cpu") if (a and a[0] == "cuda") else _real_device(*a, **k)
+    _zeros = th.zeros
+    th.empty = lambda *a, **k: _zeros(*a, **k)          # the stubbed engine writes nothing: keep its outputs finite
+    eng_mod.Engine.profile = lambda self, on: None
+    eng_mod.Engine.profile_read = lambda self: (0, 0.0)
+'''
+
+
+def test_bench_launches_its_own_ranks(tmp_path):
+    import json
+    import subprocess
+    (tmp_path / "sitecustomize.py").write_text(_SITECUSTOMIZE)
+    env = dict(os.environ, DVD_TEST_STUB_BENCH="1", DVD_TEST_ROOT=ROOT,
+               PYTHONPATH=os.pathsep.join([str(tmp_path), ROOT, os.environ.get("PYTHONPATH", "")]))
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--grid", "16",
+           "--docs", "3", "--ddim-steps", "3", "--full-res", "32x24", "--no-cpu-baseline", "--backend", "gloo"]
+    res = subprocess.run(cmd, env=env, cwd=str(tmp_path), capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]                    # ONE line, from rank 0
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 2 and line["warmup"] == 1 and line["scaling"] == "weak"
+    assert line["weight_broadcast_ms"] is not None
+    assert [r["rank"] for r in line["ranks_seen"]["ranks"]] == [0, 1]
+    assert line["config"]["parallelism"].startswith("dp2")
+
+
+def test_bench_launcher_propagates_a_rank_failure(tmp_path):
+    """A rank that dies must end the job with a non-zero exit code instead of leaving the others in a collective."""
+    import subprocess
+    (tmp_path / "sitecustomize.py").write_text(
+        _SITECUSTOMIZE + 'if os.environ.get("RANK") == "1" and os.environ.get("DVD_TEST_STUB_BENCH") == "1":\n    raise SystemExit(7)\n')
+    env = dict(os.environ, DVD_TEST_STUB_BENCH="1", DVD_TEST_ROOT=ROOT,
+               PYTHONPATH=os.pathsep.join([str(tmp_path), ROOT, os.environ.get("PYTHONPATH", "")]))
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--grid", "16", "--docs", "2",
+           "--ddim-steps", "3", "--full-res", "32x24", "--no-cpu-baseline", "--backend", "gloo"]
+    res = subprocess.run(cmd, env=env, cwd=str(tmp_path), capture_output=True, text=True, timeout=600)
+    assert res.returncode != 0

@@ -310,3 +310,29 @@ def test_dither_mean_converges_to_the_weight():
         err = float(np.sqrt(np.mean((acc.cpu().numpy() / S - target) ** 2)))
         print(f"dither mean over {S} steps: rms error {err:.3e} vs fixed rounding {fixed:.3e} ({fixed / err:.1f}x)")
         assert err * factor < fixed, (S, err, fixed)
+
+
+def test_gelu_epilogue_range(ops):
+    """The one-exponential GELU of the GEMM epilogue (gemm.hip:gelu_tanh) over [-12, 12], through the region where
+    exp(-2u) overflows (x < -5.5) and at +-1e4 / +inf, against torch's gelu(approximate='tanh') on the same f32 inputs:
+    the GEMM is x * 1 (exact in the f32-input kernel), so the epilogue is all that is measured (round-3 ADVICE)."""
+    xs = torch.cat([torch.linspace(-12, 12, 4093), torch.tensor([-1e4, 1e4, float("inf"), -0.0, 0.0, -10.5, -10.4999, -5.5])])
+    M, K, N = 4224, 16, 64
+    pad = M - xs.numel()
+    x = torch.cat([xs, torch.zeros(pad)])
+    a = torch.zeros(M, K)
+    a[:, 0] = x
+    b = torch.zeros(N, K)
+    b[:, 0] = 1.0
+    out = torch.zeros(M, N, device="cuda")
+    ops.gemm_nt(a.cuda(), b.cuda(), out32=out, act=1)
+    ref = torch.nn.functional.gelu(x.double(), approximate="tanh")
+    got = out.cpu()[:, 0].double()
+    fin = torch.isfinite(ref)
+    err = (got[fin] - ref[fin]).abs()
+    tol = 4e-7 * ref[fin].abs().clamp_min(1.0)       # v_exp_f32 / v_rcp_f32 are ~1 ulp each
+    assert bool((err <= tol).all()), float((err / tol).max())
+    assert bool(torch.equal(got[~fin], ref[~fin]))   # +inf -> +inf
+    assert bool((out.cpu()[:, 1:] == out.cpu()[:, :1]).all())   # every column saw the same value
+    neg = got[(x < -10.5)]
+    assert bool((neg == 0).all()) and bool(torch.signbit(neg).all())   # exactly -0, as the tanh form in fp32
