@@ -1,6 +1,10 @@
 #!/usr/bin/env python3
-"""DVD_ATTN_DEBUG=1 python benchmarks/attn_stamps.py : per-phase cycle shares of a KV tile (head_dim 256)."""
+"""DVD_ATTN_DEBUG=1 python benchmarks/attn_stamps.py : per-phase cycle shares of a KV tile (head_dim 256) of the ROUND 1-3
+kernels (r64 of rounds 1-3 by default - now DVD_ATTN_R64OLD -, DVD_ATTN_R32 / DVD_ATTN_PIPE / DVD_ATTN_BULK for the older
+ones).  The production kernel's stamps: benchmarks/attn_stamps_r64p.py."""
 import os, sys
+if not (os.environ.get("DVD_ATTN_R32") or os.environ.get("DVD_ATTN_PIPE") or os.environ.get("DVD_ATTN_BULK")):
+    os.environ["DVD_ATTN_R64OLD"] = "1"
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__))); import _lab; _lab.use_lab()   # the DVD_* switches exist in the lab build only (make -C dvd_amd/csrc lab)
 sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
 import ctypes as C

@@ -662,23 +662,353 @@ __global__ void __launch_bounds__(256, (D == 256 ? 1 : DVD_ATTN64_OCC)) flash_at
 
 
 // ================================================================================================
-// head_dim 256, TWO 32-row query blocks per wave, 32-key tiles ("r64").  flash_attn_glds_kernel<256> is bound by the CU's
-// LDS port: every MFMA of every wave needs its own 1-KiB fragment (4 waves x 1 KiB per 32-cycle MFMA = 128 B/clk = the
-// port's peak; benchmarks/lab/mix_lab.hip: 33.2 cycles per MFMA with fragment reads alone, 42.9 with the tile refill on
-// top).  Here one K / V^T fragment read feeds TWO MFMAs (query rows r and 32 + r), which needs O^T for 64 rows = all 256
-// AGPRs and Q for 64 rows = 128 VGPRs; the rest fits only because the key tile is halved to 32 keys (S^T 32 + P 16
-// registers for both row blocks) and the swizzled fragment offsets are recomputed with one v_xor instead of being kept.
-// A workgroup = 4 waves = 256 query rows, so K / V^T are also streamed from L2 half as often.  Same fragment maps,
-// deferred-rescale online softmax (one running max / sum per row block) and per-element arithmetic as the 32-row kernel.
-// LDS image: K tile 32 keys x 512 B, chunk c of row r at c ^ (r & 15); V^T tile 256 rows x 64 B, chunk c of row r at
-// c ^ ((r >> 2) & 3); two 32-KiB buffers.
+// head_dim 256, 64 query rows per wave, SOFTWARE-PIPELINED across key tiles ("r64p", round 4).
+//
+// What rocm's compiler made of flash_attn_r64_kernel (read in the ISA, round 4): its PV phase uses the MFMA builtin, and a
+// builtin MFMA is a pure value to the instruction selector - sched_barrier(0) pins the machine scheduler, not the order
+// the selection DAG is linearised in - so ALL 32 exponentials (+ 32 v_fma, 10 v_pk_add_f32) of a tile were emitted ahead
+// of the first PV MFMA: ~600 cycles per 32-key tile with the matrix pipe idle, on top of the LDS latency exposed after
+// every barrier.  Here the tile loop is a sequence of `asm volatile` statements (they keep their source order; the
+// compiler still allocates the registers), one statement per K / V^T fragment = two MFMAs + their VALU fillers + the
+// next fragment read, and the dependency S^T -> softmax -> PV is cut by pipelining across tiles:
+//
+//   iteration t :  phase 1  S^T(t+1) = K(t+1).Q^T     32 MFMAs | VALU in the gaps: exp2 / row sum / f16 pack of tile t
+//                                                               (chunk 0 of both row blocks, chunk 1 of row block 0);
+//                                                               this wave's 4 LDS-DMA pieces of K(t+2)
+//                  phase 2a O^T += V^T(t).P(t) chunk 0 16 MFMAs | chunk 1 of row block 1
+//                  phase 2b                    chunk 1 16 MFMAs | lane-local row maximum of S^T(t+1) and the
+//                                                               deferred-rescale test; the 4 LDS-DMA pieces of V^T(t+2)
+//                  [rare]   rescale O^T, l, m          (after PV(t) has been issued: O^T, l and P(t) share one reference)
+//                  vmcnt(4) + ONE barrier              (the V^T pieces just issued stay in flight: a 3-deep V^T ring)
+//
+// so the matrix pipe always has independent MFMAs while a tile's softmax runs on the VALU.  S^T is double-buffered in
+// architectural VGPRs (2 x 32), the loop is unrolled by two so both buffers have compile-time names; Q (128 VGPRs) and
+// O^T (all 256 AGPRs) as in flash_attn_r64_kernel.  The row maximum is checked LANE-LOCALLY (a lane owns 16 of its query's
+// 32 keys; m_run is kept identical in both halves of a row), so the cross-half exchange exists only in the rare branch.
+// Measured (MI355X, s_memtime stamps + PMC, profiles/r4_*): 3574 -> ~2900 cycles per tile, MFMA busy 58.7 -> 68.6 %, but the
+// chip holds 1.70 instead of 1.87 GHz under the denser stream (it runs at its power cap): +7 % wall for -14 % cycles.
+//
+// Why statements are merged: hipcc's hazard recogniser counts an inline-asm statement as ZERO wait states and assumes a
+// dst-forwarding hazard whenever a statement reads a VGPR that an earlier statement wrote with no compiler instruction in
+// between - it then pads with s_nop 0 (4 issue cycles each; the first version had 43 per tile).  One statement per
+// fragment keeps the def -> use chains (row sums, exponentials -> packs) inside a statement or a whole statement apart.
+//
+// LDS: K tiles are stored as 16 two-row pieces (one 1-KiB LDS-DMA each) at a pitch of 1056 B with the 16-byte chunks of
+// the odd row XOR-ed by 1: conflict-free ds_read_b128 like the old 16-way XOR swizzle, but a fragment address is ONE
+// per-lane base + an immediate (the old image cost a v_xor per read).  V^T tiles as in flash_attn_r64_kernel (two bases).
+// [K0 | K1 | V0 | V1 | V2] = 2 x 16896 + 3 x 16384 B; the K ring is indexed by immediates, the V^T ring by two rotating
+// address registers (its offsets would not fit ds_read's 16-bit immediate).  The LDS-DMA source offsets of a wave's four
+// pieces differ by a wave-uniform stride, so ONE per-lane offset register serves them (the base pointer moves in SGPRs).
+// Fragment maps, kappa key order, deferred-rescale rule and per-element arithmetic are flash_attn_r64_kernel's.
 // ================================================================================================
+namespace r64p {
+constexpr int KPIECE = 1056, KBYTES = 16 * KPIECE, VBYTES = 256 * 64, KSLOTS = 3, VSLOTS = 3, VBASE = KSLOTS * KBYTES;
+constexpr int LDS_BYTES = KSLOTS * KBYTES + VSLOTS * VBYTES;
+constexpr float RESCALE_THR = 10.f;
+
+// One 1-KiB LDS-DMA piece (prologue form).  M0 (the LDS destination) is written in the statement that uses it and NOT
+// restored: nothing else in this kernel reads M0 (checked in the ISA).
+__device__ __forceinline__ void glds_piece(const char* gbase, unsigned voff, unsigned lds) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %0" ::"s"(gbase), "s"(lds), "v"(voff) : "memory");
+}
+
+#define R64P_MFMA0(acc_, a_, b_) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(acc_) : "v"(a_), "v"(b_))
+#define R64P_MFMA(acc_, a_, b_) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc_) : "v"(a_), "v"(b_))
+#define R64P_LDS(dst_, addr_, off_) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst_) : "v"(addr_), "i"(off_))
+#define R64P_WAIT_LGKM(n_) asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(n_))
+
+// ---- text pieces of a step statement.  A step = one K / V^T fragment = two MFMAs; its shape is
+//        s_waitcnt lgkmcnt(2) | MFMA a | ds_read (fragment three steps ahead) [LDS-DMA piece] fillers A | MFMA b | fillers B
+//      The read and the DMA piece sit in the FIRST gap: the second one also carries the next step's wait and the s_nop
+//      hipcc pads every statement with, and a gap hides ~24 issue cycles (fma 4, exp 8, add 4, ds_read 4, ...) beside
+//      its MFMA's own 8; with the read behind the second MFMA that gap ran 40+ cycles (stamps: 43 cycles per MFMA).
+#define R64P_W "s_waitcnt lgkmcnt(2)\n\t"
+#define R64P_MF "v_mfma_f32_32x32x16_f16 "
+#define R64P_RD "ds_read_b128 %[nf], %[addr] offset:%[off]\n\t"
+#define R64P_DMA "s_mov_b32 m0, %[lds]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[voff], %[gb]\n\t"
+// exp unit: e = exp2(s * c - m), then the row-sum add of an OLDER unit's result (never of the exponential just issued:
+// trans-use hazard, one wait state)
+#define R64P_EU(e_, s_, m_, acc_, old_) \
+  "v_fma_f32 %[" e_ "], %[" s_ "], %[c], -%[" m_ "]\n\tv_exp_f32_e32 %[" e_ "], %[" e_ "]\n\tv_add_f32_e32 %[" acc_ "], %[" acc_ "], %[" old_ "]\n\t"
+
+// ---- phase 1, first fragment: the two S^T chains start from C = 0; no row-sum add is pending yet
+template <int OFF>
+__device__ __forceinline__ void p1_first(floatx16& sn0, floatx16& sn1, const half8& fr, half8& nf, const half8& q0,
+                                         const half8& q1, float sa, float ma, float& ea, float sb, float mb, float& eb, float c,
+                                         float& acc_a, unsigned addr) {
+  asm volatile(R64P_W R64P_MF "%[sn0], %[fr], %[q0], 0\n\t" R64P_RD
+               "v_fma_f32 %[ea], %[sa], %[c], -%[ma]\n\tv_exp_f32_e32 %[ea], %[ea]\n\t"
+               R64P_MF "%[sn1], %[fr], %[q1], 0\n\t" R64P_EU("eb", "sb", "mb", "acca", "ea")
+               : [sn0] "=&v"(sn0), [sn1] "=&v"(sn1), [nf] "=&v"(nf), [ea] "=&v"(ea), [eb] "=&v"(eb), [acca] "+v"(acc_a)
+               : [fr] "v"(fr), [q0] "v"(q0), [q1] "v"(q1), [sa] "v"(sa), [sb] "v"(sb), [ma] "v"(ma), [mb] "v"(mb), [c] "s"(c),
+                 [addr] "v"(addr), [off] "i"(OFF));
+}
+// ---- phase 1, a fragment with two exp units in its two MFMA gaps
+template <int OFF>
+__device__ __forceinline__ void p1_eu2(floatx16& sn0, floatx16& sn1, const half8& fr, half8& nf, const half8& q0, const half8& q1,
+                                       float sa, float ma, float& ea, float sb, float mb, float& eb, float c, float old,
+                                       float& acc_old, float& acc_a, unsigned addr) {
+  asm volatile(R64P_W R64P_MF "%[sn0], %[fr], %[q0], %[sn0]\n\t" R64P_RD R64P_EU("ea", "sa", "ma", "acco", "old")
+               R64P_MF "%[sn1], %[fr], %[q1], %[sn1]\n\t" R64P_EU("eb", "sb", "mb", "acca", "ea")
+               : [sn0] "+v"(sn0), [sn1] "+v"(sn1), [nf] "=&v"(nf), [ea] "=&v"(ea), [eb] "=&v"(eb), [acco] "+v"(acc_old),
+                 [acca] "+v"(acc_a)
+               : [fr] "v"(fr), [q0] "v"(q0), [q1] "v"(q1), [sa] "v"(sa), [sb] "v"(sb), [ma] "v"(ma), [mb] "v"(mb), [c] "s"(c),
+                 [old] "v"(old), [addr] "v"(addr), [off] "i"(OFF));
+}
+// ---- phase 1, a fragment without exp units: one LDS-DMA piece in its first gap, the four f16 packs of one P fragment
+//      (8 exponentials of one row block -> 4 words) in its second
+template <int OFF>
+__device__ __forceinline__ u32x4 p1_dma_pack(floatx16& sn0, floatx16& sn1, const half8& fr, half8& nf, const half8& q0,
+                                             const half8& q1, unsigned addr, const char* gb, unsigned lds, unsigned voff, float e0,
+                                             float e1, float e2, float e3, float e4, float e5, float e6, float e7) {
+  // each packed word overwrites the register of its first exponential (no extra registers: the kernel sits at 256)
+  asm volatile(R64P_W R64P_MF "%[sn0], %[fr], %[q0], %[sn0]\n\t" R64P_RD R64P_DMA R64P_MF "%[sn1], %[fr], %[q1], %[sn1]\n\t"
+               "v_cvt_pk_f16_f32 %[e0], %[e0], %[e1]\n\tv_cvt_pk_f16_f32 %[e2], %[e2], %[e3]\n\t"
+               "v_cvt_pk_f16_f32 %[e4], %[e4], %[e5]\n\tv_cvt_pk_f16_f32 %[e6], %[e6], %[e7]"
+               : [sn0] "+v"(sn0), [sn1] "+v"(sn1), [nf] "=&v"(nf), [e0] "+v"(e0), [e2] "+v"(e2), [e4] "+v"(e4), [e6] "+v"(e6)
+               : [fr] "v"(fr), [q0] "v"(q0), [q1] "v"(q1), [addr] "v"(addr), [off] "i"(OFF), [gb] "s"(gb), [lds] "s"(lds),
+                 [voff] "v"(voff), [e1] "v"(e1), [e3] "v"(e3), [e5] "v"(e5), [e7] "v"(e7)
+               : "memory");
+  return u32x4{__builtin_bit_cast(unsigned, e0), __builtin_bit_cast(unsigned, e2), __builtin_bit_cast(unsigned, e4),
+               __builtin_bit_cast(unsigned, e6)};
+}
+template <int OFF>
+__device__ __forceinline__ void p1_dma(floatx16& sn0, floatx16& sn1, const half8& fr, half8& nf, const half8& q0, const half8& q1,
+                                       unsigned addr, const char* gb, unsigned lds, unsigned voff) {
+  asm volatile(R64P_W R64P_MF "%[sn0], %[fr], %[q0], %[sn0]\n\t" R64P_RD R64P_DMA R64P_MF "%[sn1], %[fr], %[q1], %[sn1]"
+               : [sn0] "+v"(sn0), [sn1] "+v"(sn1), [nf] "=&v"(nf)
+               : [fr] "v"(fr), [q0] "v"(q0), [q1] "v"(q1), [addr] "v"(addr), [off] "i"(OFF), [gb] "s"(gb), [lds] "s"(lds),
+                 [voff] "v"(voff)
+               : "memory");
+}
+// four f16 packs (one P fragment = 8 elements of one row block) as one statement
+__device__ __forceinline__ u32x4 pack8(float e0, float e1, float e2, float e3, float e4, float e5, float e6, float e7) {
+  unsigned w0, w1, w2, w3;
+  asm volatile("v_cvt_pk_f16_f32 %0, %4, %5\n\tv_cvt_pk_f16_f32 %1, %6, %7\n\tv_cvt_pk_f16_f32 %2, %8, %9\n\t"
+               "v_cvt_pk_f16_f32 %3, %10, %11"
+               : "=&v"(w0), "=&v"(w1), "=&v"(w2), "=&v"(w3)
+               : "v"(e0), "v"(e1), "v"(e2), "v"(e3), "v"(e4), "v"(e5), "v"(e6), "v"(e7));
+  return u32x4{w0, w1, w2, w3};
+}
+// ---- phase 2a: two PV MFMAs (O^T in AGPRs) + one exp unit
+template <int OFF>
+__device__ __forceinline__ void p2_eu1(floatx16& o0, floatx16& o1, const half8& fr, half8& nf, const u32x4& p0, const u32x4& p1,
+                                       float sa, float ma, float& ea, float c, float old, float& acc_old, unsigned addr) {
+  asm volatile(R64P_W R64P_MF "%[o0], %[fr], %[p0], %[o0]\n\t" R64P_RD R64P_EU("ea", "sa", "ma", "acco", "old")
+               R64P_MF "%[o1], %[fr], %[p1], %[o1]"
+               : [o0] "+a"(o0), [o1] "+a"(o1), [nf] "=&v"(nf), [ea] "=&v"(ea), [acco] "+v"(acc_old)
+               : [fr] "v"(fr), [p0] "v"(p0), [p1] "v"(p1), [sa] "v"(sa), [ma] "v"(ma), [c] "s"(c), [old] "v"(old),
+                 [addr] "v"(addr), [off] "i"(OFF));
+}
+// ---- phase 2b.  The lane-local maximum of S^T(next) runs in four chains (two per row block).
+// first step: the chains start (elements 0-2 and 7-9 of each row block)
+template <int OFF>
+__device__ __forceinline__ void p2_max_first(floatx16& o0, floatx16& o1, const half8& fr, half8& nf, const u32x4& p0,
+                                             const u32x4& p1, const floatx16& s0, const floatx16& s1, float& a0, float& b0,
+                                             float& a1, float& b1, unsigned addr) {
+  asm volatile(R64P_W R64P_MF "%[o0], %[fr], %[p0], %[o0]\n\t" R64P_RD
+               "v_max3_f32 %[a0], %[x0], %[x1], %[x2]\n\tv_max3_f32 %[b0], %[x3], %[x4], %[x5]\n\t"
+               R64P_MF "%[o1], %[fr], %[p1], %[o1]\n\t"
+               "v_max3_f32 %[a1], %[y0], %[y1], %[y2]\n\tv_max3_f32 %[b1], %[y3], %[y4], %[y5]"
+               : [o0] "+a"(o0), [o1] "+a"(o1), [nf] "=&v"(nf), [a0] "=&v"(a0), [b0] "=&v"(b0), [a1] "=&v"(a1), [b1] "=&v"(b1)
+               : [fr] "v"(fr), [p0] "v"(p0), [p1] "v"(p1), [x0] "v"(s0[0]), [x1] "v"(s0[1]), [x2] "v"(s0[2]), [x3] "v"(s0[7]),
+                 [x4] "v"(s0[8]), [x5] "v"(s0[9]), [y0] "v"(s1[0]), [y1] "v"(s1[1]), [y2] "v"(s1[2]), [y3] "v"(s1[7]),
+                 [y4] "v"(s1[8]), [y5] "v"(s1[9]), [addr] "v"(addr), [off] "i"(OFF));
+}
+// a step that extends the four chains by two elements each: a <- max3(a, xa0, xa1), b <- max3(b, xb0, xb1)
+template <int OFF>
+__device__ __forceinline__ void p2_max_step(floatx16& o0, floatx16& o1, const half8& fr, half8& nf, const u32x4& p0,
+                                            const u32x4& p1, float& a0, float& b0, float& a1, float& b1, float xa0, float xa1,
+                                            float xb0, float xb1, float ya0, float ya1, float yb0, float yb1, unsigned addr) {
+  asm volatile(R64P_W R64P_MF "%[o0], %[fr], %[p0], %[o0]\n\t" R64P_RD
+               "v_max3_f32 %[a0], %[a0], %[xa0], %[xa1]\n\tv_max3_f32 %[b0], %[b0], %[xb0], %[xb1]\n\t"
+               R64P_MF "%[o1], %[fr], %[p1], %[o1]\n\t"
+               "v_max3_f32 %[a1], %[a1], %[ya0], %[ya1]\n\tv_max3_f32 %[b1], %[b1], %[yb0], %[yb1]"
+               : [o0] "+a"(o0), [o1] "+a"(o1), [nf] "=&v"(nf), [a0] "+v"(a0), [b0] "+v"(b0), [a1] "+v"(a1), [b1] "+v"(b1)
+               : [fr] "v"(fr), [p0] "v"(p0), [p1] "v"(p1), [xa0] "v"(xa0), [xa1] "v"(xa1), [xb0] "v"(xb0), [xb1] "v"(xb1),
+                 [ya0] "v"(ya0), [ya1] "v"(ya1), [yb0] "v"(yb0), [yb1] "v"(yb1), [addr] "v"(addr), [off] "i"(OFF));
+}
+// The remaining steps of phase 2b carry one LDS-DMA piece of V^T(t+2) in their first gap and their VALU in the second.
+#define R64P_P2_DMA_STEP(name_, valu_, outs_, ins_, ...)                                                                   \
+  template <int OFF>                                                                                                       \
+  __device__ __forceinline__ void name_(floatx16& o0, floatx16& o1, const half8& fr, half8& nf, const u32x4& p0,           \
+                                        const u32x4& p1, unsigned addr, const char* gb, unsigned lds, unsigned voff,        \
+                                        __VA_ARGS__) {                                                                     \
+    asm volatile(R64P_W R64P_MF "%[o0], %[fr], %[p0], %[o0]\n\t" R64P_RD R64P_DMA R64P_MF "%[o1], %[fr], %[p1], %[o1]\n\t" \
+                 valu_                                                                                                     \
+                 : [o0] "+a"(o0), [o1] "+a"(o1), [nf] "=&v"(nf) outs_                                                      \
+                 : [fr] "v"(fr), [p0] "v"(p0), [p1] "v"(p1), [addr] "v"(addr), [off] "i"(OFF), [gb] "s"(gb), [lds] "s"(lds), \
+                   [voff] "v"(voff) ins_                                                                                   \
+                 : "memory");                                                                                              \
+  }
+#define R64P_COMMA ,
+// join: a <- max3(a, b, x14) per row block
+R64P_P2_DMA_STEP(p2_join, "v_max3_f32 %[a0], %[a0], %[b0], %[x14]\n\tv_max3_f32 %[a1], %[a1], %[b1], %[y14]",
+                 R64P_COMMA[a0] "+v"(a0) R64P_COMMA[a1] "+v"(a1),
+                 R64P_COMMA[b0] "v"(b0) R64P_COMMA[b1] "v"(b1) R64P_COMMA[x14] "v"(x14) R64P_COMMA[y14] "v"(y14), float& a0, float b0,
+                 float& a1, float b1, float x14, float y14)
+// last element, then d = max(a0 * c - thr0, a1 * c - thr1): > 0 in some lane <=> a row's maximum grew by more than THR
+R64P_P2_DMA_STEP(p2_last, "v_max_f32_e32 %[a0], %[a0], %[x15]\n\tv_max_f32_e32 %[a1], %[a1], %[y15]",
+                 R64P_COMMA[a0] "+v"(a0) R64P_COMMA[a1] "+v"(a1), R64P_COMMA[x15] "v"(x15) R64P_COMMA[y15] "v"(y15), float& a0,
+                 float& a1, float x15, float y15)
+R64P_P2_DMA_STEP(p2_test,
+                 "v_fma_f32 %[d], %[a0], %[c], -%[thr0]\n\tv_fma_f32 %[t], %[a1], %[c], -%[thr1]\n\tv_max_f32_e32 %[d], %[d], %[t]",
+                 R64P_COMMA[d] "=&v"(d) R64P_COMMA[t] "=&v"(t),
+                 R64P_COMMA[a0] "v"(a0) R64P_COMMA[a1] "v"(a1) R64P_COMMA[c] "s"(c) R64P_COMMA[thr0] "v"(thr0) R64P_COMMA[thr1] "v"(thr1),
+                 float a0, float a1, float c, float thr0, float thr1, float& d, float& t)
+// lane mask of d > 0, and the first half of the row-sum update
+R64P_P2_DMA_STEP(p2_mask,
+                 "v_cmp_lt_f32_e64 %[mask], 0, %[d]\n\tv_add_f32_e32 %[l0], %[l0], %[ra0]\n\tv_add_f32_e32 %[l1], %[l1], %[ra1]",
+                 R64P_COMMA[mask] "=&s"(mask) R64P_COMMA[l0] "+v"(l0) R64P_COMMA[l1] "+v"(l1),
+                 R64P_COMMA[d] "v"(d) R64P_COMMA[ra0] "v"(ra0) R64P_COMMA[ra1] "v"(ra1), float d, unsigned long long& mask, float& l0,
+                 float ra0, float& l1, float ra1)
+// last step of an iteration: the second half of the row-sum update (no DMA piece)
+template <int OFF>
+__device__ __forceinline__ void p2_lsum(floatx16& o0, floatx16& o1, const half8& fr, half8& nf, const u32x4& p0, const u32x4& p1,
+                                        float& l0, float rb0, float& l1, float rb1, unsigned addr) {
+  asm volatile(R64P_W R64P_MF "%[o0], %[fr], %[p0], %[o0]\n\t" R64P_RD R64P_MF "%[o1], %[fr], %[p1], %[o1]\n\t"
+               "v_add_f32_e32 %[l0], %[l0], %[rb0]\n\tv_add_f32_e32 %[l1], %[l1], %[rb1]"
+               : [o0] "+a"(o0), [o1] "+a"(o1), [nf] "=&v"(nf), [l0] "+v"(l0), [l1] "+v"(l1)
+               : [fr] "v"(fr), [p0] "v"(p0), [p1] "v"(p1), [rb0] "v"(rb0), [rb1] "v"(rb1), [addr] "v"(addr), [off] "i"(OFF));
+}
+
+struct Soft {            // per row block: running max, its rescale threshold m + THR, running sum (lane-partial)
+  float m, thr, l;
+};
+
+#define R64P_STAMP(k_)                                                                         \
+  if constexpr (DBG_ != 0) {                                                                   \
+    unsigned long long now_;                                                                   \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)::"memory");               \
+    acc_t[k_] += now_ - tprev;                                                                 \
+    tprev = now_;                                                                              \
+  }
+
+// One pipelined iteration t.  SC = S^T(t) (complete, reference max valid): its P is formed and consumed here; SN = S^T(t+1),
+// written here.  kcur / knext: K fragment base addresses of the ring slots of K(t+1) (phase 1) and K(t+2) (pre-read at the
+// end of phase 2b); vrd0 / vrd1: V^T(t) fragment bases (chunk 0 / 1).  fr: the four-slot fragment ring, in flight ACROSS
+// iterations: step n waits for fragment n, and reads fragment n + 3 into the slot step n - 1 has just consumed.
+template <int DBG_>
+__device__ __forceinline__ void tile_iter(unsigned long long (&acc_t)[6], unsigned long long& tprev, half8 (&fr)[4],
+                                          floatx16 (&SC)[2], floatx16 (&SN)[2], const half8 (&qf)[2][16], floatx16 (&o)[2][8],
+                                          Soft (&sm)[2], float c, unsigned kcur, unsigned knext, unsigned vrd0, unsigned vrd1,
+                                          const char* kg_next, const char* vg_next, unsigned kstride4, unsigned vstride4,
+                                          unsigned koff0, unsigned voff0, unsigned lds_k_dst, unsigned lds_v_dst) {
+  float e[32];                    // exponentials by exp-unit number
+  float ra[2] = {0.f, 0.f}, rb[2] = {0.f, 0.f};   // row sums: adds issued in an MFMA pair's first / second gap
+  // exp unit u (0..31) -> (row block, S^T element): chunk 0 of rb 0 and rb 1 interleaved (u < 16), then chunk 1 of rb 0
+  // (16..23), then chunk 1 of rb 1 (24..31)
+#define URB(u_) ((u_) < 16 ? ((u_) & 1) : ((u_) < 24 ? 0 : 1))
+#define UEL(u_) ((u_) < 16 ? ((u_) >> 1) : ((u_) < 24 ? 8 + (u_) - 16 : 8 + (u_) - 24))
+#define USC(u_) SC[URB(u_)][UEL(u_)]
+#define UM(u_) sm[URB(u_)].m
+  // ---------------- phase 1: S^T(next) = K . Q^T; exp units 0..23 of the current tile in the first 24 gaps ----------------
+  u32x4 p00, p10, p01, p11;
+#define P1_EU2(f_)                                                                                                          \
+  p1_eu2<((f_) + 3) * 32>(SN[0], SN[1], fr[(f_) & 3], fr[((f_) + 3) & 3], qf[0][f_], qf[1][f_], USC(2 * (f_)), UM(2 * (f_)),     \
+                          e[2 * (f_)], USC(2 * (f_) + 1), UM(2 * (f_) + 1), e[2 * (f_) + 1], c, e[2 * (f_) - 1],                \
+                          rb[URB(2 * (f_) - 1)], ra[URB(2 * (f_))], kcur);
+  p1_first<3 * 32>(SN[0], SN[1], fr[0], fr[3], qf[0][0], qf[1][0], USC(0), UM(0), e[0], USC(1), UM(1), e[1], c, ra[0], kcur);
+  P1_EU2(1)
+  P1_EU2(2)
+  P1_EU2(3)
+  P1_EU2(4)
+  P1_EU2(5)
+  P1_EU2(6)
+  P1_EU2(7)                        // units 14, 15: chunk 0 is complete
+  P1_EU2(8)
+  P1_EU2(9)
+  P1_EU2(10)
+  P1_EU2(11)                       // units 22, 23: chunk 1 of row block 0 is complete
+#undef P1_EU2
+  // the last four fragments carry this wave's 4 LDS-DMA pieces of K(t+3) (they have more than an iteration to land) and the
+  // f16 packs of the three P fragments formed so far; the ring runs on into phase 2: V^T fragments (chunk 0, d blocks
+  // 0..2) behind the last K fragment
+  p00 = p1_dma_pack<15 * 32>(SN[0], SN[1], fr[0], fr[3], qf[0][12], qf[1][12], kcur, kg_next, lds_k_dst, koff0, e[0], e[2], e[4],
+                             e[6], e[8], e[10], e[12], e[14]);
+  p10 = p1_dma_pack<0 * 2048>(SN[0], SN[1], fr[1], fr[0], qf[0][13], qf[1][13], vrd0, kg_next + kstride4, lds_k_dst + KPIECE, koff0,
+                              e[1], e[3], e[5], e[7], e[9], e[11], e[13], e[15]);
+  p01 = p1_dma_pack<1 * 2048>(SN[0], SN[1], fr[2], fr[1], qf[0][14], qf[1][14], vrd0, kg_next + 2 * (size_t)kstride4,
+                              lds_k_dst + 2 * KPIECE, koff0, e[16], e[17], e[18], e[19], e[20], e[21], e[22], e[23]);
+  p1_dma<2 * 2048>(SN[0], SN[1], fr[3], fr[2], qf[0][15], qf[1][15], vrd0, kg_next + 3 * (size_t)kstride4,
+                   lds_k_dst + 3 * KPIECE, koff0);
+  R64P_STAMP(0)
+  // ---------------- phase 2a: O^T += V^T . P chunk 0 (d blocks g = 0..7); exp units 24..31 ----------------
+#define P2A(g_, addr_, off_)                                                                                               \
+  p2_eu1<off_>(o[0][g_], o[1][g_], fr[(g_) & 3], fr[((g_) + 3) & 3], p00, p10, USC(24 + (g_)), sm[1].m, e[24 + (g_)], c,    \
+               e[23 + (g_)], rb[URB(23 + (g_))], addr_);
+  P2A(0, vrd0, 3 * 2048)
+  P2A(1, vrd0, 4 * 2048)
+  P2A(2, vrd0, 5 * 2048)
+  P2A(3, vrd0, 6 * 2048)
+  P2A(4, vrd0, 7 * 2048)
+  P2A(5, vrd1, 0 * 2048)
+  P2A(6, vrd1, 1 * 2048)
+  P2A(7, vrd1, 2 * 2048)
+#undef P2A
+  R64P_STAMP(1)
+  // ---------------- the iteration's ONE barrier.  Every LDS-DMA piece but the four K(t+3) pieces just issued has landed
+  // (K(t+2) and V^T(t+1): issued an iteration ago) and becomes visible to every wave; every wave has finished phase 1 of
+  // this iteration and phase 2b of the previous one, so the K slot the next phase 1 refills and the V^T slot phase 2b
+  // refills below are free.
+  if constexpr (DBG_ != 0) {
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    R64P_STAMP(2)
+    asm volatile("s_barrier" ::: "memory");
+    R64P_STAMP(3)
+  } else {
+    asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+  }
+  asm volatile("v_add_f32_e32 %0, %0, %1" : "+v"(rb[1]) : "v"(e[31]));     // the last unit's row-sum add
+  p11 = pack8(e[24], e[25], e[26], e[27], e[28], e[29], e[30], e[31]);
+  // ---------------- phase 2b: chunk 1; lane-local maximum of S^T(next) in four chains, the rescale test, l += row sums;
+  // this wave's 4 LDS-DMA pieces of V^T(t+2); the first three K fragments of the next iteration ----------------
+  float a0, b0, a1, b1, dtest, ttmp;
+  unsigned long long mask;
+  p2_max_first<3 * 2048>(o[0][0], o[1][0], fr[0], fr[3], p01, p11, SN[0], SN[1], a0, b0, a1, b1, vrd1);
+  p2_max_step<4 * 2048>(o[0][1], o[1][1], fr[1], fr[0], p01, p11, a0, b0, a1, b1, SN[0][3], SN[0][4], SN[0][10], SN[0][11],
+                        SN[1][3], SN[1][4], SN[1][10], SN[1][11], vrd1);
+  p2_max_step<5 * 2048>(o[0][2], o[1][2], fr[2], fr[1], p01, p11, a0, b0, a1, b1, SN[0][5], SN[0][6], SN[0][12], SN[0][13],
+                        SN[1][5], SN[1][6], SN[1][12], SN[1][13], vrd1);
+  p2_join<6 * 2048>(o[0][3], o[1][3], fr[3], fr[2], p01, p11, vrd1, vg_next, lds_v_dst, voff0, a0, b0, a1, b1, SN[0][14],
+                    SN[1][14]);
+  p2_last<7 * 2048>(o[0][4], o[1][4], fr[0], fr[3], p01, p11, vrd1, vg_next + vstride4, lds_v_dst + 1024, voff0, a0, a1,
+                    SN[0][15], SN[1][15]);
+  p2_test<0 * 32>(o[0][5], o[1][5], fr[1], fr[0], p01, p11, knext, vg_next + 2 * (size_t)vstride4, lds_v_dst + 2 * 1024, voff0,
+                  a0, a1, c, sm[0].thr, sm[1].thr, dtest, ttmp);
+  p2_mask<1 * 32>(o[0][6], o[1][6], fr[2], fr[1], p01, p11, knext, vg_next + 3 * (size_t)vstride4, lds_v_dst + 3 * 1024, voff0,
+                  dtest, mask, sm[0].l, ra[0], sm[1].l, ra[1]);
+  p2_lsum<2 * 32>(o[0][7], o[1][7], fr[3], fr[2], p01, p11, sm[0].l, rb[0], sm[1].l, rb[1], knext);
+  R64P_STAMP(4)
+  // deferred rescale (rare): some lane saw its row's maximum over its 16 keys of the next tile exceed m + THR
+  if (mask != 0) {
+    asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");          // the last PV MFMAs must have written O^T
+    const float mloc[2] = {a0, a1};
+#pragma unroll
+    for (int r_ = 0; r_ < 2; ++r_) {
+      const float mx = half_swap_max(mloc[r_] * c);            // the row's maximum over all 32 keys, same in both halves
+      const float m_new = fmaxf(sm[r_].m, mx);
+      const float alpha = __builtin_amdgcn_exp2f(sm[r_].m - m_new);
+      sm[r_].m = m_new;
+      sm[r_].thr = m_new + RESCALE_THR;
+      sm[r_].l *= alpha;
+#pragma unroll
+      for (int dt = 0; dt < 8; ++dt) scale_acc_in_agpr(o[r_][dt], alpha);
+    }
+  }
+  R64P_STAMP(5)
+#undef URB
+#undef UEL
+#undef USC
+#undef UM
+}
+}  // namespace r64p
+
 template <int DBG>
-__global__ void __launch_bounds__(256, 1) flash_attn_r64_kernel(AttnArgs p) {
-  constexpr int D = 256, KB = 32, KROWB = 512, KBYTES = KB * KROWB, VROWB = 64, VBYTES = D * VROWB, BUF = KBYTES + VBYTES;
-  constexpr int KS = 16, DT = 8, RB = 2;
-  constexpr float RESCALE_THR = 10.f;
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][BUF]
+__global__ void __launch_bounds__(256, 1) flash_attn_r64p_kernel(AttnArgs p) {
+  using namespace r64p;
+  constexpr int D = 256, KB = 32, KS = 16, DT = 8, RB = 2;
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [K0 | K1 | V0 | V1 | V2]
   typedef __attribute__((address_space(3))) void* lptr_t;
 
   const int nwg = gridDim.x;
@@ -709,23 +1039,18 @@ __global__ void __launch_bounds__(256, 1) flash_attn_r64_kernel(AttnArgs p) {
   }
   __builtin_amdgcn_s_waitcnt(0x0F70);   // retire the Q loads with a wait the compiler tracks (see flash_attn_glds_kernel)
 
-  // per-lane SOURCE offsets of this wave's 4 + 4 direct-to-LDS loads per tile
-  unsigned koff[4], voff[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int q = (4 * wave + i) * 64 + lane;
-    const int krow = q >> 5, kpos = q & 31;
-    koff[i] = (unsigned)krow * (unsigned)(p.ldk * 2) + (unsigned)((kpos ^ (krow & 15)) * 16);
-    const int vrow = q >> 2, vpos = q & 3;
-    voff[i] = (unsigned)vrow * (unsigned)(p.ldvt * 2) + (unsigned)((vpos ^ ((vrow >> 2) & 3)) * 16);
-  }
-  // fragment read offsets, recomputed per read from two per-lane bases:
-  //   K, k-step ks :  kr*512 + (((2 ks + h) ^ (kr & 15)) * 16)   =  kbase ^ (ks * 32)      (kr & 15 only touches bits 4..7,
-  //                                                                   2 ks * 16 = ks * 32 touches bits 5..8: plain XOR)
-  //   V^T, chunk c, d block dt :  KBYTES + (32 dt + r)*64 + (((2 c + h) ^ ((r >> 2) & 3)) * 16)  =  (vbase ^ (c * 32)) + dt * 2048
+  // LDS-DMA source offsets.  K piece j = 4 wave + i holds key rows 2j, 2j + 1: LDS slot (e = lane >> 5, pos = lane & 31)
+  // <- row 2j + e, chunk pos ^ e; the pieces of one wave are 2 rows = `kstride4` bytes apart, so the per-lane offset is
+  // the one of piece 4 wave and the base pointer advances.  V^T piece j holds d rows 16j .. 16j + 15: lane -> row
+  // 16j + (lane >> 2), chunk (lane & 3) ^ ((lane >> 4) & 3) (the row's bits 2,3 are the lane's bits 4,5 for every j).
+  const unsigned kstride4 = (unsigned)(2 * p.ldk * 2), vstride4 = (unsigned)(16 * p.ldvt * 2);
+  const unsigned koff0 = (unsigned)(8 * wave + (lane >> 5)) * (unsigned)(p.ldk * 2) + (unsigned)(((lane & 31) ^ (lane >> 5)) * 16);
+  const unsigned voff0 = (unsigned)(64 * wave + (lane >> 2)) * (unsigned)(p.ldvt * 2) + (unsigned)(((lane & 3) ^ ((lane >> 4) & 3)) * 16);
+  const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t)smem;
   const int kr = kappa(r);
-  const int kbase = kr * KROWB + ((h ^ (kr & 15)) * 16);
-  const int vbase = KBYTES + r * VROWB + ((h ^ ((r >> 2) & 3)) * 16);
+  const unsigned kaddr = lds0 + (kr >> 1) * KPIECE + (kr & 1) * 512 + ((h ^ (kr & 1)) * 16);        // slot 0; + ks * 32
+  const unsigned vrel0 = lds0 + VBASE + r * 64 + ((h ^ ((r >> 2) & 3)) * 16);                       // chunk 0, slot 0; + dt * 2048
+  const unsigned vrel1 = vrel0 ^ 32;                                                                // chunk 1
 
   floatx16 o[RB][DT];
 #pragma unroll
@@ -734,135 +1059,102 @@ __global__ void __launch_bounds__(256, 1) flash_attn_r64_kernel(AttnArgs p) {
     for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
       for (int i = 0; i < 16; ++i) o[rb][dt][i] = 0.f;
-  float m_run[RB] = {-1e30f, -1e30f}, l_run[RB] = {0.f, 0.f};
-  const int nt = p.tk / KB;
+  Soft sm[RB] = {{-1e30f, -1e30f, 0.f}, {-1e30f, -1e30f, 0.f}};
+  const int nt = p.tk / KB;              // even (tk % 64 == 0)
   const size_t ktile = (size_t)KB * p.ldk * 2;
-  const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t)smem;
+  const unsigned kdst = lds0 + (4 * wave) * KPIECE, vdst = lds0 + VBASE + (4 * wave) * 1024;
 
+  // ---- prologue: K(0), K(1), K(2) -> K slots 0, 1, 2; V(0), V(1) -> V slots 0, 1
+  {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    glds_one(Kg, koff[i], lds0 + (4 * wave + i) * 1024);
-    glds_one(Vg, voff[i], lds0 + KBYTES + (4 * wave + i) * 1024);
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-
-#define SB() __builtin_amdgcn_sched_barrier(0)
-#define KFRAG(ks_) (*(const half8*)(base + (kbase ^ ((ks_) * 32))))
-#define VFRAG(c_, dt_) (*(const half8*)(base + (vbase ^ ((c_) * 32)) + (dt_) * 2048))
-  unsigned long long acc_t[5] = {0, 0, 0, 0, 0};
-  unsigned long long tprev = 0;
-#define STAMP(k_)                                                              \
-  if constexpr (DBG & 1) {                                                     \
-    __builtin_amdgcn_sched_barrier(0);                                         \
-    const unsigned long long now_ = __builtin_amdgcn_s_memtime();              \
-    __builtin_amdgcn_s_waitcnt(0xC07F);                                        \
-    acc_t[k_] += now_ - tprev;                                                 \
-    tprev = now_;                                                              \
-    __builtin_amdgcn_sched_barrier(0);                                         \
-  }
-  if constexpr (DBG & 1) tprev = __builtin_amdgcn_s_memtime();
-  int cur = 0;
-  for (int t = 0; t < nt; ++t) {
-    const int tn = min(t + 1, nt - 1);
-    const char* kg_next = Kg + (size_t)tn * ktile;
-    const char* vg_next = Vg + (size_t)tn * (KB * 2);
-    const unsigned lds_next = lds0 + (cur ^ 1) * BUF + (4 * wave) * 1024;
-    const char* base = smem + cur * BUF;
-    STAMP(0)
-    half8 fr[4];
-    floatx16 s[RB];
+    for (int j = 0; j < 3; ++j) {
+      const char* kj = Kg + (size_t)min(j, nt - 1) * ktile;
+      const char* vj = Vg + (size_t)min(j, nt - 1) * (KB * 2);
 #pragma unroll
-    for (int f = 0; f < 4; ++f) fr[f] = KFRAG(f);
-    SB();
-    // ---- S^T = K.Q^T : 16 K fragments, two MFMAs each; the next tile's 8 loads go out after every second fragment
-#pragma unroll
-    for (int f = 0; f < KS; ++f) {
-      // S^T accumulates in ARCHITECTURAL VGPRs, by inline asm: left to the compiler these MFMAs get AGPR destinations,
-      // and as O^T owns all 256 AGPRs it then evicts two O^T accumulators to VGPRs and back every tile (64 moves).
-      // The two chains alternate, so a dependent MFMA is always one independent 8-pass MFMA behind its producer.
-      if (f == 0) {      // first step: C = 0 as an inline constant instead of 32 v_mov per tile
-        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=v"(s[0]) : "v"(fr[0]), "v"(qf[0][0]));
-        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=v"(s[1]) : "v"(fr[0]), "v"(qf[1][0]));
-      } else {
-        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(s[0]) : "v"(fr[f & 3]), "v"(qf[0][f]));
-        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(s[1]) : "v"(fr[f & 3]), "v"(qf[1][f]));
+      for (int i = 0; i < 4; ++i) {
+        glds_piece(kj + (size_t)i * kstride4, koff0, kdst + j * KBYTES + i * KPIECE);
+        if (j < 2) glds_piece(vj + (size_t)i * vstride4, voff0, vdst + j * VBYTES + i * 1024);
       }
-      if (f + 4 < KS) fr[f & 3] = KFRAG(f + 4);
-      else fr[f & 3] = VFRAG(0, f + 4 - KS);
-      if (f & 1) {
-        if (f < 8) glds_one(kg_next, koff[f >> 1], lds_next + (f >> 1) * 1024);
-        else glds_one(vg_next, voff[(f >> 1) - 4], lds_next + KBYTES + ((f >> 1) - 4) * 1024);
-      }
-      SB();
     }
-    asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");      // the last two MFMAs' results must have landed before the VALU reads them
-    STAMP(1)
-    // ---- online softmax, per row block
-    float mx[RB];
+  }
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+
+  floatx16 sA[RB], sB[RB];
+  {   // S^T(0) -> sA, un-pipelined; its row maximum sets the reference
+    half8 f0[4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) R64P_LDS(f0[f], kaddr, f * 32);
+#pragma unroll
+    for (int f = 0; f < 16; ++f) {
+      if (f < 13) R64P_WAIT_LGKM(3);
+      else if (f == 13) R64P_WAIT_LGKM(2);
+      else if (f == 14) R64P_WAIT_LGKM(1);
+      else R64P_WAIT_LGKM(0);
+      if (f == 0) { R64P_MFMA0(sA[0], f0[0], qf[0][0]); R64P_MFMA0(sA[1], f0[0], qf[1][0]); }
+      else { R64P_MFMA(sA[0], f0[f & 3], qf[0][f]); R64P_MFMA(sA[1], f0[f & 3], qf[1][f]); }
+      if (f + 4 < 16) R64P_LDS(f0[f & 3], kaddr, (f + 4) * 32);
+    }
+    // every wave has read K(0) before any wave's first iteration overwrites K slot 0 with K(3)
+    asm volatile("s_nop 15\n\ts_nop 7\n\ts_barrier" ::: "memory");
 #pragma unroll
     for (int rb = 0; rb < RB; ++rb) {
       float m = -1e30f;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) m = fmaxf(m, s[rb][i]);
-      mx[rb] = half_swap_max(m * p.c);
+      for (int i = 0; i < 16; ++i) m = fmaxf(m, sA[rb][i]);
+      m = half_swap_max(m * p.c);
+      sm[rb].m = m;
+      sm[rb].thr = m + RESCALE_THR;
     }
-    if (__any(fmaxf(mx[0] - m_run[0], mx[1] - m_run[1]) > RESCALE_THR)) {     // deferred rescale
-#pragma unroll
-      for (int rb = 0; rb < RB; ++rb) {
-        const float m_new = fmaxf(m_run[rb], mx[rb]);
-        const float alpha = __builtin_amdgcn_exp2f(m_run[rb] - m_new);
-        m_run[rb] = m_new;
-        l_run[rb] *= alpha;
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt) scale_acc_in_agpr(o[rb][dt], alpha);
-      }
-    }
-    float rs[RB] = {0.f, 0.f};
-    half8 pf[RB][2];
-#define PEXP4(rb_, c_, e_)                                                                          \
-  {                                                                                                 \
-    const float pv_ = __builtin_amdgcn_exp2f(fmaf(s[rb_][8 * (c_) + (e_)], p.c, -m_run[rb_]));      \
-    rs[rb_] += pv_;                                                                                 \
-    pf[rb_][c_][e_] = (_Float16)pv_;                                                                \
   }
+
+  unsigned long long acc_t[6] = {0, 0, 0, 0, 0, 0};
+  unsigned long long tprev = 0;
+  if constexpr (DBG != 0) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev)::"memory");
+  // Rings.  Iteration t reads K(t+1) from K slot (t+1) % 3, pre-reads K(t+2) from slot (t+2) % 3 and refills slot t % 3
+  // with K(t+3); it reads V^T(t) from V slot t % 3 and refills slot (t+2) % 3 with V^T(t+2).
+  unsigned kcur = kaddr + KBYTES, knext = kaddr + 2 * KBYTES;
+  unsigned vrd0 = vrel0, vrd1 = vrel1;
+  int slot = 0;                           // t % 3 (wave-uniform)
+  // the fragment ring of the loop: the first three fragments of K(1) for iteration 0's phase 1
+  half8 fr[4];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { PEXP4(0, 0, e) PEXP4(1, 0, e) }
-    STAMP(2)
-    SB();
-    // ---- O^T += V^T.P : 16 V^T fragments (chunk c, d block dt), two MFMAs each; chunk 1's exps in chunk 0's gaps
+  for (int f = 0; f < 3; ++f) R64P_LDS(fr[f], kcur, f * 32);
+  for (int t = 0; t < nt; t += 2) {
 #pragma unroll
-    for (int f = 0; f < 2 * DT; ++f) {
-      const int c = f >> 3, dt = f & 7;
-      o[0][dt] = mfma32_f16(fr[f & 3], pf[0][c], o[0][dt]);
-      o[1][dt] = mfma32_f16(fr[f & 3], pf[1][c], o[1][dt]);
-      if (f + 4 < 2 * DT) fr[f & 3] = VFRAG((f + 4) >> 3, (f + 4) & 7);
-      if (c == 0) { PEXP4(0, 1, dt) PEXP4(1, 1, dt) }
-      SB();
+    for (int par = 0; par < 2; ++par) {
+      const int tt = t + par;
+      const int tk3 = min(tt + 3, nt - 1), tv2 = min(tt + 2, nt - 1);
+      const int vwr = slot == 0 ? 2 : slot - 1;                              // (t + 2) % 3
+      const char* kg_next = Kg + (size_t)tk3 * ktile;
+      const char* vg_next = Vg + (size_t)tv2 * (KB * 2);
+      if (par == 0)   // even tile: P(t) from sA, S(t+1) -> sB
+        tile_iter<DBG>(acc_t, tprev, fr, sA, sB, qf, o, sm, p.c, kcur, knext, vrd0, vrd1, kg_next, vg_next, kstride4, vstride4,
+                       koff0, voff0, kdst + slot * KBYTES, vdst + vwr * VBYTES);
+      else            // odd tile: P(t) from sB, S(t+1) -> sA
+        tile_iter<DBG>(acc_t, tprev, fr, sB, sA, qf, o, sm, p.c, kcur, knext, vrd0, vrd1, kg_next, vg_next, kstride4, vstride4,
+                       koff0, voff0, kdst + slot * KBYTES, vdst + vwr * VBYTES);
+      // rotate: K(t+2)'s slot becomes the phase-1 slot, the slot just refilled (t % 3) the pre-read slot
+      kcur = knext;
+      knext = kaddr + slot * KBYTES;
+      const int vstep = slot == 2 ? -2 * VBYTES : VBYTES;                    // V read slot (t + 1) % 3
+      vrd0 += vstep;
+      vrd1 += vstep;
+      slot = slot == 2 ? 0 : slot + 1;
     }
-    l_run[0] += rs[0];
-    l_run[1] += rs[1];
-    STAMP(3)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    STAMP(4)
-    cur ^= 1;
   }
-  if constexpr (DBG & 1) {
+  // drain the LDS-DMA and the fragment reads still in flight (the last iterations re-load clamped tiles): LDS must not be
+  // written after the workgroup has ended; and the last PV MFMAs must have written O^T before the compiler's code reads it
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 15\n\ts_nop 7" ::: "memory");
+  if constexpr (DBG != 0) {
     if (lane == 0 && p.stamps) {
-      unsigned long long* o_ = p.stamps + ((size_t)blockIdx.x * 4 + wave) * 5;
-      for (int k = 0; k < 5; ++k) o_[k] = acc_t[k];
+      unsigned long long* o_ = p.stamps + ((size_t)blockIdx.x * 4 + wave) * 6;
+      for (int k = 0; k < 6; ++k) o_[k] = acc_t[k];
     }
   }
-#undef STAMP
-#undef SB
-#undef KFRAG
-#undef VFRAG
-#undef PEXP4
 
 #pragma unroll
   for (int rb = 0; rb < RB; ++rb) {
-    const float l_tot = l_run[rb] + __shfl_xor(l_run[rb], 32);
+    const float l_tot = sm[rb].l + __shfl_xor(sm[rb].l, 32);
     const float inv = 1.f / l_tot;
     const int qglob = qb * 256 + wave * 64 + rb * 32 + r;
     if (qglob < p.tq) {
@@ -879,7 +1171,6 @@ __global__ void __launch_bounds__(256, 1) flash_attn_r64_kernel(AttnArgs p) {
     }
   }
 }
-
 
 #ifdef DVD_LAB
 #include "../../benchmarks/lab/csrc/attention_lab.inc"
@@ -903,7 +1194,7 @@ static constexpr int R64_MIN_TQ = 5376;
 extern "C" const char* dvd_flash_attn_kernel_name(int head_dim, int tq, int tk) {
   if (head_dim != 64 && head_dim != 256) return "";
   if (tk % 64 != 0) return head_dim == 256 ? "flash_attn_kernel<256>" : "flash_attn_kernel<64>";
-  if (head_dim == 256) return tq >= R64_MIN_TQ ? "flash_attn_r64_kernel<0>" : "flash_attn_glds_kernel<256, 0>";
+  if (head_dim == 256) return tq >= R64_MIN_TQ ? "flash_attn_r64p_kernel<0>" : "flash_attn_glds_kernel<256, 0>";
   return "flash_attn_glds_kernel<64, 0>";
 }
 
@@ -944,7 +1235,7 @@ extern "C" int dvd_flash_attn(const dvd_attn_desc* d, void* stream) {
   const bool first_on_device = attr_done.need(dev_bit);
   if (first_on_device) {
     allow_lds(flash_attn_glds_kernel<256, 0>, 2 * (64 * 512 + 256 * 128));
-    allow_lds(flash_attn_r64_kernel<0>, 2 * (32 * 512 + 256 * 64));
+    allow_lds(flash_attn_r64p_kernel<0>, r64p::LDS_BYTES);
     allow_lds(flash_attn_kernel<256>, 2 * (64 * (2 * 256 + 16) + 256 * (2 * 64 + 16)));
     attr_done.done(dev_bit);
   }
@@ -953,7 +1244,7 @@ extern "C" int dvd_flash_attn(const dvd_attn_desc* d, void* stream) {
   p.stamps = g_attn_stamps;
   const bool dbg = getenv("DVD_ATTN_DEBUG"), bulk = getenv("DVD_ATTN_BULK");
   if (getenv("DVD_ATTN_V1")) fast = false;
-  if (getenv("DVD_ATTN_R64")) r64 = d->head_dim == 256;
+  if (getenv("DVD_ATTN_R64") || getenv("DVD_ATTN_R64P") || getenv("DVD_ATTN_R64OLD")) r64 = d->head_dim == 256;
   if (getenv("DVD_ATTN_R32") || getenv("DVD_ATTN_PIPE") || bulk) r64 = false;
   if (first_on_device) {
     constexpr int LDS = 2 * (64 * 512 + 256 * 128);
@@ -963,7 +1254,9 @@ extern "C" int dvd_flash_attn(const dvd_attn_desc* d, void* stream) {
     allow_lds(flash_attn_glds_kernel<256, 3>, LDS);
     allow_lds(flash_attn_pipe_kernel<0>, LDS);
     allow_lds(flash_attn_pipe_kernel<1>, LDS);
+    allow_lds(flash_attn_r64_kernel<0>, 2 * (32 * 512 + 256 * 64));
     allow_lds(flash_attn_r64_kernel<1>, 2 * (32 * 512 + 256 * 64));
+    allow_lds(flash_attn_r64p_kernel<1>, r64p::LDS_BYTES);
   }
   if (fast && d->head_dim == 256) {
     constexpr int LDS = 2 * (64 * 512 + 256 * 128);
@@ -971,10 +1264,17 @@ extern "C" int dvd_flash_attn(const dvd_attn_desc* d, void* stream) {
       flash_attn_dsplit_kernel<<<(unsigned)nwg, 512, LDS, st>>>(p);
       return check_launch("flash_attn(lab dsplit)");
     }
-    if (r64 && dbg) {
+    if (r64 && getenv("DVD_ATTN_R64OLD")) {   // rounds 1-3's production kernel (lab include), with or without its stamps
       p.nqb = cdiv(d->tq, 256);
-      flash_attn_r64_kernel<1><<<(unsigned)((long)p.nqb * d->heads * d->batch), 256, 2 * (32 * 512 + 256 * 64), st>>>(p);
-      return check_launch("flash_attn(lab r64 stamps)");
+      const unsigned g = (unsigned)((long)p.nqb * d->heads * d->batch);
+      if (dbg) flash_attn_r64_kernel<1><<<g, 256, 2 * (32 * 512 + 256 * 64), st>>>(p);
+      else flash_attn_r64_kernel<0><<<g, 256, 2 * (32 * 512 + 256 * 64), st>>>(p);
+      return check_launch("flash_attn(lab r64 old)");
+    }
+    if (r64 && dbg) {                         // the production kernel with its s_memtime stamps
+      p.nqb = cdiv(d->tq, 256);
+      flash_attn_r64p_kernel<1><<<(unsigned)((long)p.nqb * d->heads * d->batch), 256, r64p::LDS_BYTES, st>>>(p);
+      return check_launch("flash_attn(lab r64p stamps)");
     }
     if (!r64 && getenv("DVD_ATTN_PIPE")) {   // slower (830 vs 975 TF/s): see the kernel's header
       if (dbg) flash_attn_pipe_kernel<1><<<(unsigned)nwg, 256, LDS, st>>>(p);
@@ -1004,7 +1304,7 @@ extern "C" int dvd_flash_attn(const dvd_attn_desc* d, void* stream) {
   // ---- product dispatch: four kernels, chosen by (head_dim, tq, tk) ----
   if (fast && r64) {
     p.nqb = cdiv(d->tq, 256);
-    flash_attn_r64_kernel<0><<<(unsigned)((long)p.nqb * d->heads * d->batch), 256, 2 * (32 * 512 + 256 * 64), st>>>(p);
+    flash_attn_r64p_kernel<0><<<(unsigned)((long)p.nqb * d->heads * d->batch), 256, r64p::LDS_BYTES, st>>>(p);
   } else if (fast && d->head_dim == 256) {
     flash_attn_glds_kernel<256, 0><<<(unsigned)nwg, 256, 2 * (64 * 512 + 256 * 128), st>>>(p);
   } else if (fast) {

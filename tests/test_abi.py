@@ -44,7 +44,7 @@ def test_product_library_reads_no_environment_and_ships_no_experiments():
 
 
 def test_attention_kernel_choice_depends_on_shape_only():
-    assert lib.flash_attn_kernel_name(256, 20736, 20736) == "flash_attn_r64_kernel<0>"
+    assert lib.flash_attn_kernel_name(256, 20736, 20736) == "flash_attn_r64p_kernel<0>"
     assert lib.flash_attn_kernel_name(256, 1024, 1024) == "flash_attn_glds_kernel<256, 0>"
     assert lib.flash_attn_kernel_name(256, 1296, 1296) == "flash_attn_kernel<256>"
     assert lib.flash_attn_kernel_name(64, 20736, 20736) == "flash_attn_glds_kernel<64, 0>"
