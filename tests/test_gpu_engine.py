@@ -150,21 +150,15 @@ def _saturated(x):
     return float((x.abs() >= 1).float().mean())
 
 
-@pytest.mark.parametrize("grid,steps,hyp,family", [(16, 50, 2, "plain"), (16, 50, 2, "tame"), (32, 50, 2, "tame"),
-                                                   (96, 50, 1, "tame"), (72, 25, 1, "tame")])
-def test_long_loop_vs_oracle(grid, steps, hyp, family):
-    """BASELINE's 50-step DDIM (not reference-runnable natively: local.py has 3 steps) against the CPU oracle.
-    G = 96 is an UP-sampling, non-native grid like BASELINE's 288 (feat 64 -> G, T % 64 == 0: the LDS-DMA attention
-    kernels, warped-feat branch live from step 2); G = 72 is ragged (T = 1296, T % 64 = 16: the register-staged
-    attention fallback and the GEMM edge tiles).  The two large grids run one hypothesis (and the ragged one 25 steps) to
-    keep the oracle - which dominates this suite's run time - inside the driver's time limit; the whole 50-step loop at
-    G = 288 is recorded once per round in profiles/ (tests/tools/parity_g288.py).
-    The bar of 1e-3 is asserted on the UN-CLAMPED, UN-AVERAGED x0 of the last step; on the tame family (every pixel
-    inside (-1, 1), like a trained model's coordinates) no error hides behind the final clamp."""
+def test_long_loop_vs_live_oracle():
+    """The ONE long loop whose oracle still runs on the GPU box (round-3 VERDICT, weak 5: 80 % of the suite's 833 s was the
+    CPU oracle inside this file; every other long loop now compares with a committed oracle trace, below): BASELINE's 50-step
+    DDIM at G = 32, two hypotheses, tame family, against the CPU oracle executed here.  The bar of 1e-3 is asserted on the
+    UN-CLAMPED, UN-AVERAGED x0 of the last step."""
     from dvd_amd import sampler, schedule
     from oracle import dvd_oracle as O
-    gain = synth.tame_gain(steps) if family == "tame" else 1.0
-    eng, orc, doc_t, inv1 = setup(grid, 1, hyp, gain)
+    grid, steps, hyp = 32, 50, 2
+    eng, orc, doc_t, inv1 = setup(grid, 1, hyp, synth.tame_gain(steps))
     tab = schedule.Tables(schedule.named_betas("cosine", steps))
     xT = torch.from_numpy(synth.synth_noise(0, hyp, grid, SEED_IN))
     tr_ref, tr = [], []
@@ -173,92 +167,85 @@ def test_long_loop_vs_oracle(grid, steps, hyp, family):
     per = [float((a.cpu() - b).pow(2).mean().sqrt()) for a, b in zip(tr, tr_ref)]
     err = float((out.cpu() - ref).pow(2).mean().sqrt())
     sat = _saturated(tr_ref[-1])
-    print(f"long loop rmse G={grid} S={steps} H={hyp} {family}: final {err:.2e}, un-clamped last x0 {per[-1]:.2e}, "
+    print(f"long loop rmse G={grid} S={steps} H={hyp} tame (live oracle): final {err:.2e}, un-clamped last x0 {per[-1]:.2e}, "
           f"last x0 std {float(tr_ref[-1].std()):.3f}, saturated pixels {sat:.4f}, per-step[::7]", per[::7])
-    if grid >= 66:
-        # large grids dither the weights of the 256-wide GEMMs by default (one GEMM pass); the same loop with the
-        # (hi, lo) split everywhere (2x the GEMM MFMAs, round 2's default) and with plain f16 weights, for the record
-        try:
-            for name, opts in (("split (dither off)", {"dither": 0}), ("plain f16 (no split, no dither)",
-                                                                       {"dither": 0, "split_weights": 0})):
-                for k, v in opts.items():
-                    eng.set_option(k, v)
-                tr2 = []
-                out2 = sampler.sample(eng, tab, xT.cuda(), trace=tr2)
-                per2 = [float((a.cpu() - b).pow(2).mean().sqrt()) for a, b in zip(tr2, tr_ref)]
-                print(f"   {name}: final {float((out2.cpu() - ref).pow(2).mean().sqrt()):.2e}, un-clamped last x0 "
-                      f"{per2[-1]:.2e}, per-step[::7]", per2[::7])
-                if "split_weights" not in opts:
-                    assert per2[-1] < 1e-3, per2[-1]
-        finally:
-            eng.set_option("dither", 1)
-            eng.set_option("split_weights", 1)
-    assert per[-1] < 1e-3, per[-1]          # un-clamped, un-averaged x0 of the last step
-    if family == "tame":
-        assert sat < 0.01, sat              # the family does what it is for
-        assert per[-1] < 6e-5, per[-1]      # measured 1.3e-5 .. 2.1e-5 on MI355X (x3), dithered or split alike
+    assert sat < 0.01, sat
+    assert per[-1] < 6e-5, per[-1]          # measured 1.3e-5 on MI355X (x3 + margin); north_star's bar is 1e-3
     assert err < 3.8e-4, (err, per[-1])
 
 
-@pytest.mark.parametrize("steps", [25, 250])
-def test_ddpm_loop_vs_oracle(steps):
-    """BASELINE configs[3]'s sampler (DDPM ancestral, FIXED_LARGE variance, fixed noise table) at G = 16 against the
-    oracle, short and at full length: 250 noise-driven steps accumulate the denoiser's error.  Tame family: the bar is
-    asserted on the un-clamped, un-averaged last x0."""
-    from dvd_amd import sampler, schedule
-    from oracle import dvd_oracle as O
-    grid = 16
-    eng, orc, doc_t, inv1 = setup(grid, 1, 2, synth.tame_gain(steps))
-    tab = schedule.Tables(schedule.named_betas("cosine", steps))
-    xT = torch.from_numpy(synth.synth_noise(0, 2, grid, SEED_IN))
-    noises = {i: torch.from_numpy(synth.synth_noise(0, 2, grid, SEED_IN, step=i)) for i in range(steps)}
-    tr_ref, tr = [], []
-    ref = orc.sample_loop(O.Schedule(steps), xT, {k: v[:1] for k, v in doc_t.items()}, sampler="ddpm", noises=noises,
-                          trace=tr_ref)
-    out = sampler.sample(eng, tab, xT.cuda(), sampler="ddpm", noise_fn=lambda i: noises[i].cuda(), trace=tr)
-    per = [float((a.cpu() - b).pow(2).mean().sqrt()) for a, b in zip(tr, tr_ref)]
-    err = float((out.cpu() - ref).pow(2).mean().sqrt())
-    sat = _saturated(tr_ref[-1])
-    print(f"ddpm loop S={steps}: final {err:.2e}, un-clamped last x0 {per[-1]:.2e}, last x0 std "
-          f"{float(tr_ref[-1].std()):.3f}, saturated pixels {sat:.4f}, per-step[::25]", per[::25])
-    assert sat < 0.01, sat
-    assert per[-1] < 1e-3 and err < 1e-3, (err, per[-1])
-    assert per[-1] < 6e-5, per[-1]          # measured 2.1e-5 (25 steps) / 1.1e-5 (250 steps) on MI355X (x3)
+# ------------------------------------------------------------------------------------------------
+# Long loops against COMMITTED ORACLE TRACES (tests/golden/oracle_<case>.npz, written by tests/tools/gen_oracle_traces.py:
+# the CPU oracle's un-clamped x0 at the kept loop positions and its final map; every input is regenerated here from the
+# same seeds).  The engine's roll-out is the only thing that runs on the box - the whole 50-step loop at G = 288 (95 minutes
+# of oracle time) is a 3-second test.
+#   absolute bars: north_star's 1e-3 on the un-clamped, un-averaged last x0, and ~3x the measured error on the tame family;
+#   relative bar : rmse / std(x0), the SAME for the tame and the plain family (round-3 ADVICE: the tame family scales the
+#                  final layer by 1.6 / S, which shrinks absolute errors ~30x): < 3e-4 at the last step (measured 5-8e-5),
+#                  < 1.2e-3 at every kept step (one evaluation on dithered weights: 4-6e-4).
+# ------------------------------------------------------------------------------------------------
+def _trace_case(name):
+    from tests.tools import gen_oracle_traces as T
+    z = np.load(os.path.join(GOLD, f"oracle_{name}.npz"))
+    grid, steps, hyp, family, smp = int(z["grid"]), int(z["steps"]), int(z["hyp"]), str(z["family"]), str(z["sampler"])
+    assert (grid, steps, hyp, family, smp) == tuple(T.CASES[name][:5])
+    sd, doc, xT, noises, gain = T.inputs(grid, steps, hyp, family, smp)
+    assert abs(gain - float(z["out_gain"])) < 1e-12
+    return z, grid, steps, hyp, family, smp, sd, doc, xT, noises
 
 
-def _ddpm_large_grid(steps):
-    """BASELINE configs[3] runs its ancestral steps at G = 288, where the weights of the 256-wide GEMMs are dithered:
-    the same sampler on a LARGE-tile grid (G = 72: T = 1296 > 1024 tokens, ragged), one hypothesis, tame family -
-    un-clamped last x0 against the oracle, dithered and split.  40 steps here (the oracle costs 2 s per step); the full
-    250 steps are run once per round by tests/tools/ddpm250_large_grid.py (8.5 minutes; profiles/r3_ddpm250_g72.txt:
-    6.5e-6 dithered, 6.2e-6 split)."""
+def _engine_rollout(eng, steps, smp, xT, noises, **opts):
     from dvd_amd import sampler, schedule
-    from oracle import dvd_oracle as O
-    grid = 72
-    eng, orc, doc_t, inv1 = setup(grid, 1, 1, synth.tame_gain(steps))
     tab = schedule.Tables(schedule.named_betas("cosine", steps))
-    xT = torch.from_numpy(synth.synth_noise(0, 1, grid, SEED_IN))
-    noises = {i: torch.from_numpy(synth.synth_noise(0, 1, grid, SEED_IN, step=i)) for i in range(steps)}
-    tr_ref = []
-    orc.sample_loop(O.Schedule(steps), xT, {k: v[:1] for k, v in doc_t.items()}, sampler="ddpm", noises=noises, trace=tr_ref)
-    res = {}
+    for k, v in opts.items():
+        eng.set_option(k, v)
+    tr = []
+    noise_fn = (lambda i: noises[i].cuda()) if smp == "ddpm" else None
+    out = sampler.sample(eng, tab, xT.cuda(), sampler=smp, noise_fn=noise_fn, trace=tr)
+    return tr, out
+
+
+TRACE_CASES = ["ddim_g16_s50_plain", "ddim_g16_s50_tame", "ddim_g72_s25_tame", "ddim_g96_s50_tame", "ddim_g96_s50_plain",
+               "ddpm_g16_s25_tame", "ddpm_g16_s250_tame", "ddpm_g72_s40_tame", "ddim_g288_s50_tame"]
+
+
+@pytest.mark.parametrize("name", TRACE_CASES)
+def test_long_loop_vs_oracle_trace(name):
+    """G = 96 is an UP-sampling, non-native grid like BASELINE's 288 (feat 64 -> G, T % 64 == 0: the LDS-DMA attention
+    kernels, warped-feat branch live from step 2), once on the tame and once on the PLAIN family (x0 std 7.8: the family of
+    the golden vectors); G = 72 is ragged (T = 1296, T % 64 = 16: the register-staged attention fallback and the GEMM edge
+    tiles); the DDPM cases are BASELINE configs[3]'s sampler (ancestral, FIXED_LARGE variance, fixed noise table) at 25 / 250
+    steps (G = 16) and on a large-tile grid (G = 72: dithered weights); ddim_g288_s50_tame is the HEADLINE configuration's
+    whole loop (T = 20 736 tokens, the r64p attention kernel and the 256-wide GEMMs on dithered weights at every step)."""
+    from dvd_amd.engine import Engine
+    z, grid, steps, hyp, family, smp, sd, doc, xT, noises = _trace_case(name)
+    eng = Engine(grid, 1, hyp)
+    eng.load_state_dict(sd)
+    del sd
+    eng.prepare(*[doc[k].cuda() for k in ("y512", "mask_cat", "mask_y512", "line_msk")])
+    kept, ref_x0, ref_final, std = [int(k) for k in z["kept"]], z["x0"], z["final"], z["x0_std"]
+    runs = {"default": {}}
+    if grid >= 66 and grid < 288:   # large grids dither by default: also the (hi, lo) split everywhere (round 2's default)
+        runs["split (dither off)"] = {"dither": 0}
     try:
-        for name, dither in (("dither", 1), ("split", 0)):
-            eng.set_option("dither", dither)
-            tr = []
-            sampler.sample(eng, tab, xT.cuda(), sampler="ddpm", noise_fn=lambda i: noises[i].cuda(), trace=tr)
-            res[name] = float((tr[-1].cpu() - tr_ref[-1]).pow(2).mean().sqrt())
+        for label, opts in runs.items():
+            tr, out = _engine_rollout(eng, steps, smp, xT, noises, **opts)
+            per = {k: float(np.sqrt(((tr[k].cpu().numpy() - ref_x0[j]) ** 2).mean())) for j, k in enumerate(kept)}
+            rel = {k: per[k] / float(std[k]) for k in kept}
+            err = float(np.sqrt(((out.cpu().numpy() - ref_final) ** 2).mean()))
+            last = steps - 1
+            print(f"{name} [{label}]: final {err:.2e}, un-clamped x0 rmse per kept step {per}, relative to the map's std "
+                  f"{ {k: round(v, 7) for k, v in rel.items()} }, last x0 std {float(std[last]):.3f}, saturated "
+                  f"{float(z['last_x0_saturated']):.4f}")
+            assert per[last] < 1e-3 and err < 1e-3, (label, per[last], err)            # north_star's bar, un-clamped
+            # relative to the map's std: 5-8e-5 at the end of a roll-out on BOTH families; a single evaluation on dithered
+            # weights carries the whole f16 weight rounding (4-6e-4 at the first step), which averages out over the steps
+            assert rel[last] < 3e-4 and max(rel.values()) < 1.2e-3, (label, rel)
+            if family == "tame":
+                assert float(z["last_x0_saturated"]) < 0.01
+                assert per[last] < 6e-5, (label, per[last])   # measured 0.65e-5 .. 2.1e-5 on MI355X, dithered or split alike
     finally:
-        eng.set_option("dither", 1)
-    print(f"ddpm {steps} steps at G=72: un-clamped last x0 rmse {res}, last x0 std {float(tr_ref[-1].std()):.3f}, saturated "
-          f"{_saturated(tr_ref[-1]):.4f}")
-    assert _saturated(tr_ref[-1]) < 0.01
-    assert res["dither"] < 1e-4 and res["split"] < 1e-4, res     # measured 6.5e-6 / 6.2e-6 at 250 steps
-    return res
-
-
-def test_ddpm_large_grid_vs_oracle():
-    _ddpm_large_grid(40)
+        eng.set_option("dither", 1 if grid >= 66 else 0)
 
 
 def test_batched_documents_match_single():
@@ -305,11 +292,12 @@ def test_graph_replay_equals_eager(grid):
         assert torch.equal(r, eager)
 
 
-def test_engine_at_the_baseline_grid_vs_oracle():
-    """G = 288 (BASELINE configs[1]-[4]) under -m gpu: Engine(288, 2 documents, 2 hypotheses).  (a) the first loop step
-    (t_model > 600: init_feat <- feat) and an evaluation on the warped-feature branch (feat_mode 2, init_flow = the
-    first step's x0) of document 0 / hypothesis 0 against the CPU oracle, coordinate RMSE < 1e-3; (b) the two documents
-    batched give the same bits as each document alone (no cross-document arithmetic at the production size)."""
+def test_engine_at_the_baseline_grid_batch_equals_single():
+    """G = 288 (BASELINE configs[1]-[4]) under -m gpu: Engine(288, 2 documents, 2 hypotheses): the first loop step
+    (t_model > 600: init_feat <- feat) and an evaluation on the warped-feature branch (feat_mode 2, init_flow = the first
+    step's x0) of two documents batched give the same bits as each document alone (no cross-document arithmetic at the
+    production size).  Parity with the oracle at this grid: test_long_loop_vs_oracle_trace[ddim_g288_s50_tame] (the whole
+    50-step loop), and every bench.py run (two live-oracle evaluations)."""
     from dvd_amd import sampler, schedule
     from dvd_amd.engine import Engine
     from oracle import dvd_oracle as O
@@ -343,18 +331,3 @@ def test_engine_at_the_baseline_grid_vs_oracle():
         assert torch.equal(a, x0_first[2 * d:2 * d + 2]), d
         assert torch.equal(b, x0_mid[2 * d:2 * d + 2]), d
     del one
-    # (a) against the oracle (document 0, hypothesis 0)
-    orc = O.Oracle(sd, G)
-    with torch.no_grad():
-        inv = orc.prepare(*[doc_t[k][:1] for k in keys])
-        x = xT[:1]
-        ref_first, _ = orc.forward(x, float(t_first), inv, torch.zeros_like(x), inv["feat"])
-        e1 = float((ref_first - x0_first[:1].cpu()).pow(2).mean().sqrt())
-        flow = x0_first[:1].cpu()
-        init_feat = O.grid_sample_ref(inv["feat"], (flow + O.base_grid(G, G)) * 2 - 1)
-        ref_mid, _ = orc.forward(x, float(t_mid), inv, flow, init_feat)
-        e2 = float((ref_mid - x0_mid[:1].cpu()).pow(2).mean().sqrt())
-    print(f"G=288 engine vs oracle: first step {e1:.2e}, warped-feature branch {e2:.2e}")
-    # ONE evaluation sees the whole f16 rounding of the dithered weights (the dither only averages out over steps):
-    # measured 1.05e-4 / 1.25e-4 (5.2e-5 with the split in every GEMM); north_star's bar is 1e-3
-    assert e1 < 3e-4 and e2 < 3e-4, (e1, e2)
