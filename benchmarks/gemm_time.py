@@ -10,7 +10,7 @@ from dvd_amd import ops
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 MODE = sys.argv[2] if len(sys.argv) > 2 else "plain"
 EXE = 4.0 if MODE == "split" else 2.0
-M32 = os.environ.get("DVD_GEMM_M16", "-")
+M32 = os.environ.get("DVD_GEMM_M16", "-") + ("/big2" if os.environ.get("DVD_GEMM_BIG2") else "")
 M = 331776
 for name, N, K in (("qk  N=3072 K=1536", 3072, 1536), ("c1  N=2048 K=1536", 2048, 1536), ("fc  N=1536 K=1536", 1536, 1536),
                    ("c2  N=1536 K=2048", 1536, 2048)):

@@ -824,6 +824,228 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_big_kernel(GemmArgs p) {
 
 
 #ifdef DVD_LAB
+
+// ================================================================================================
+// Round 4: the 256 x 256 tile with ONE wave per SIMD ("big2").  Four waves (2 x 2), each 128 x 128 of the tile = 4 x 4
+// accumulators = all 256 AGPRs, so a k-step reads 8 fragments for 16 MFMAs (0.5 ds_read_b128 per MFMA; the 8-wave kernel:
+// 0.75) and nothing competes with the wave for its SIMD.  What the second wave per SIMD bought the 8-wave kernel - cover
+// for LDS latency, LDS-DMA issue and the barrier - is bought here by the schedule, pinned like the attention kernel's
+// (flash_attn_r64p_kernel, attention.hip): the K loop is a sequence of `asm volatile` statements of four MFMAs each, with
+// the fragment reads of the NEXT half slab and the LDS-DMA pieces of the half slab three ahead in their gaps.
+//   * K is walked in HALF slabs of 32 (two k-steps, 32 MFMAs per wave): [A 256 x 32 | B 256 x 32] = 32 KiB, a ring of four
+//     buffers.  LDS rows are 64 B, 16-byte chunk c of row r at c ^ ((r >> 2) & 3) (conflict-free ds_read_b128, the
+//     attention kernel's V^T image); one LDS-DMA piece = 16 rows.
+//   * iteration j (half slab j in registers): 8 MFMAs | vmcnt(8) + THE barrier | 24 MFMAs with the 16 fragment reads of
+//     half slab j + 1 and this wave's 8 pieces of half slab j + 3.  At the barrier half slab j + 1 has landed (its pieces
+//     were issued two iterations ago) and every wave has left iteration j - 1, whose buffer the new pieces overwrite.  The
+//     LDS-DMA queue is never drained inside the K loop (counted vmcnt), the LDS queue is waited for with counted lgkmcnt.
+// Plain and residual epilogues through the shared LDS staging (epilogue_block64), tile walk of the 8-wave kernel.  One
+// weight tensor only (the dithered weights of large grids); a (hi, lo) pair takes the split kernels.
+// MEASURED (MI355X, benchmarks/gemm_time.py, same process order A/B/A/B, M = 331 776; profiles/r4_gemm_big2.txt) and
+// REJECTED: 943-961 TF/s at K = 1536 (N = 3072 / 2048 / 1536) and 1031-1036 at K = 2048 against 1015-1041 and 1077-1081
+// for the 8-wave kernel: 4-9 % SLOWER, bit-identical results.  The K loop is not where the 8-wave kernel loses: a 256 x 256
+// tile needs 32 KiB of operands per 1024 matrix cycles = 32 B/clk, the CU's whole L2 -> LDS rate, whatever
+// the wave layout; what the one-wave layout adds is an epilogue run by four waves instead of eight (twice the staging
+// and store work per wave, half the stores in flight) and a per-tile prologue nobody hides.  LAB ONLY (DVD_GEMM_BIG2=1).
+// ================================================================================================
+namespace big2 {
+#define B2_MF "v_mfma_f32_32x32x16_f16 "
+#define B2_RD(i_) "ds_read_b128 %[n" #i_ "], %[addr] offset:%[o" #i_ "]\n\t"
+#define B2_DMA(i_) "s_mov_b32 m0, %[l" #i_ "]\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %[v" #i_ "], %[gb]\n\t"
+// four MFMAs of one accumulator row: acc[n] += a . b[n]
+__device__ __forceinline__ void mm4(floatx16& c0, floatx16& c1, floatx16& c2, floatx16& c3, const half8& a, const half8& b0,
+                                    const half8& b1, const half8& b2, const half8& b3) {
+  asm volatile(B2_MF "%[c0], %[a], %[b0], %[c0]\n\t" B2_MF "%[c1], %[a], %[b1], %[c1]\n\t" B2_MF "%[c2], %[a], %[b2], %[c2]\n\t"
+               B2_MF "%[c3], %[a], %[b3], %[c3]"
+               : [c0] "+a"(c0), [c1] "+a"(c1), [c2] "+a"(c2), [c3] "+a"(c3)
+               : [a] "v"(a), [b0] "v"(b0), [b1] "v"(b1), [b2] "v"(b2), [b3] "v"(b3));
+}
+// the same behind a counted LDS wait
+template <int LG>
+__device__ __forceinline__ void mm4_wait(floatx16& c0, floatx16& c1, floatx16& c2, floatx16& c3, const half8& a, const half8& b0,
+                                         const half8& b1, const half8& b2, const half8& b3) {
+  asm volatile("s_waitcnt lgkmcnt(%[lg])\n\t" B2_MF "%[c0], %[a], %[b0], %[c0]\n\t" B2_MF "%[c1], %[a], %[b1], %[c1]\n\t"
+               B2_MF "%[c2], %[a], %[b2], %[c2]\n\t" B2_MF "%[c3], %[a], %[b3], %[c3]"
+               : [c0] "+a"(c0), [c1] "+a"(c1), [c2] "+a"(c2), [c3] "+a"(c3)
+               : [a] "v"(a), [b0] "v"(b0), [b1] "v"(b1), [b2] "v"(b2), [b3] "v"(b3), [lg] "i"(LG));
+}
+// four MFMAs, each followed by one fragment read of the next half slab (four 32-row blocks of ONE operand and k-step:
+// one address register, immediates 0 / 2048 / 4096 / 6144), and two LDS-DMA pieces (after the 2nd and the 4th MFMA)
+template <int LG>   // LG >= 0: counted LDS wait in front
+__device__ __forceinline__ void mm4_rd4_dma2(floatx16& c0, floatx16& c1, floatx16& c2, floatx16& c3, const half8& a,
+                                             const half8& b0, const half8& b1, const half8& b2, const half8& b3, half8& n0,
+                                             half8& n1, half8& n2, half8& n3, unsigned addr, const char* gb, unsigned l0,
+                                             unsigned v0, unsigned l1, unsigned v1) {
+  if constexpr (LG >= 0) {
+    asm volatile("s_waitcnt lgkmcnt(%[lg])\n\t" B2_MF "%[c0], %[a], %[b0], %[c0]\n\t" B2_RD(0) B2_MF "%[c1], %[a], %[b1], %[c1]\n\t"
+                 B2_RD(1) B2_DMA(0) B2_MF "%[c2], %[a], %[b2], %[c2]\n\t" B2_RD(2) B2_MF "%[c3], %[a], %[b3], %[c3]\n\t" B2_RD(3)
+                 B2_DMA(1)
+                 : [c0] "+a"(c0), [c1] "+a"(c1), [c2] "+a"(c2), [c3] "+a"(c3), [n0] "=&v"(n0), [n1] "=&v"(n1), [n2] "=&v"(n2),
+                   [n3] "=&v"(n3)
+                 : [a] "v"(a), [b0] "v"(b0), [b1] "v"(b1), [b2] "v"(b2), [b3] "v"(b3), [addr] "v"(addr), [o0] "i"(0),
+                   [o1] "i"(2048), [o2] "i"(4096), [o3] "i"(6144), [gb] "s"(gb), [l0] "s"(l0), [v0] "v"(v0), [l1] "s"(l1),
+                   [v1] "v"(v1), [lg] "i"(LG)
+                 : "memory");
+  } else {
+    asm volatile(B2_MF "%[c0], %[a], %[b0], %[c0]\n\t" B2_RD(0) B2_MF "%[c1], %[a], %[b1], %[c1]\n\t" B2_RD(1) B2_DMA(0)
+                 B2_MF "%[c2], %[a], %[b2], %[c2]\n\t" B2_RD(2) B2_MF "%[c3], %[a], %[b3], %[c3]\n\t" B2_RD(3) B2_DMA(1)
+                 : [c0] "+a"(c0), [c1] "+a"(c1), [c2] "+a"(c2), [c3] "+a"(c3), [n0] "=&v"(n0), [n1] "=&v"(n1), [n2] "=&v"(n2),
+                   [n3] "=&v"(n3)
+                 : [a] "v"(a), [b0] "v"(b0), [b1] "v"(b1), [b2] "v"(b2), [b3] "v"(b3), [addr] "v"(addr), [o0] "i"(0),
+                   [o1] "i"(2048), [o2] "i"(4096), [o3] "i"(6144), [gb] "s"(gb), [l0] "s"(l0), [v0] "v"(v0), [l1] "s"(l1),
+                   [v1] "v"(v1)
+                 : "memory");
+  }
+}
+__device__ __forceinline__ void dma_piece(const char* gb, unsigned voff, unsigned lds) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %0" ::"s"(gb), "s"(lds), "v"(voff) : "memory");
+}
+struct Frags {        // one half slab's operands of a wave: [k-step][32-row block]
+  half8 a[2][4], b[2][4];
+};
+constexpr int HALF = 32768, BOFF = 16384, NBUF = 4;
+
+// One iteration: the 32 MFMAs of the half slab in `cur`, the reads of the next one into `nxt`, the pieces of the half slab
+// three ahead.  rd_*: fragment read bases (k-step 0 / 1 of A, of B) inside the NEXT half slab's buffer.
+__device__ __forceinline__ void half_slab(floatx16 (&acc)[4][4], const Frags& cur, Frags& nxt, unsigned rd_a0, unsigned rd_a1,
+                                          unsigned rd_b0, unsigned rd_b1, const char* a_src, const char* b_src,
+                                          const unsigned (&aoff)[4], const unsigned (&boff)[4], unsigned lds_dst) {
+#define ROW(m_) acc[m_][0], acc[m_][1], acc[m_][2], acc[m_][3]
+#define OPS(s_, m_) cur.a[s_][m_], cur.b[s_][0], cur.b[s_][1], cur.b[s_][2], cur.b[s_][3]
+  mm4_wait<8>(ROW(0), OPS(0, 0));                 // this half slab's k-step-0 fragments have arrived
+  mm4(ROW(1), OPS(0, 1));
+  // half slab j + 1 has landed in every wave's view; every wave has left the previous iteration
+  asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+  mm4_rd4_dma2<-1>(ROW(2), OPS(0, 2), nxt.b[0][0], nxt.b[0][1], nxt.b[0][2], nxt.b[0][3], rd_b0, a_src, lds_dst, aoff[0],
+                   lds_dst + 1024, aoff[1]);
+  mm4_rd4_dma2<-1>(ROW(3), OPS(0, 3), nxt.a[0][0], nxt.a[0][1], nxt.a[0][2], nxt.a[0][3], rd_a0, a_src, lds_dst + 2048, aoff[2],
+                   lds_dst + 3072, aoff[3]);
+  // k-step 1: its fragments were read an iteration ago; the 8 reads just issued may still be in flight
+  mm4_rd4_dma2<8>(ROW(0), OPS(1, 0), nxt.b[1][0], nxt.b[1][1], nxt.b[1][2], nxt.b[1][3], rd_b1, b_src, lds_dst + BOFF, boff[0],
+                  lds_dst + BOFF + 1024, boff[1]);
+  mm4_rd4_dma2<-1>(ROW(1), OPS(1, 1), nxt.a[1][0], nxt.a[1][1], nxt.a[1][2], nxt.a[1][3], rd_a1, b_src, lds_dst + BOFF + 2048,
+                   boff[2], lds_dst + BOFF + 3072, boff[3]);
+  mm4(ROW(2), OPS(1, 2));
+  mm4(ROW(3), OPS(1, 3));
+#undef ROW
+#undef OPS
+}
+}  // namespace big2
+
+__global__ void __launch_bounds__(256, 1) gemm_nt_big2_kernel(GemmArgs p) {
+  using namespace big2;
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // 4 x [A half | B half]; then the epilogue's staging
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  const int nwg = p.ntm * p.ntn;
+  const int z = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const int wr = wave >> 1, wc = wave & 1;
+  const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t)smem;
+  // fragment read bases inside buffer 0: row (128 w + r) of the operand half, chunk (2 s + h) ^ ((r >> 2) & 3)
+  const unsigned fa0 = lds0 + (128 * wr + r) * 64 + ((h ^ ((r >> 2) & 3)) * 16), fa1 = fa0 ^ 32;
+  const unsigned fb0 = lds0 + BOFF + (128 * wc + r) * 64 + ((h ^ ((r >> 2) & 3)) * 16), fb1 = fb0 ^ 32;
+  const int nh = p.K / 32;                         // half slabs
+  for (int vid = blockIdx.x; vid < nwg; vid += gridDim.x) {
+    int tm, tn;
+    tile_coords(vid, p.ntm, p.ntn, tm, tn);
+    tm = __builtin_amdgcn_readfirstlane(tm); tn = __builtin_amdgcn_readfirstlane(tn);
+    const int bm0 = tm * 256, bn0 = tn * 256;
+    const _Float16* A = (const _Float16*)p.A + z * p.sA;
+    const _Float16* B = (const _Float16*)p.B + z * p.sB;
+    // per-lane source offsets of this wave's 4 + 4 pieces of a half slab: piece i = rows 16 (4 wave + i) .. + 15, LDS slot
+    // (row, pos = lane & 3) <- chunk pos ^ ((row >> 2) & 3); rows clamped into the matrix (ragged last tiles)
+    unsigned aoff[4], boff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = 16 * (4 * wave + i) + (lane >> 2), pos = lane & 3;
+      const int logical = pos ^ ((row >> 2) & 3);
+      const int ra = min(bm0 + row, p.M - 1) - bm0, rb = min(bn0 + row, p.N - 1) - bn0;
+      aoff[i] = (unsigned)ra * (unsigned)(p.lda * 2) + logical * 16;
+      boff[i] = (unsigned)rb * (unsigned)(p.ldb * 2) + logical * 16;
+    }
+    const char* Atile = (const char*)(A + (size_t)bm0 * p.lda);
+    const char* Btile = (const char*)(B + (size_t)bn0 * p.ldb);
+    // the 16 accumulators are zeroed IN the accumulator file, one MFMA each (0 . 0 + 0: the operand fragment is a zero
+    // VGPR quad): written as `acc = 0` the compiler builds 256 zero VGPRs first and spills them around the prologue
+    floatx16 acc[4][4];
+    {
+      const half8 zf = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n)
+          asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %1, 0" : "=a"(acc[m][n]) : "v"(zf));
+    }
+    const unsigned pdst = lds0 + (4 * wave) * 1024;         // this wave's pieces inside a buffer's A half
+    // ---- prologue: half slabs 0, 1, 2 -> buffers 0, 1, 2 (clamped re-loads of the last one when K is short)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const size_t kb = (size_t)min(j, nh - 1) * 64;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        dma_piece(Atile + kb, aoff[i], pdst + j * HALF + i * 1024);
+        dma_piece(Btile + kb, boff[i], pdst + j * HALF + BOFF + i * 1024);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");      // half slab 0 has landed
+    Frags f0, f1;
+    // the first half slab's fragments, in the order the loop's counted waits expect: B k0, A k0, B k1, A k1
+#define B2_PRIME(dst_, base_, m_) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst_) : "v"(base_), "i"((m_) * 2048))
+    B2_PRIME(f0.b[0][0], fb0, 0); B2_PRIME(f0.b[0][1], fb0, 1); B2_PRIME(f0.b[0][2], fb0, 2); B2_PRIME(f0.b[0][3], fb0, 3);
+    B2_PRIME(f0.a[0][0], fa0, 0); B2_PRIME(f0.a[0][1], fa0, 1); B2_PRIME(f0.a[0][2], fa0, 2); B2_PRIME(f0.a[0][3], fa0, 3);
+    B2_PRIME(f0.b[1][0], fb1, 0); B2_PRIME(f0.b[1][1], fb1, 1); B2_PRIME(f0.b[1][2], fb1, 2); B2_PRIME(f0.b[1][3], fb1, 3);
+    B2_PRIME(f0.a[1][0], fa1, 0); B2_PRIME(f0.a[1][1], fa1, 1); B2_PRIME(f0.a[1][2], fa1, 2); B2_PRIME(f0.a[1][3], fa1, 3);
+#undef B2_PRIME
+    // ---- K loop, two half slabs per trip (the fragment sets alternate by name)
+    int rdbuf = 1;                                   // buffer of half slab j + 1
+    for (int j = 0; j < nh; j += 2) {
+#pragma unroll
+      for (int par = 0; par < 2; ++par) {
+        const int jj = j + par;
+        if (jj < nh) {                               // wave-uniform (K / 32 may be odd)
+          const unsigned ro = (unsigned)rdbuf * HALF;
+          const int wrbuf = (rdbuf + 2) & 3;         // buffer of half slab j + 3 = the one half slab j - 1 was read from
+          const size_t kb = (size_t)min(jj + 3, nh - 1) * 64;
+          if (par == 0)
+            half_slab(acc, f0, f1, fa0 + ro, fa1 + ro, fb0 + ro, fb1 + ro, Atile + kb, Btile + kb, aoff, boff, pdst + wrbuf * HALF);
+          else
+            half_slab(acc, f1, f0, fa0 + ro, fa1 + ro, fb0 + ro, fb1 + ro, Atile + kb, Btile + kb, aoff, boff, pdst + wrbuf * HALF);
+          rdbuf = (rdbuf + 1) & 3;
+        }
+      }
+    }
+    // the ring still has pieces and reads in flight (clamped re-loads): drain them before LDS becomes the epilogue's
+    // staging area; the last MFMAs must have written their accumulators before the compiler's code reads them
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 15\n\ts_nop 7\n\ts_barrier" ::: "memory");
+
+    // ---------------- epilogue (the 8-wave kernel's flavours) ----------------
+    float* C32 = p.C32 ? p.C32 + z * p.sC32 : nullptr;
+    _Float16* C16 = p.C16 ? p.C16 + z * p.sC16 : nullptr;
+    const float* bias = p.bias ? p.bias + z * p.sBias : nullptr;
+    const float* res = p.res ? p.res + z * p.sRes : nullptr;
+    const float* gate = p.gate ? p.gate + z * p.sGate : nullptr;
+    float* stage = (float*)smem + wave * (64 * 64);
+    int lane_e = lane;
+    asm volatile("" : "+v"(lane_e));                 // see gemm_nt_big_kernel: keep epilogue addressing out of the K loop
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+      for (int nb = 0; nb < 2; ++nb) {
+        __builtin_amdgcn_sched_barrier(0);   // one 64 x 64 block at a time: 64 accumulator values in VGPRs, not 256
+        const int row0 = bm0 + 128 * wr + 64 * mb, col0 = bn0 + 128 * wc + 64 * nb;
+        if (res)
+          epilogue_block64<1>(p, stage, acc[2 * mb][2 * nb], acc[2 * mb][2 * nb + 1], acc[2 * mb + 1][2 * nb],
+                              acc[2 * mb + 1][2 * nb + 1], row0, col0, lane_e, C32, C16, bias, res, gate);
+        else
+          epilogue_block64<0>(p, stage, acc[2 * mb][2 * nb], acc[2 * mb][2 * nb + 1], acc[2 * mb + 1][2 * nb],
+                              acc[2 * mb + 1][2 * nb + 1], row0, col0, lane_e, C32, C16, bias, res, gate);
+      }
+    __syncthreads();   // every wave has read its staging region back: the next tile's LDS-DMA may overwrite it
+  }
+}
+
 // ================================================================================================
 // The same 256 x 256 x 64 kernel on v_mfma_f32_16x16x32_f16.  Both MFMA shapes do the same FLOPs per cycle, read the
 // same number of fragments per FLOP on this wave tile (12 ds_read_b128 per 32-deep step) and use the same LDS image; but
@@ -1457,6 +1679,22 @@ extern "C" int dvd_gemm_nt(const dvd_gemm_desc* d, void* stream) {
     if (nblk > 256) nblk = 256;
     gemm_nt_big16_kernel<<<dim3(nblk, d->batch), 512, LDS, (hipStream_t)stream>>>(p);
     return check_launch("gemm_nt(big16)");
+  }
+#endif
+#ifdef DVD_LAB
+  if (big && !d->B_lo && !d->A_lo && d->K % 32 == 0 && p.vec_epilogue && !d->pos && !d->gate && !(d->bias && d->bias_row) &&
+      getenv("DVD_GEMM_BIG2")) {
+    p.ntm = cdiv(d->M, 256); p.ntn = d->N / 256;
+    constexpr int LDS = big2::NBUF * big2::HALF;
+    static DeviceOnce once2;
+    if (const auto bit = DeviceOnce::current_bit(); once2.need(bit)) {
+      (void)hipFuncSetAttribute((const void*)gemm_nt_big2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+      once2.done(bit);
+    }
+    int nblk = p.ntm * p.ntn;
+    if (nblk > 256) nblk = 256;
+    gemm_nt_big2_kernel<<<dim3(nblk, d->batch), 256, LDS, (hipStream_t)stream>>>(p);
+    return check_launch("gemm_nt(big2)");
   }
 #endif
   if (big) {

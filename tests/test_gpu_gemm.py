@@ -336,3 +336,35 @@ def test_gelu_epilogue_range(ops):
     assert bool((out.cpu()[:, 1:] == out.cpu()[:, :1]).all())   # every column saw the same value
     neg = got[(x < -10.5)]
     assert bool((neg == 0).all()) and bool(torch.signbit(neg).all())   # exactly -0, as the tanh form in fp32
+
+
+@pytest.mark.parametrize("M,N,K", [(1024, 1536, 1536), (1100, 512, 256), (2048, 3072, 1536), (4096, 256, 64), (777, 256, 192)])
+def test_gemm_big2_kernel(ops, lab, monkeypatch, M, N, K):
+    """LAB switch DVD_GEMM_BIG2: the one-wave-per-SIMD 256 x 256 kernel (gemm_nt_big2_kernel: 4 waves x 128 x 128, half-slab
+    ring of four, pinned asm stream; measured 4-9 % slower than the 8-wave kernel and kept in the lab build only) on the
+    large-tile shapes incl. ragged M and K = 64 (a ring shorter than its depth): exact integers, then random data with the plain, bias + GELU -> f16 and residual epilogues."""
+    monkeypatch.setenv("DVD_GEMM_BIG2", "1")
+    rng = np.random.RandomState(M + N + K)
+    ai = torch.from_numpy(rng.randint(-4, 5, (M, K)).astype(np.float32)).half()
+    bi = torch.from_numpy(rng.randint(-4, 5, (N, K)).astype(np.float32)).half()      # asymmetric, non-square
+    out = torch.zeros(M, N, device="cuda")
+    ops.gemm_nt(ai.cuda(), bi.cuda(), out32=out)
+    assert torch.equal(out.cpu(), ai.float() @ bi.float().t())
+    a, b = rnd(f"b2a{M}{K}", (M, K)).half(), rnd(f"b2b{N}{K}", (N, K)).half()
+    ref = a.double() @ b.double().t()
+    ops.gemm_nt(a.cuda(), b.cuda(), out32=out)
+    assert (out.cpu().double() - ref).abs().max().item() < 1e-4 * K ** 0.5
+    bias, res = rnd("b2bias", (N,)), rnd("b2res", (M, N))
+    out16 = torch.zeros(M, N, dtype=torch.float16, device="cuda")
+    ops.gemm_nt(a.cuda(), b.cuda(), out16=out16, bias=bias.cuda(), act=1)
+    refg = torch.nn.functional.gelu(ref + bias.double(), approximate="tanh")
+    assert (out16.cpu().double() - refg).abs().max().item() < 2e-2
+    out2 = res.clone().cuda()
+    ops.gemm_nt(a.cuda(), b.cuda(), out32=out2, bias=bias.cuda(), act=2, res=out2)
+    ref2 = torch.relu(ref + bias.double()) + res.double()
+    assert (out2.cpu().double() - ref2).abs().max().item() < 1e-4 * K ** 0.5 + 1e-5
+    # and the same bits as the 8-wave kernel would give?  No: the K order inside a tile is the same (k ascending), so yes
+    monkeypatch.delenv("DVD_GEMM_BIG2")
+    out8 = torch.zeros(M, N, device="cuda")
+    ops.gemm_nt(a.cuda(), b.cuda(), out32=out8)
+    assert torch.equal(out8, out), "big2 and the 8-wave kernel accumulate k in the same order: equal bits expected"
