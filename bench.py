@@ -428,7 +428,7 @@ def main(argv=None):
         dist.destroy_process_group()
 
 
-def other_configs(dev, blob288, H, FH, FW, want_cpu=True):
+def other_configs(dev, blob288, H, FH, FW, want_cpu=True, legs=("cfg4", "cfg3", "native")):
     """Bounded legs for the BASELINE.json configurations the headline is NOT quoted on, each with its own time, value and
     parity figure (the headline fields of the line are untouched):
       configs[4]  16 documents, 50-step DDIM, G = 288, + 3508x2480 unwarp: ONE whole batch;
@@ -456,75 +456,79 @@ def other_configs(dev, blob288, H, FH, FW, want_cpu=True):
         torch.cuda.synchronize()
         return time.perf_counter() - t0, r
 
-    # ---- configs[4]: 16 documents + full-resolution unwarp --------------------------------------------------------
-    B = 16
-    eng = Engine(G, B, H, device=dev)
-    eng.bind_blob(blob288)
-    cond = docs(B, G)
-    x_T = torch.randn(B * H, 2, G, G, device=dev, generator=gen)
-    src_u8 = torch.randint(0, 256, (B, FH, FW, 3), device=dev, dtype=torch.uint8, generator=gen)
-    tab = schedule.Tables(schedule.named_betas("cosine", 50))
+    if "cfg4" in legs:
+        # ---- configs[4]: 16 documents + full-resolution unwarp --------------------------------------------------------
+        B = 16
+        eng = Engine(G, B, H, device=dev)
+        eng.bind_blob(blob288)
+        cond = docs(B, G)
+        x_T = torch.randn(B * H, 2, G, G, device=dev, generator=gen)
+        src_u8 = torch.randint(0, 256, (B, FH, FW, 3), device=dev, dtype=torch.uint8, generator=gen)
+        tab = schedule.Tables(schedule.named_betas("cosine", 50))
 
-    def cfg4():
-        eng.prepare(*cond)
-        flow = sampler.sample(eng, tab, x_T)
-        return flow, ops.unwarp_u8_batch(flow, src_u8)
-    dt, (flow, outs) = timed(cfg4)
-    # parity of the leg's own product: document 0's unwarped u8 image against the CPU oracle's tail on the same flow
-    par = None
-    if want_cpu:
-        from oracle import dvd_oracle as O
-        srcf = src_u8[0].permute(2, 0, 1)[None].float().cpu()
-        _, _, ref8 = O.unwarp_tail(flow[:1].cpu(), srcf)
-        got8 = outs[0].cpu().numpy().astype(np.int32)
-        d = np.abs(got8 - ref8.astype(np.int32))
-        par = {"what": "document 0: fused u8 unwarp (3508x2480) vs the CPU oracle's upsample + grid_sample + uint8 on the "
-                       "same flow", "pixels_equal": float((d == 0).mean()), "max_abs_u8": int(d.max()),
-               "ok": bool((d <= 1).mean() > 0.9999)}
-    out["configs[4]"] = {"workload": f"BASELINE configs[4]: batch={B} documents x {H} hypotheses, 50-step DDIM, 288x288 grid, "
-                                     f"+ {FH}x{FW} u8 unwarp", "batches_timed": 1, "ms_per_batch": round(dt * 1e3, 1),
-                         "value": round(B / dt, 5), "unit": "documents/s", "parity": par}
-    del eng, cond, x_T, src_u8, outs, flow
-    torch.cuda.empty_cache()
+        def cfg4():
+            eng.prepare(*cond)
+            flow = sampler.sample(eng, tab, x_T)
+            return flow, ops.unwarp_u8_batch(flow, src_u8)
+        dt, (flow, outs) = timed(cfg4)
+        # parity of the leg's own product: document 0's unwarped u8 image against the CPU oracle's tail on the same flow
+        par = None
+        if want_cpu:
+            from oracle import dvd_oracle as O
+            srcf = src_u8[0].permute(2, 0, 1)[None].float().cpu()
+            _, _, ref8 = O.unwarp_tail(flow[:1].cpu(), srcf)
+            got8 = outs[0].cpu().numpy().astype(np.int32)
+            d = np.abs(got8 - ref8.astype(np.int32))
+            par = {"what": "document 0: fused u8 unwarp (3508x2480) vs the CPU oracle's upsample + grid_sample + uint8 on the "
+                           "same flow", "pixels_equal": float((d == 0).mean()), "max_abs_u8": int(d.max()),
+                   "ok": bool((d <= 1).mean() > 0.9999)}
+        out["configs[4]"] = {"workload": f"BASELINE configs[4]: batch={B} documents x {H} hypotheses, 50-step DDIM, 288x288 grid, "
+                                         f"+ {FH}x{FW} u8 unwarp", "batches_timed": 1, "ms_per_batch": round(dt * 1e3, 1),
+                             "value": round(B / dt, 5), "unit": "documents/s", "parity": par}
+        del eng, cond, x_T, src_u8, outs, flow
+        torch.cuda.empty_cache()
 
-    # ---- configs[3]: 250-step DDPM at 4 documents ------------------------------------------------------------------
-    B = 4
-    eng = Engine(G, B, H, device=dev)
-    eng.bind_blob(blob288)
-    cond = docs(B, G)
-    x_T = torch.randn(B * H, 2, G, G, device=dev, generator=gen)
-    tab = schedule.Tables(schedule.named_betas("cosine", 250))
-    last = {}
+    if "cfg3" in legs:
+        # ---- configs[3]: 250-step DDPM at 4 documents ------------------------------------------------------------------
+        B = 4
+        eng = Engine(G, B, H, device=dev)
+        eng.bind_blob(blob288)
+        cond = docs(B, G)
+        x_T = torch.randn(B * H, 2, G, G, device=dev, generator=gen)
+        tab = schedule.Tables(schedule.named_betas("cosine", 250))
+        last = {}
 
-    def noise_fn(i):
-        z = torch.randn(B * H, 2, G, G, device=dev, generator=gen)
-        if i == 125:
-            last[i] = z
-        return z
+        def noise_fn(i):
+            z = torch.randn(B * H, 2, G, G, device=dev, generator=gen)
+            if i == 125:
+                last[i] = z
+            return z
 
-    def cfg3():
-        eng.prepare(*cond)
-        return sampler.sample(eng, tab, x_T, sampler="ddpm", noise_fn=noise_fn)
-    dt, flow = timed(cfg3)
-    # parity of the scheduler path this leg exercises: one ancestral step on the run's own tensors vs the oracle's formula
-    par = None
-    if want_cpu:
-        from oracle import dvd_oracle as O
-        i = 125
-        x_t, x0 = x_T[:2].contiguous(), flow.repeat_interleave(H, 0)[:2].contiguous()
-        nz = last[i][:2].contiguous()
-        got = ops.sched_step(tab.ddpm_coef(i), x_t, x0, nz).cpu()
-        ref = O.ddpm_step(O.Schedule(250), i, x_t.cpu(), x0.cpu(), nz.cpu())
-        err = float((got - ref).abs().max())
-        par = {"what": "fused DDPM step (t = 125, FIXED_LARGE) on this run's tensors vs the oracle's p_mean_variance + "
-                       "noise line", "max_abs": err, "ok": bool(err < 1e-5)}
-    out["configs[3]"] = {"workload": f"BASELINE configs[3] at batch={B} instead of 32 documents (x {H} hypotheses): 250-step "
-                                     "DDPM ancestral sampling, 288x288 grid (no unwarp in this configuration)",
-                         "batches_timed": 1, "ms_per_batch": round(dt * 1e3, 1), "value": round(B / dt, 5),
-                         "unit": "documents/s", "finite": bool(torch.isfinite(flow).all()), "parity": par}
-    del eng, cond, x_T, flow, last
-    torch.cuda.empty_cache()
+        def cfg3():
+            eng.prepare(*cond)
+            return sampler.sample(eng, tab, x_T, sampler="ddpm", noise_fn=noise_fn)
+        dt, flow = timed(cfg3)
+        # parity of the scheduler path this leg exercises: one ancestral step on the run's own tensors vs the oracle's formula
+        par = None
+        if want_cpu:
+            from oracle import dvd_oracle as O
+            i = 125
+            x_t, x0 = x_T[:2].contiguous(), flow.repeat_interleave(H, 0)[:2].contiguous()
+            nz = last[i][:2].contiguous()
+            got = ops.sched_step(tab.ddpm_coef(i), x_t, x0, nz).cpu()
+            ref = O.ddpm_step(O.Schedule(250), i, x_t.cpu(), x0.cpu(), nz.cpu())
+            err = float((got - ref).abs().max())
+            par = {"what": "fused DDPM step (t = 125, FIXED_LARGE) on this run's tensors vs the oracle's p_mean_variance + "
+                           "noise line", "max_abs": err, "ok": bool(err < 1e-5)}
+        out["configs[3]"] = {"workload": f"BASELINE configs[3] at batch={B} instead of 32 documents (x {H} hypotheses): 250-step "
+                                         "DDPM ancestral sampling, 288x288 grid (no unwarp in this configuration)",
+                             "batches_timed": 1, "ms_per_batch": round(dt * 1e3, 1), "value": round(B / dt, 5),
+                             "unit": "documents/s", "finite": bool(torch.isfinite(flow).all()), "parity": par}
+        del eng, cond, x_T, flow, last
+        torch.cuda.empty_cache()
 
+    if "native" not in legs:
+        return out
     # ---- the reference's native point, from a decoded image -------------------------------------------------------
     Gn, Sn = 64, 3
     sd = synth.synth_state_dict(Gn, seed=7, blocks=[11])
@@ -571,6 +575,42 @@ def other_configs(dev, blob288, H, FH, FW, want_cpu=True):
                                        "decoded 1024x768 image: ingest + U2NETP x2 + line UNet + sampling + u8 unwarp",
                            "documents_timed": len(lat), "ms_per_document_median": round(statistics.median(lat), 3),
                            "value": round(1e3 / statistics.median(lat), 2), "unit": "documents/s", "parity": par}
+    # ---- the same operating point BATCHED (admin/local.py's per-document settings, `batch_docs` documents per engine
+    # batch - what val_TDiff.run does): B distinct decoded images -> ingest each, ONE pass of the three pre-stage nets over
+    # the batch, ONE engine batch (B x H samples), one batched unwarp.  Parity: every document of the batch must give the bits
+    # it gives alone (no cross-document arithmetic), and document 0 is compared with the CPU oracle like the single leg.
+    single_flow, single_img = flow.clone(), img_u8
+    del eng
+    for Bn in (8, 32):
+        imgs = [torch.roll(img_u8, shifts=(17 * d, 29 * d), dims=(0, 1)).contiguous() for d in range(Bn)]
+        engb = Engine(Gn, Bn, H, device=dev)
+        engb.load_state_dict(sd)
+        xTb = torch.cat([torch.from_numpy(synth.synth_noise(d, H, Gn, 1234)).to(dev) for d in range(Bn)])
+
+        def native_batch():
+            ys, srcs = zip(*[ops.ingest_u8(im, swap_rb=False, out_size=512, want_rgb=True) for im in imgs])
+            y = torch.stack(ys)
+            c = prestage.conditioning(dewarp, seg, line, y, Gn)
+            engb.prepare(y, c["mask_cat"].contiguous(), c["mask_y512"].contiguous(), c["line_msk"].contiguous())
+            fl = sampler.sample(engb, tabn, xTb)
+            return fl, ops.unwarp_u8_batch(fl, torch.stack(srcs))
+        for _ in range(2):
+            native_batch()
+        lat = []
+        for _ in range(7):
+            dt, (flb, o8b) = timed(native_batch)
+            lat.append(dt * 1e3)
+        med = statistics.median(lat)
+        same = bool(torch.equal(flb[0], single_flow[0]))          # document 0 is the single leg's document
+        out[f"native_point_batch{Bn}"] = {
+            "workload": f"reference-native settings (G=64, 3-step DDIM, {H} hypotheses), {Bn} documents per engine batch, from "
+                        "decoded 1024x768 images: ingest + ONE batched pass of U2NETP x2 + line UNet + sampling + batched u8 unwarp",
+            "batches_timed": len(lat), "ms_per_batch_median": round(med, 3), "ms_per_document": round(med / Bn, 3),
+            "value": round(Bn * 1e3 / med, 1), "unit": "documents/s",
+            "parity": {"what": "document 0 of the batch == the same document sampled alone (bit for bit; its map is the one "
+                               "compared with the CPU oracle in native_point)", "ok": same}}
+        del engb, xTb, imgs, flb, o8b
+        torch.cuda.empty_cache()
     for k in out:
         p = out[k].get("parity")
         if p is not None and not p["ok"]:

@@ -11,6 +11,10 @@ extern "C" {
 int dvd_gemm_debug_stamps(void* dev_u64);
 /* DVD_ATTN_DEBUG=1: device buffer [workgroups*4*5] u64 receiving per-wave phase times of the attention kernels */
 int dvd_attn_debug_stamps(void* dev_u64);
+/* the streaming ceiling of the drop-in grid_sample's access pattern: same tiles, same 2 + c + c plane streams at 16 bytes per
+ * lane, no gather (source address = output address; hin == h, win == w) - warp.hip, benchmarks/warp_time.py */
+int dvd_lab_stream_copy_planes(const float* src, const float* grid, float* out, int n, int c, int h, int w, int nontemporal,
+                               int tile_w /* 32: the gather kernel's 32 x 32 tiles; 64 / 128 / 256: wider, flatter tiles */, void* stream);
 #ifdef __cplusplus
 }
 #endif

@@ -32,3 +32,21 @@ for name, f, bpp in (("grid_sample f32 (32 B/px)", lambda: ops.grid_sample(srcf,
         continue
     ms = t(f)
     print(f"{name:28s} B={B}: {ms:.3f} ms  {bpp * H * W * B / ms / 1e6:.0f} GB/s   lib={lib} amp={AMP} var={os.environ.get('DVD_WARP_LDSVAR', '-')} wgs={os.environ.get('DVD_WARP_WGS', '-')} nolds={os.environ.get('DVD_WARP_NOLDS', '-')}")
+
+if LIBSEL == "lab":
+    # the streaming ceiling of the drop-in kernel's own access pattern (lab entry point; identity "gather")
+    import ctypes as C
+    from dvd_amd import lib
+    from dvd_amd.lib import ptr, stream_ptr
+    raw = lib.raw()
+    raw.dvd_lab_stream_copy_planes.restype = C.c_int
+    out = torch.empty_like(srcf)
+    for tw in (32, 64, 128, 256):
+        for nt in (0, 1):
+            f = lambda: raw.dvd_lab_stream_copy_planes(ptr(srcf), ptr(grid), ptr(out), B, 3, H, W, nt, tw, stream_ptr())
+            ms = t(f)
+            print(f"{'stream copy ' + str(tw) + 'x' + str(1024 // tw) + (' nt' if nt else ''):28s} B={B}: {ms:.3f} ms  {32 * H * W * B / ms / 1e6:.0f} GB/s   "
+                  f"(2 grid + 3 source planes read, 3 written, 16 B per lane, tiles in XCD bands, no gather)")
+    f = lambda: out.copy_(srcf)
+    ms = t(f)
+    print(f"{'torch copy_ (D2D) of 3 planes':28s} B={B}: {ms:.3f} ms  {24 * H * W * B / ms / 1e6:.0f} GB/s  (24 B/px)")

@@ -551,12 +551,16 @@ __global__ void __launch_bounds__(256, (D == 256 ? 1 : DVD_ATTN64_OCC)) flash_at
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int i = 0; i < 16; ++i) mx = fmaxf(mx, s[kb][i]);
-    if constexpr (!NEGM) mx *= p.c;
-    mx = half_swap_max(mx);                    // NEGM: already (row max) * c - m_run
+    if constexpr (!NEGM) mx *= p.c;            // NEGM: already (row max) * c - m_run
+    // The deferred-rescale test is LANE-LOCAL (round 4): a lane holds 32 of its query's 64 keys and m_run is kept identical
+    // in both halves of a row, so "some lane's own maximum exceeds m_run + THR" is exactly "some row's maximum does"; the
+    // cross-half exchange (v_mov + v_permlane32_swap + 3 v_max + 3 s_nop per tile in a VALU-issue-bound loop) moves into the
+    // rare branch.
     bool resc;
     if constexpr (NEGM) resc = t == 0 || __any(mx > RESCALE_THR);    // the first tile always sets the reference maximum
     else resc = __any(mx - m_run > RESCALE_THR);
     if (resc) {                                // deferred rescale, see flash_attn_kernel
+      mx = half_swap_max(mx);                  // the row's maximum over all 64 keys, the same in both halves
       float alpha;
       if constexpr (NEGM) {
         const float delta = t == 0 ? mx : fmaxf(mx, 0.f);

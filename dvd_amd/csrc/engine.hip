@@ -335,6 +335,7 @@ static int gemm(int dtype, int M, int N, int K, int batch, const void* A, int ld
   d.gate = gate; d.ldgate = N; d.gate_rows = gate_rows;
   d.res = res; d.ldres = ldres; d.strideRes = sRes;
   if (dtype == 2) { d.dtype = 0; d.small_tiles = 1; }     // dtype 2 = f16 operands on 128x128 tiles (small grids)
+  if (dtype == 3) { d.dtype = 0; d.small_tiles = 2; }     // dtype 3 = the same family, many rows (see dvd_gemm_desc)
   return dvd_gemm_nt(&d, stream);
 }
 
@@ -607,7 +608,9 @@ static int enqueue_step(Engine* e, const float* x_t, int feat_mode, const float*
   const int G = e->G, N = e->N, side = e->side, hyp = e->hyp;
   const int T = (int)e->T;
   const long NT = e->NT;
-  const int F16 = e->small_tiles ? 2 : 0;     // gemm() dtype code: f16 operands, 128x128 tiles on small grids
+  // gemm() dtype code: f16 operands; on small grids 128x128 tiles, and from 16 384 token rows on (a batch of >= 8 documents
+  // x 2 hypotheses at G = 64) the 256x256 kernel in the bit-compatible two-sweep form for the 256-wide shapes
+  const int F16 = e->small_tiles ? (e->NT >= 16384 ? 3 : 2) : 0;
   constexpr int F16S = 2;                     // ... and 128x128 tiles on every grid (a function of the GEMM, not of the batch)
 
   float* tbuf = (float*)e->B(e->bi.tbuf);

@@ -1617,10 +1617,15 @@ extern "C" int dvd_gemm_nt(const dvd_gemm_desc* d, void* stream) {
   // large-tile kernel for the big f16 GEMMs (decoder): N a multiple of 256, at least a few row tiles
   // kernel choice depends on (dtype, N, K, split) only, never on M: a document then takes the same kernels - and the
   // same fp32 summation order - whether it is sampled alone or in a batch (bit-identical results, tested)
-  const bool small = d->small_tiles != 0;      // the caller's problem family is small: 128x128 tiles everywhere
+  // small_tiles 1: the caller's problem family is small: 128x128 tiles everywhere.  small_tiles 2: the same family with MANY
+  // rows (a large batch of small grids): shapes with N % 256 == 0 take the 256x256 kernel in its TWO-SWEEP form - low parts
+  // first, scale, high parts, k ascending in 16-deep MFMA steps: exactly the 128x128 kernel's accumulation sequence, so a
+  // document still gets the same bits alone (small_tiles 1) and in a large batch (tests/test_gpu_gemm.py) - everything else
+  // stays on the 128x128 kernel.
+  const bool small = d->small_tiles == 1, small_many = d->small_tiles == 2;
   const bool big = d->dtype == 0 && d->N % 256 == 0 && !lab_v1 && !small;
   if (d->dtype == 0 && d->N % 128 == 0 && d->N % 256 != 0 && !d->A_lo && (!d->B_lo || d->lo_scale == 1.f) &&
-      d->K % 32 == 0 && !lab_twopass && !lab_v1 && !small) {
+      d->K % 32 == 0 && !lab_twopass && !lab_v1 && !small && !small_many) {
     // 256 x 128 tiles for the DiT block's 384-wide GEMMs: (hi, lo) in one pass, or ONE (dithered) weight tensor
     p.ntm = cdiv(d->M, 256); p.ntn = d->N / 128;
     constexpr int LDS = 8 * 16384;                    // 3 stages x 32 KiB, rounded up to the epilogue's 8 x 16 KiB
@@ -1636,7 +1641,7 @@ extern "C" int dvd_gemm_nt(const dvd_gemm_desc* d, void* stream) {
     else gemm_nt_split128_kernel<false><<<dim3(nblk, d->batch), 512, LDS, (hipStream_t)stream>>>(p);
     return check_launch("gemm_nt(128-wide)");
   }
-  if (big && d->B_lo && !d->A_lo && d->lo_scale == 1.f && d->K % 32 == 0 && !lab_twopass) {
+  if (big && d->B_lo && !d->A_lo && d->lo_scale == 1.f && d->K % 32 == 0 && !lab_twopass && !small_many) {
     p.ntm = cdiv(d->M, 256); p.ntn = d->N / 256;
     constexpr int LDS = 3 * 3 * 256 * 64;
     static DeviceOnce once_s;

@@ -797,3 +797,67 @@ extern "C" int dvd_unwarp_u8(const float* flow, int g, const uint8_t* src_hwc, u
                              float scale, void* stream) {
   return dvd_unwarp_u8_batch(flow, g, src_hwc, out_hwc, 1, h, w, scale, stream);
 }
+
+
+#ifdef DVD_LAB
+// ---------------------------------------------------------------------------------------
+// LAB: the streaming CEILING of the drop-in grid_sample's access pattern (round-3 VERDICT, weak 10: "the ceiling quoted
+// against it is a hipMemcpy").  Same launch geometry as grid_sample_lds_kernel (32 x 32 tiles in XCD bands, 256 threads x
+// 4 consecutive pixels), same streams - two grid planes and c source planes read, c output planes written, every access
+// 16 bytes per lane - but NO gather: a thread's source address is its own output address (needs hin == h, win == w).  What
+// this kernel reaches is what eight interleaved 16-byte-per-lane plane streams reach on the box; the distance from it to
+// grid_sample_lds_kernel is the price of the dependent grid -> footprint -> LDS round trip.
+// ---------------------------------------------------------------------------------------
+template <int NT, int TW>
+__global__ void __launch_bounds__(256) stream_copy_planes_kernel(const float* __restrict__ src, const float* __restrict__ grid,
+                                                                float* __restrict__ out, int c, int h, int w, int ntx, int nty,
+                                                                unsigned tiles_total, unsigned tiles_per_xcd) {
+  const unsigned seq = blockIdx.x >> 3, xcd = blockIdx.x & 7u;
+  const unsigned tile = xcd * tiles_per_xcd + seq;
+  if (seq >= tiles_per_xcd || tile >= tiles_total) return;
+  const unsigned per_img = (unsigned)ntx * (unsigned)nty;
+  const int n = (int)(tile / per_img);
+  const unsigned rem = tile - (unsigned)n * per_img;
+  const int ty = (int)(rem / (unsigned)ntx), tx = (int)(rem - (unsigned)ty * (unsigned)ntx);
+  const int tid = threadIdx.x;
+  constexpr int TPR = TW / 4, TH = 256 / TPR;
+  const int x = tx * TW + 4 * (tid % TPR), y = ty * TH + (tid / TPR);
+  const size_t hw = (size_t)h * w;
+  const bool live = x < w && y < h;
+  const uint32_t poff = ((uint32_t)min(y, h - 1) * (uint32_t)w + (uint32_t)min(x, w - 4)) * 4u;
+  const float* g = grid + (size_t)n * 2 * hw;
+  const float4 gx = NT ? load_f4_nt(g, poff) : load_f4(g, poff), gy = NT ? load_f4_nt(g + hw, poff) : load_f4(g + hw, poff);
+  const float bias = (gx.x + gx.y + gx.z + gx.w + gy.x + gy.y + gy.z + gy.w) * 1e-30f;   // keeps the grid loads alive
+  const float* s = src + (size_t)n * c * hw;
+  float* o = out + (size_t)n * c * hw;
+  for (int ch = 0; ch < c; ++ch) {
+    float4 v = load_f4(s + (size_t)ch * hw, poff);
+    v.x += bias; v.y += bias; v.z += bias; v.w += bias;
+    if (live) {
+      if (NT) store_f4_nt(o + (size_t)ch * hw, poff, v);
+      else *reinterpret_cast<float4*>(reinterpret_cast<char*>(o + (size_t)ch * hw) + poff) = v;
+    }
+  }
+}
+
+extern "C" int dvd_lab_stream_copy_planes(const float* src, const float* grid, float* out, int n, int c, int h, int w,
+                                          int nontemporal, int tile_w, void* stream) {
+  DVD_REQUIRE(src && grid && out && n > 0 && c > 0 && w % 4 == 0, "lab_stream_copy_planes: bad arguments");
+  DVD_REQUIRE(tile_w == 32 || tile_w == 64 || tile_w == 128 || tile_w == 256, "lab_stream_copy_planes: tile_w in {32,64,128,256}");
+  const int ntx = cdiv(w, tile_w), nty = cdiv(h, 1024 / tile_w);
+  const size_t total = (size_t)ntx * nty * n;
+  const unsigned per_xcd = (unsigned)((total + 7) / 8);
+#define SC_LAUNCH(NT_, TW_)                                                                                          \
+  stream_copy_planes_kernel<NT_, TW_><<<per_xcd * 8u, 256, 0, (hipStream_t)stream>>>(src, grid, out, c, h, w, ntx, nty, \
+                                                                                   (unsigned)total, per_xcd)
+  if (nontemporal) {
+    if (tile_w == 32) SC_LAUNCH(1, 32); else if (tile_w == 64) SC_LAUNCH(1, 64); else if (tile_w == 128) SC_LAUNCH(1, 128);
+    else SC_LAUNCH(1, 256);
+  } else {
+    if (tile_w == 32) SC_LAUNCH(0, 32); else if (tile_w == 64) SC_LAUNCH(0, 64); else if (tile_w == 128) SC_LAUNCH(0, 128);
+    else SC_LAUNCH(0, 256);
+  }
+#undef SC_LAUNCH
+  return check_launch("lab_stream_copy_planes");
+}
+#endif

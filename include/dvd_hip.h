@@ -129,7 +129,9 @@ typedef struct {
   int small_tiles;                           /* f16 only: 1 = 128x128 tiles for every shape.  The caller's statement about
                                                 its PROBLEM FAMILY (the engine sets it from the grid, never from the batch):
                                                 at a few thousand rows the 256x256 persistent kernels put < 50 workgroups on
-                                                256 CUs and run one workgroup's K loop latency-bound */
+                                                256 CUs and run one workgroup's K loop latency-bound.  2 = the same family
+                                                with many rows: N % 256 == 0 shapes take the 256x256 kernel in the two-sweep
+                                                form whose accumulation sequence IS the 128x128 kernel's (same bits) */
 } dvd_gemm_desc;
 
 int dvd_gemm_nt(const dvd_gemm_desc* desc, void* stream);

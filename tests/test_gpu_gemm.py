@@ -368,3 +368,34 @@ def test_gemm_big2_kernel(ops, lab, monkeypatch, M, N, K):
     out8 = torch.zeros(M, N, device="cuda")
     ops.gemm_nt(a.cuda(), b.cuda(), out32=out8)
     assert torch.equal(out8, out), "big2 and the 8-wave kernel accumulate k in the same order: equal bits expected"
+
+
+@pytest.mark.parametrize("side", ["B", "A"])
+def test_gemm_small_family_many_rows_same_bits(ops, side):
+    """dvd_gemm_desc.small_tiles = 2 (a LARGE batch of small grids: N % 256 == 0 shapes on the 256x256 kernel, two sweeps)
+    must give the bits of small_tiles = 1 (128x128 tiles everywhere) - a document sampled alone and in a batch of 32 then
+    agree bit for bit although the batch runs the faster kernel - for the (hi, lo) weight pair on either side and the
+    epilogues the engine uses (bias + ReLU -> f16, residual -> f32, plain f16)."""
+    M, N, K = 2304, 1536, 1536
+    a = rnd("sm/a", (M, K)).half()
+    w = rnd("sm/w", (N, K)) * 0.05
+    hi = w.half()
+    lo = (w - hi.float()).half()
+    bias, res = rnd("sm/bias", (N,)), rnd("sm/res", (M, N))
+    for st in (1, 2):
+        if side == "B":
+            o16 = torch.zeros(M, N, dtype=torch.float16, device="cuda")
+            ops.gemm_nt(a.cuda(), hi.cuda(), out16=o16, b_lo=lo.cuda(), lo_scale=1.0, bias=bias.cuda(), act=2, small_tiles=st)
+            o32 = res.clone().cuda()
+            ops.gemm_nt(a.cuda(), hi.cuda(), out32=o32, b_lo=lo.cuda(), lo_scale=1.0, res=o32, small_tiles=st)
+        else:          # the V^T projections: weights on the A side, the output transposed
+            o16 = torch.zeros(N, M, dtype=torch.float16, device="cuda")
+            ops.gemm_nt(hi.cuda(), a.cuda(), out16=o16, a_lo=lo.cuda(), lo_scale=1.0, small_tiles=st)
+            o32 = torch.zeros(N, M, device="cuda")
+            ops.gemm_nt(hi.cuda(), a.cuda(), out32=o32, a_lo=lo.cuda(), lo_scale=1.0, small_tiles=st)
+        if st == 1:
+            ref16, ref32 = o16.clone(), o32.clone()
+    assert torch.equal(o16, ref16) and torch.equal(o32, ref32)
+    want = (a.double() @ w.double().t())
+    got = o32.cpu().double() - (res.double() if side == "B" else 0)
+    assert ((got if side == "B" else got.t()) - want).abs().max().item() < 2e-5
