@@ -5,7 +5,7 @@
 #   durations: a --kernel-trace --stats pass of the same probes (never combined with --pmc)
 # run on the GPU box from the repo root:  bash benchmarks/pmc_round.sh r2   -> gpurun_out/pmc_<round>/ , then
 #   python3 benchmarks/pmc_round_json.py gpurun_out/pmc_r3 profiles r3
-round=${1:-r3}
+round=${1:-r4}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 out=gpurun_out/pmc_$round
 rm -rf $out; mkdir -p $out
