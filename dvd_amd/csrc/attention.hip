@@ -1176,6 +1176,187 @@ __global__ void __launch_bounds__(256, 1) flash_attn_r64p_kernel(AttnArgs p) {
   }
 }
 
+
+// ================================================================================================
+// r64m = r64p with HAND-ALLOCATED registers and ONE exp unit per fragment step (round 4, second step).
+// In r64p the 32 exponential units of a tile must be finished before that tile's second PV chunk starts, so 24 of them sit
+// in phase 1 - two per fragment step: gaps of 40+ issue cycles beside 32-cycle MFMAs (stamps: 37 cycles per MFMA in phase
+// 1, 32-33 in phase 2) - and phase 2b has none.  Letting a tile's first 8 units run one iteration EARLY (in the previous
+// iteration's phase 2b) gives every one of the 32 fragment steps exactly one unit, but with compiler-allocated registers it
+// cost 8 + live values and hipcc answered with 193 scratch reloads of Q inside the loop (the kernel sits at 256 + 256).
+// Here the loop's state lives in registers chosen by hand (gen_attn_r64m.py: the plan, the schedule and the generator of
+// attn_r64m_body.inc): an exponential OVERWRITES the S^T element it consumes, a packed word is written straight into its
+// P fragment register, so the softmax owns no register at all, and an iteration is TWO asm statements (phase 1 + 2a | the
+// compiler's l update and rare rescale | barrier + phase 2b) with every register also passed as a physical-register
+// operand, so the compiler knows what lives where.
+// ================================================================================================
+#include "attn_r64m_body.inc"
+
+template <int DBG>
+__global__ void __launch_bounds__(256, 1) flash_attn_r64m_kernel(AttnArgs p) {
+  using namespace r64p;
+  constexpr int D = 256, KB = 32, DT = 8, RB = 2;
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [K0 | K1 | K2 | V0 | V1 | V2]
+  typedef __attribute__((address_space(3))) void* lptr_t;
+
+  const int nwg = gridDim.x;
+  int id = blockIdx.x;
+  {
+    const int q = nwg / 8, rr = nwg % 8, xcd = id % 8, k = id / 8;
+    id = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + k;
+  }
+  const int qb = id % p.nqb;          // 256-row query blocks
+  const int bh = id / p.nqb;
+  const int head = bh % p.heads, b = bh / p.heads;
+  const int kvb = b / p.kv_div;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+
+  const _Float16* Qg = p.Q + b * p.sQ + (size_t)head * D;
+  const char* Kg = (const char*)(p.K + kvb * p.sK + (size_t)head * D);
+  const char* Vg = (const char*)(p.Vt + kvb * p.sVt + (size_t)head * D * p.ldvt);
+
+  R64mState st;
+  {
+    const int q0 = min(qb * 256 + wave * 64 + r, p.tq - 1), q1 = min(qb * 256 + wave * 64 + 32 + r, p.tq - 1);
+    r64m_load_q(st, Qg + (size_t)q0 * p.ldq + 8 * h, Qg + (size_t)q1 * p.ldq + 8 * h);
+  }
+  const unsigned kstride4 = (unsigned)(2 * p.ldk * 2), vstride4 = (unsigned)(16 * p.ldvt * 2);
+  const unsigned koff0 = (unsigned)(8 * wave + (lane >> 5)) * (unsigned)(p.ldk * 2) + (unsigned)(((lane & 31) ^ (lane >> 5)) * 16);
+  const unsigned voff0 = (unsigned)(64 * wave + (lane >> 2)) * (unsigned)(p.ldvt * 2) + (unsigned)(((lane & 3) ^ ((lane >> 4) & 3)) * 16);
+  const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t)smem;
+  const int kr = kappa(r);
+  const unsigned kaddr = lds0 + (kr >> 1) * KPIECE + (kr & 1) * 512 + ((h ^ (kr & 1)) * 16);        // slot 0; + ks * 32
+  const unsigned vrel0 = lds0 + VBASE + r * 64 + ((h ^ ((r >> 2) & 3)) * 16);                       // chunk 0, slot 0; + dt * 2048
+  const unsigned vrel1 = vrel0 ^ 32;                                                                // chunk 1
+
+  floatx16 o[RB][DT];
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) o[rb][dt][i] = 0.f;
+  Soft sm[RB] = {{-1e30f, -1e30f, 0.f}, {-1e30f, -1e30f, 0.f}};
+  const int nt = p.tk / KB;              // even (tk % 64 == 0)
+  const size_t ktile = (size_t)KB * p.ldk * 2;
+  const unsigned kdst = lds0 + (4 * wave) * KPIECE, vdst = lds0 + VBASE + (4 * wave) * 1024;
+
+  // ---- prologue: K(0), K(1), K(2) -> K slots 0, 1, 2; V(0), V(1) -> V slots 0, 1
+  {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const char* kj = Kg + (size_t)min(j, nt - 1) * ktile;
+      const char* vj = Vg + (size_t)min(j, nt - 1) * (KB * 2);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        glds_piece(kj + (size_t)i * kstride4, koff0, kdst + j * KBYTES + i * KPIECE);
+        if (j < 2) glds_piece(vj + (size_t)i * vstride4, voff0, vdst + j * VBYTES + i * 1024);
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+
+  float a0, a1;
+  r64m_prologue_s0(st, kaddr, a0, a1);                                   // S^T(0) -> buffer A; lane-local maxima
+  asm volatile("s_barrier" ::: "memory");                                // every wave has read K(0) before K slot 0 is refilled
+  {
+    const float mloc[2] = {a0, a1};
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+      const float m = half_swap_max(mloc[rb] * p.c);
+      sm[rb].m = m;
+      sm[rb].thr = m + RESCALE_THR;
+    }
+  }
+  // Rings.  Iteration t reads K(t+1) from K slot (t+1) % 3, pre-reads K(t+2) from slot (t+2) % 3 and refills slot t % 3
+  // with K(t+3); it reads V^T(t) from V slot t % 3 and refills slot (t+2) % 3 with V^T(t+2).
+  unsigned kcur = kaddr + KBYTES, knext = kaddr + 2 * KBYTES;
+  unsigned vrd0 = vrel0, vrd1 = vrel1;
+  int slot = 0;                           // t % 3 (wave-uniform)
+  float rs0 = 0.f, rs1 = 0.f;
+  r64m_prologue_units(st, kcur, p.c, sm[0].m, sm[1].m, rs0, rs1);       // units 0..7 of tile 0; the ring: K(1) fragments 0..2
+  for (int t = 0; t < nt; t += 2) {
+#pragma unroll
+    for (int par = 0; par < 2; ++par) {
+      const int tt = t + par;
+      const int tk3 = min(tt + 3, nt - 1), tv2 = min(tt + 2, nt - 1);
+      const int vwr = slot == 0 ? 2 : slot - 1;                              // (t + 2) % 3
+      const char* kg = Kg + (size_t)tk3 * ktile;
+      const char* vg = Vg + (size_t)tv2 * (KB * 2);
+      const unsigned lk = kdst + slot * KBYTES, lv = vdst + vwr * VBYTES;
+      unsigned long long mask;
+      if (par == 0)
+        r64m_A0(st, o, rs0, rs1, a0, a1, mask, kcur, vrd0, vrd1, koff0, p.c, sm[0].m, sm[1].m, sm[0].thr, sm[1].thr, kg,
+                kg + kstride4, kg + 2 * (size_t)kstride4, kg + 3 * (size_t)kstride4, lk, lk + KPIECE, lk + 2 * KPIECE, lk + 3 * KPIECE);
+      else
+        r64m_A1(st, o, rs0, rs1, a0, a1, mask, kcur, vrd0, vrd1, koff0, p.c, sm[0].m, sm[1].m, sm[0].thr, sm[1].thr, kg,
+                kg + kstride4, kg + 2 * (size_t)kstride4, kg + 3 * (size_t)kstride4, lk, lk + KPIECE, lk + 2 * KPIECE, lk + 3 * KPIECE);
+      sm[0].l += rs0;
+      sm[1].l += rs1;
+      rs0 = 0.f;
+      rs1 = 0.f;
+      // deferred rescale (rare): some lane saw its row's maximum over its 16 keys of tile t + 1 exceed m + THR.  O^T holds
+      // the tiles up to t's chunk 0 and l the row sums up to t, both at the old reference - and so does the packed chunk 1
+      // of P(t), which enters O^T in phase 2b: all three are scaled.
+      if (mask != 0) {
+        asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");          // the last PV MFMAs must have written O^T
+        const float mloc[2] = {a0, a1};
+#pragma unroll
+        for (int r_ = 0; r_ < 2; ++r_) {
+          const float mx = half_swap_max(mloc[r_] * p.c);
+          const float m_new = fmaxf(sm[r_].m, mx);
+          const float alpha = __builtin_amdgcn_exp2f(sm[r_].m - m_new);
+          sm[r_].m = m_new;
+          sm[r_].thr = m_new + RESCALE_THR;
+          sm[r_].l *= alpha;
+#pragma unroll
+          for (int dt = 0; dt < DT; ++dt) scale_acc_in_agpr(o[r_][dt], alpha);
+          const half2v a2 = {(_Float16)alpha, (_Float16)alpha};
+          if (r_ == 0) r64m_scale_p0(st, __builtin_bit_cast(unsigned, a2));
+          else r64m_scale_p1(st, __builtin_bit_cast(unsigned, a2));
+        }
+      }
+      if (par == 0)
+        r64m_B0(st, o, rs0, rs1, vrd1, knext, voff0, p.c, sm[0].m, sm[1].m, vg, vg + vstride4, vg + 2 * (size_t)vstride4,
+                vg + 3 * (size_t)vstride4, lv, lv + 1024, lv + 2048, lv + 3072);
+      else
+        r64m_B1(st, o, rs0, rs1, vrd1, knext, voff0, p.c, sm[0].m, sm[1].m, vg, vg + vstride4, vg + 2 * (size_t)vstride4,
+                vg + 3 * (size_t)vstride4, lv, lv + 1024, lv + 2048, lv + 3072);
+      kcur = knext;
+      knext = kaddr + slot * KBYTES;
+      const int vstep = slot == 2 ? -2 * VBYTES : VBYTES;
+      vrd0 += vstep;
+      vrd1 += vstep;
+      slot = slot == 2 ? 0 : slot + 1;
+    }
+  }
+  // drain the LDS-DMA and the fragment reads still in flight (the last iterations re-load clamped tiles, and the last phase
+  // 2b formed the early units of a tile that does not exist - never added to l): LDS must not be written after the workgroup
+  // has ended; and the last PV MFMAs must have written O^T before the compiler's code reads it
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 15\n\ts_nop 7" ::: "memory");
+
+#pragma unroll
+  for (int rb = 0; rb < RB; ++rb) {
+    const float l_tot = sm[rb].l + __shfl_xor(sm[rb].l, 32);
+    const float inv = 1.f / l_tot;
+    const int qglob = qb * 256 + wave * 64 + rb * 32 + r;
+    if (qglob < p.tq) {
+      _Float16* op = p.O + b * p.sO + (size_t)qglob * p.ldo + (size_t)head * D;
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          half4 v;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = (_Float16)(o[rb][dt][4 * g4 + j] * inv);
+          *(half4*)(op + 32 * dt + 8 * g4 + 4 * h) = v;
+        }
+    }
+  }
+}
+
 #ifdef DVD_LAB
 #include "../../benchmarks/lab/csrc/attention_lab.inc"
 #endif
@@ -1248,7 +1429,7 @@ extern "C" int dvd_flash_attn(const dvd_attn_desc* d, void* stream) {
   p.stamps = g_attn_stamps;
   const bool dbg = getenv("DVD_ATTN_DEBUG"), bulk = getenv("DVD_ATTN_BULK");
   if (getenv("DVD_ATTN_V1")) fast = false;
-  if (getenv("DVD_ATTN_R64") || getenv("DVD_ATTN_R64P") || getenv("DVD_ATTN_R64OLD")) r64 = d->head_dim == 256;
+  if (getenv("DVD_ATTN_R64") || getenv("DVD_ATTN_R64P") || getenv("DVD_ATTN_R64M") || getenv("DVD_ATTN_R64OLD")) r64 = d->head_dim == 256;
   if (getenv("DVD_ATTN_R32") || getenv("DVD_ATTN_PIPE") || bulk) r64 = false;
   if (first_on_device) {
     constexpr int LDS = 2 * (64 * 512 + 256 * 128);
@@ -1261,12 +1442,18 @@ extern "C" int dvd_flash_attn(const dvd_attn_desc* d, void* stream) {
     allow_lds(flash_attn_r64_kernel<0>, 2 * (32 * 512 + 256 * 64));
     allow_lds(flash_attn_r64_kernel<1>, 2 * (32 * 512 + 256 * 64));
     allow_lds(flash_attn_r64p_kernel<1>, r64p::LDS_BYTES);
+    allow_lds(flash_attn_r64m_kernel<0>, r64p::LDS_BYTES);
   }
   if (fast && d->head_dim == 256) {
     constexpr int LDS = 2 * (64 * 512 + 256 * 128);
     if (getenv("DVD_ATTN_DSPLIT")) {   // measured slower (732 vs 812 TF/s)
       flash_attn_dsplit_kernel<<<(unsigned)nwg, 512, LDS, st>>>(p);
       return check_launch("flash_attn(lab dsplit)");
+    }
+    if (r64 && getenv("DVD_ATTN_R64M")) {     // r64p's schedule with hand-allocated registers, one exp unit per step
+      p.nqb = cdiv(d->tq, 256);
+      flash_attn_r64m_kernel<0><<<(unsigned)((long)p.nqb * d->heads * d->batch), 256, r64p::LDS_BYTES, st>>>(p);
+      return check_launch("flash_attn(lab r64m)");
     }
     if (r64 && getenv("DVD_ATTN_R64OLD")) {   // rounds 1-3's production kernel (lab include), with or without its stamps
       p.nqb = cdiv(d->tq, 256);
