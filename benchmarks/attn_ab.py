@@ -11,12 +11,12 @@ from dvd_amd import ops
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 7
 hd = int(sys.argv[3]) if len(sys.argv) > 3 else 256
-specs = sys.argv[4:] or ["r64p=", "r64old=DVD_ATTN_R64OLD"]
+specs = sys.argv[4:] or ["r64p=", "r64m=DVD_ATTN_R64M"]
 variants = []
 for sp in specs:
     name, _, envs = sp.partition("=")
     variants.append((name, [e for e in envs.split(",") if e]))
-ALL = sorted({e for _, es in variants for e in es})
+ALL = sorted({e.split(":")[0] for _, es in variants for e in es})          # ENVVAR or ENVVAR:value
 T, C = 20736, 6 * hd
 qk = torch.randn(B, T, 2 * C, device="cuda").half()
 vt = torch.randn(B, C, T, device="cuda").half()
@@ -27,7 +27,8 @@ def call(name, envs):
     for e in ALL:
         os.environ.pop(e, None)
     for e in envs:
-        os.environ[e] = "1"
+        k, _, v = e.partition(":")
+        os.environ[k] = v or "1"
     ops.flash_attn(qk[:, :, :C], qk[:, :, C:], vt, outs[name], 6, hd, 1.0 / hd ** 0.5)
 
 

@@ -1,16 +1,16 @@
 #!/bin/bash
 # PMC A/B of the head_dim-256 decoder attention kernels (lab build): MFMA busy, VALU port, sustained clock, wave stalls.
-# usage (GPU box): bash benchmarks/pmc_attn_ab.sh "<name>=<ENVVAR or empty>" ...
+# usage (GPU box): bash benchmarks/pmc_attn_ab.sh "<name>=<ENVVAR[:value][,ENVVAR...] or empty>" ...   (NOSTATS=1: counters only)
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 out=gpurun_out/pmc_attn_ab
 rm -rf $out; mkdir -p $out
 export PROBE_B=16
 for spec in "$@"; do
   name=${spec%%=*}; envs=${spec#*=}
-  for e in ${envs//,/ }; do export $e=1; done
+  for e in ${envs//,/ }; do if [[ $e == *:* ]]; then export ${e%%:*}=${e#*:}; else export $e=1; fi; done
   timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_MFMA GRBM_GUI_ACTIVE --output-format csv -d $out/$name -- python3 benchmarks/pmc_probe.py attn256 --lab > $out/$name.log 2>&1 || tail -3 $out/$name.log
-  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${name}_stats -- python3 benchmarks/pmc_probe.py attn256 --lab > $out/${name}_stats.log 2>&1 || tail -3 $out/${name}_stats.log
-  for e in ${envs//,/ }; do unset $e; done
+  [ -n "$NOSTATS" ] || timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${name}_stats -- python3 benchmarks/pmc_probe.py attn256 --lab > $out/${name}_stats.log 2>&1 || tail -3 $out/${name}_stats.log
+  for e in ${envs//,/ }; do unset ${e%%:*}; done
 done
 python3 - "$@" <<'PY'
 import csv, glob, sys

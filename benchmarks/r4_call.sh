@@ -1,4 +1,3 @@
-cd $GRAFT_REPO_ROOT
+#!/bin/bash
 mkdir -p gpurun_out/r4
-timeout 900 python -m pytest tests/test_gpu_attention.py -x -q -k "r64m" 2>&1 | tail -15
-timeout 600 python benchmarks/attn_ab.py 16 7 256 r64p= r64m=DVD_ATTN_R64M 2>&1 | grep -v amdgpu.ids
+for a in 0; do echo "== ablation $a"; timeout 200 python benchmarks/attn_stamps_r64m.py 16 $a 2>&1 | grep -v amdgpu.ids; done | tee gpurun_out/r4/c24_stamps.txt

@@ -1191,11 +1191,40 @@ __global__ void __launch_bounds__(256, 1) flash_attn_r64p_kernel(AttnArgs p) {
 // operand, so the compiler knows what lives where.
 // ================================================================================================
 #include "attn_r64m_body.inc"
+#ifdef DVD_LAB
+#include "../../benchmarks/lab/csrc/attn_r64m_abl.inc"
+#endif
+
+template <int RB_, int... DT_>
+__device__ __forceinline__ void r64m_store_row(_Float16* op, float inv, std::integer_sequence<int, DT_...>) {
+  auto tile = [&](auto dt_c) {
+    constexpr int dt = decltype(dt_c)::value;
+    const floatx16 x = r64m_read_o<16 * (8 * RB_ + dt)>();
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      half4 v;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = (_Float16)(x[4 * g4 + j] * inv);
+      *(half4*)(op + 32 * dt + 8 * g4) = v;
+    }
+  };
+  (tile(std::integral_constant<int, DT_>{}), ...);
+}
+
+__device__ __forceinline__ const char* uniform_ptr(const char* q) {      // tell the compiler the pointer is wave-uniform
+  const unsigned long long v = (unsigned long long)q;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return (const char*)(((unsigned long long)hi << 32) | lo);
+}
 
 template <int DBG>
-__global__ void __launch_bounds__(256, 1) flash_attn_r64m_kernel(AttnArgs p) {
+__global__ void __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(R64M_COMPILER_VGPRS))) flash_attn_r64m_kernel(AttnArgs p) {
   using namespace r64p;
   constexpr int D = 256, KB = 32, DT = 8, RB = 2;
+#ifdef DVD_LAB
+  unsigned long long ts[4] = {0, 0, 0, 0};   // lab: s_memtime at kernel entry | loop entry | loop exit | kernel exit (OUTSIDE the loop)
+  if (p.stamps) ts[0] = __builtin_readcyclecounter();
+#endif
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [K0 | K1 | K2 | V0 | V1 | V2]
   typedef __attribute__((address_space(3))) void* lptr_t;
 
@@ -1217,10 +1246,9 @@ __global__ void __launch_bounds__(256, 1) flash_attn_r64m_kernel(AttnArgs p) {
   const char* Kg = (const char*)(p.K + kvb * p.sK + (size_t)head * D);
   const char* Vg = (const char*)(p.Vt + kvb * p.sVt + (size_t)head * D * p.ldvt);
 
-  R64mState st;
   {
     const int q0 = min(qb * 256 + wave * 64 + r, p.tq - 1), q1 = min(qb * 256 + wave * 64 + 32 + r, p.tq - 1);
-    r64m_load_q(st, Qg + (size_t)q0 * p.ldq + 8 * h, Qg + (size_t)q1 * p.ldq + 8 * h);
+    r64m_load_q(Qg + (size_t)q0 * p.ldq + 8 * h, Qg + (size_t)q1 * p.ldq + 8 * h);
   }
   const unsigned kstride4 = (unsigned)(2 * p.ldk * 2), vstride4 = (unsigned)(16 * p.ldvt * 2);
   const unsigned koff0 = (unsigned)(8 * wave + (lane >> 5)) * (unsigned)(p.ldk * 2) + (unsigned)(((lane & 31) ^ (lane >> 5)) * 16);
@@ -1231,13 +1259,7 @@ __global__ void __launch_bounds__(256, 1) flash_attn_r64m_kernel(AttnArgs p) {
   const unsigned vrel0 = lds0 + VBASE + r * 64 + ((h ^ ((r >> 2) & 3)) * 16);                       // chunk 0, slot 0; + dt * 2048
   const unsigned vrel1 = vrel0 ^ 32;                                                                // chunk 1
 
-  floatx16 o[RB][DT];
-#pragma unroll
-  for (int rb = 0; rb < RB; ++rb)
-#pragma unroll
-    for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) o[rb][dt][i] = 0.f;
+  r64m_zero_o();                         // O^T: a[0:255], owned by the statements like v[32:255]
   Soft sm[RB] = {{-1e30f, -1e30f, 0.f}, {-1e30f, -1e30f, 0.f}};
   const int nt = p.tk / KB;              // even (tk % 64 == 0)
   const size_t ktile = (size_t)KB * p.ldk * 2;
@@ -1259,7 +1281,7 @@ __global__ void __launch_bounds__(256, 1) flash_attn_r64m_kernel(AttnArgs p) {
   asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
 
   float a0, a1;
-  r64m_prologue_s0(st, kaddr, a0, a1);                                   // S^T(0) -> buffer A; lane-local maxima
+  r64m_prologue_s0(kaddr, a0, a1);                                   // S^T(0) -> buffer A; lane-local maxima
   asm volatile("s_barrier" ::: "memory");                                // every wave has read K(0) before K slot 0 is refilled
   {
     const float mloc[2] = {a0, a1};
@@ -1270,68 +1292,86 @@ __global__ void __launch_bounds__(256, 1) flash_attn_r64m_kernel(AttnArgs p) {
       sm[rb].thr = m + RESCALE_THR;
     }
   }
-  // Rings.  Iteration t reads K(t+1) from K slot (t+1) % 3, pre-reads K(t+2) from slot (t+2) % 3 and refills slot t % 3
-  // with K(t+3); it reads V^T(t) from V slot t % 3 and refills slot (t+2) % 3 with V^T(t+2).
-  unsigned kcur = kaddr + KBYTES, knext = kaddr + 2 * KBYTES;
-  unsigned vrd0 = vrel0, vrd1 = vrel1;
-  int slot = 0;                           // t % 3 (wave-uniform)
-  float rs0 = 0.f, rs1 = 0.f;
-  r64m_prologue_units(st, kcur, p.c, sm[0].m, sm[1].m, rs0, rs1);       // units 0..7 of tile 0; the ring: K(1) fragments 0..2
-  for (int t = 0; t < nt; t += 2) {
+  // Rings.  Tile t reads K(t+1) from K slot (t+1) % 3, pre-reads K(t+2) from slot (t+2) % 3 and refills slot t % 3 with
+  // K(t+3); it reads V^T(t) from V slot t % 3 and refills slot (t+2) % 3 with V^T(t+2).  The statements come in six
+  // variants (t % 6): every LDS address in them is a loop-invariant base + an immediate, the DMA source pairs kg / vg
+  // are advanced by the compiler between the statements (no further once they reach the last tile, which is then simply
+  // re-loaded), so that between two tiles it has only that, `l += rs` and the out-of-line rare branch to emit.
+  unsigned koff[4], voff[4];
 #pragma unroll
-    for (int par = 0; par < 2; ++par) {
-      const int tt = t + par;
-      const int tk3 = min(tt + 3, nt - 1), tv2 = min(tt + 2, nt - 1);
-      const int vwr = slot == 0 ? 2 : slot - 1;                              // (t + 2) % 3
-      const char* kg = Kg + (size_t)tk3 * ktile;
-      const char* vg = Vg + (size_t)tv2 * (KB * 2);
-      const unsigned lk = kdst + slot * KBYTES, lv = vdst + vwr * VBYTES;
-      unsigned long long mask;
-      if (par == 0)
-        r64m_A0(st, o, rs0, rs1, a0, a1, mask, kcur, vrd0, vrd1, koff0, p.c, sm[0].m, sm[1].m, sm[0].thr, sm[1].thr, kg,
-                kg + kstride4, kg + 2 * (size_t)kstride4, kg + 3 * (size_t)kstride4, lk, lk + KPIECE, lk + 2 * KPIECE, lk + 3 * KPIECE);
-      else
-        r64m_A1(st, o, rs0, rs1, a0, a1, mask, kcur, vrd0, vrd1, koff0, p.c, sm[0].m, sm[1].m, sm[0].thr, sm[1].thr, kg,
-                kg + kstride4, kg + 2 * (size_t)kstride4, kg + 3 * (size_t)kstride4, lk, lk + KPIECE, lk + 2 * KPIECE, lk + 3 * KPIECE);
-      sm[0].l += rs0;
-      sm[1].l += rs1;
-      rs0 = 0.f;
-      rs1 = 0.f;
-      // deferred rescale (rare): some lane saw its row's maximum over its 16 keys of tile t + 1 exceed m + THR.  O^T holds
-      // the tiles up to t's chunk 0 and l the row sums up to t, both at the old reference - and so does the packed chunk 1
-      // of P(t), which enters O^T in phase 2b: all three are scaled.
-      if (mask != 0) {
-        asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");          // the last PV MFMAs must have written O^T
-        const float mloc[2] = {a0, a1};
-#pragma unroll
-        for (int r_ = 0; r_ < 2; ++r_) {
-          const float mx = half_swap_max(mloc[r_] * p.c);
-          const float m_new = fmaxf(sm[r_].m, mx);
-          const float alpha = __builtin_amdgcn_exp2f(sm[r_].m - m_new);
-          sm[r_].m = m_new;
-          sm[r_].thr = m_new + RESCALE_THR;
-          sm[r_].l *= alpha;
-#pragma unroll
-          for (int dt = 0; dt < DT; ++dt) scale_acc_in_agpr(o[r_][dt], alpha);
-          const half2v a2 = {(_Float16)alpha, (_Float16)alpha};
-          if (r_ == 0) r64m_scale_p0(st, __builtin_bit_cast(unsigned, a2));
-          else r64m_scale_p1(st, __builtin_bit_cast(unsigned, a2));
-        }
-      }
-      if (par == 0)
-        r64m_B0(st, o, rs0, rs1, vrd1, knext, voff0, p.c, sm[0].m, sm[1].m, vg, vg + vstride4, vg + 2 * (size_t)vstride4,
-                vg + 3 * (size_t)vstride4, lv, lv + 1024, lv + 2048, lv + 3072);
-      else
-        r64m_B1(st, o, rs0, rs1, vrd1, knext, voff0, p.c, sm[0].m, sm[1].m, vg, vg + vstride4, vg + 2 * (size_t)vstride4,
-                vg + 3 * (size_t)vstride4, lv, lv + 1024, lv + 2048, lv + 3072);
-      kcur = knext;
-      knext = kaddr + slot * KBYTES;
-      const int vstep = slot == 2 ? -2 * VBYTES : VBYTES;
-      vrd0 += vstep;
-      vrd1 += vstep;
-      slot = slot == 2 ? 0 : slot + 1;
-    }
+  for (int i = 0; i < 4; ++i) {
+    koff[i] = koff0 + i * kstride4;
+    voff[i] = voff0 + i * vstride4;
   }
+  const char* kg = uniform_ptr(Kg + (size_t)min(3, nt - 1) * ktile);
+  const char* vg = uniform_ptr(Vg + (size_t)min(2, nt - 1) * (KB * 2));
+  int tc = 0;
+  const int klim = nt - 4, vlim = nt - 3;
+  const unsigned kstep = (unsigned)ktile, vstep = KB * 2;
+  float rs0 = 0.f, rs1 = 0.f;
+  r64m_prologue_units(kaddr, p.c, sm[0].m, sm[1].m, rs0, rs1);       // units 0..7 of tile 0; the ring: K(1) fragments 0..2
+#define R64M_A_ARGS rs0, rs1, a0, a1, mask, kg, kaddr, vrel0, vrel1, koff, p.c, sm[0].m, sm[1].m, sm[0].thr, sm[1].thr, kdst
+#define R64M_B_ARGS rs0, rs1, vg, kaddr, vrel1, voff, p.c, sm[0].m, sm[1].m, vdst
+#ifdef DVD_LAB
+#define R64M_STEP(S, V, ARGS)                                         \
+  do {                                                                \
+    if constexpr (DBG == 0) r64m_##S##V(ARGS);                        \
+    else if constexpr (DBG == 1) r64m_##S##V##_noeu(ARGS);            \
+    else if constexpr (DBG == 2) r64m_##S##V##_nobar(ARGS);           \
+    else if constexpr (DBG == 3) r64m_##S##V##_mfmaonly_nobar(ARGS);          \
+    else r64m_##S##V##_mfmaonly(ARGS);                                \
+  } while (0)
+#else
+#define R64M_STEP(S, V, ARGS) r64m_##S##V(ARGS)
+#endif
+  // deferred rescale (rare): some lane saw its row's maximum over its 16 keys of tile t + 1 exceed m + THR.  O^T holds the
+  // tiles up to t's chunk 0 and l the row sums up to t, both at the old reference - and so does the packed chunk 1 of P(t),
+  // which enters O^T in phase 2b: all three are scaled.
+#define R64M_TILE(V)                                                                                   \
+  {                                                                                                    \
+    unsigned long long mask;                                                                           \
+    R64M_STEP(A, V, R64M_A_ARGS);                                                                      \
+    kg += tc < klim ? kstep : 0u;                                                                      \
+    sm[0].l += rs0;                                                                                    \
+    sm[1].l += rs1;                                                                                    \
+    rs0 = 0.f;                                                                                         \
+    rs1 = 0.f;                                                                                         \
+    if (__builtin_expect(mask != 0, 0)) {                                                              \
+      asm volatile("s_nop 15\n\ts_nop 7" ::: "memory"); /* the last PV MFMAs must have written O^T */  \
+      const float mloc[2] = {a0, a1};                                                                  \
+      _Pragma("unroll") for (int r_ = 0; r_ < 2; ++r_) {                                               \
+        const float mx = half_swap_max(mloc[r_] * p.c);                                                \
+        const float m_new = fmaxf(sm[r_].m, mx);                                                       \
+        const float alpha = __builtin_amdgcn_exp2f(sm[r_].m - m_new);                                  \
+        sm[r_].m = m_new;                                                                              \
+        sm[r_].thr = m_new + RESCALE_THR;                                                              \
+        sm[r_].l *= alpha;                                                                             \
+        if (r_ == 0) r64m_scale_o0(alpha);                                                             \
+        else r64m_scale_o1(alpha);                                                                     \
+        const half2v a2 = {(_Float16)alpha, (_Float16)alpha};                                          \
+        if (r_ == 0) r64m_scale_p0(__builtin_bit_cast(unsigned, a2));                              \
+        else r64m_scale_p1(__builtin_bit_cast(unsigned, a2));                                      \
+      }                                                                                                \
+    }                                                                                                  \
+    R64M_STEP(B, V, R64M_B_ARGS);                                                                      \
+    vg += tc < vlim ? vstep : 0u;                                                                      \
+    ++tc;                                                                                              \
+  }
+#ifdef DVD_LAB
+  if (p.stamps) ts[1] = __builtin_readcyclecounter();
+#endif
+  for (int t = 0; t < nt; t += 6) {         // nt is even
+    R64M_TILE(0) R64M_TILE(1)
+    if (t + 2 >= nt) break;
+    R64M_TILE(2) R64M_TILE(3)
+    if (t + 4 >= nt) break;
+    R64M_TILE(4) R64M_TILE(5)
+  }
+#undef R64M_TILE
+#undef R64M_STEP
+#ifdef DVD_LAB
+  if (p.stamps) ts[2] = __builtin_readcyclecounter();
+#endif
   // drain the LDS-DMA and the fragment reads still in flight (the last iterations re-load clamped tiles, and the last phase
   // 2b formed the early units of a tile that does not exist - never added to l): LDS must not be written after the workgroup
   // has ended; and the last PV MFMAs must have written O^T before the compiler's code reads it
@@ -1343,18 +1383,28 @@ __global__ void __launch_bounds__(256, 1) flash_attn_r64m_kernel(AttnArgs p) {
     const float inv = 1.f / l_tot;
     const int qglob = qb * 256 + wave * 64 + rb * 32 + r;
     if (qglob < p.tq) {
-      _Float16* op = p.O + b * p.sO + (size_t)qglob * p.ldo + (size_t)head * D;
-#pragma unroll
-      for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-          half4 v;
-#pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] = (_Float16)(o[rb][dt][4 * g4 + j] * inv);
-          *(half4*)(op + 32 * dt + 8 * g4 + 4 * h) = v;
-        }
+      _Float16* op = p.O + b * p.sO + (size_t)qglob * p.ldo + (size_t)head * D + 4 * h;
+      if (rb == 0) r64m_store_row<0>(op, inv, std::make_integer_sequence<int, 8>{});
+      else r64m_store_row<1>(op, inv, std::make_integer_sequence<int, 8>{});
     }
   }
+#ifdef DVD_LAB
+  if (p.stamps) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ts[3] = __builtin_readcyclecounter();
+    if (lane == 0) {
+      unsigned long long* o_ = p.stamps + ((size_t)blockIdx.x * 4 + wave) * 6;
+      o_[0] = ts[1] - ts[0];
+      o_[1] = ts[2] - ts[1];
+      o_[2] = ts[3] - ts[2];
+      o_[3] = ts[0];
+      o_[4] = ts[3];
+      // HW_ID (register 4, all 32 bits) | XCC_ID (register 20, bits 3:0) << 32: which CU ran this workgroup
+      o_[5] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) |
+              ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 32);
+    }
+  }
+#endif
 }
 
 #ifdef DVD_LAB
@@ -1443,6 +1493,10 @@ extern "C" int dvd_flash_attn(const dvd_attn_desc* d, void* stream) {
     allow_lds(flash_attn_r64_kernel<1>, 2 * (32 * 512 + 256 * 64));
     allow_lds(flash_attn_r64p_kernel<1>, r64p::LDS_BYTES);
     allow_lds(flash_attn_r64m_kernel<0>, r64p::LDS_BYTES);
+    allow_lds(flash_attn_r64m_kernel<1>, r64p::LDS_BYTES);
+    allow_lds(flash_attn_r64m_kernel<2>, r64p::LDS_BYTES);
+    allow_lds(flash_attn_r64m_kernel<3>, r64p::LDS_BYTES);
+    allow_lds(flash_attn_r64m_kernel<4>, r64p::LDS_BYTES);
   }
   if (fast && d->head_dim == 256) {
     constexpr int LDS = 2 * (64 * 512 + 256 * 128);
@@ -1452,7 +1506,15 @@ extern "C" int dvd_flash_attn(const dvd_attn_desc* d, void* stream) {
     }
     if (r64 && getenv("DVD_ATTN_R64M")) {     // r64p's schedule with hand-allocated registers, one exp unit per step
       p.nqb = cdiv(d->tq, 256);
-      flash_attn_r64m_kernel<0><<<(unsigned)((long)p.nqb * d->heads * d->batch), 256, r64p::LDS_BYTES, st>>>(p);
+      const unsigned g = (unsigned)((long)p.nqb * d->heads * d->batch);
+      // DVD_ATTN_R64M_ABL = 1..4: TIMING ABLATIONS (garbage results): no exp units | no barrier | MFMAs only, no barrier | MFMAs only
+      switch (getenv("DVD_ATTN_R64M_ABL") ? atoi(getenv("DVD_ATTN_R64M_ABL")) : 0) {
+        case 1: flash_attn_r64m_kernel<1><<<g, 256, r64p::LDS_BYTES, st>>>(p); break;
+        case 2: flash_attn_r64m_kernel<2><<<g, 256, r64p::LDS_BYTES, st>>>(p); break;
+        case 3: flash_attn_r64m_kernel<3><<<g, 256, r64p::LDS_BYTES, st>>>(p); break;
+        case 4: flash_attn_r64m_kernel<4><<<g, 256, r64p::LDS_BYTES, st>>>(p); break;
+        default: flash_attn_r64m_kernel<0><<<g, 256, r64p::LDS_BYTES, st>>>(p);
+      }
       return check_launch("flash_attn(lab r64m)");
     }
     if (r64 && getenv("DVD_ATTN_R64OLD")) {   // rounds 1-3's production kernel (lab include), with or without its stamps

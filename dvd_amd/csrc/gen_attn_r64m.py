@@ -15,8 +15,11 @@ Register plan (one wave per SIMD: 256 architectural VGPRs + 256 AGPRs):
         v[64:95]   S^T buffer A            rb 0: 64..79, rb 1: 80..95
         v[96:127]  S^T buffer B
         v[128:255] Q fragments             128 + 4 * (16 rb + ks)
-  Every hand-allocated register is also passed as an operand with a physical-register constraint, so the compiler knows
-  the state lives there between statements (see `pinned`).
+  The kernel is compiled with amdgpu_num_vgpr(32): the compiler's allocator is confined to v[0:31] and the statements
+  own v[32:255] outright (they are named literally in the text, never passed as operands).  v1 passed every one of them as
+  a physical-register operand instead; with six tile variants in the loop hipcc then failed to coalesce the copies around
+  the back-edge and spilled and re-loaded the pinned state once per loop trip.  tests/test_abi.py greps the kernel's ISA:
+  outside the asm statements no instruction may name a VGPR above v31.
 An exponential OVERWRITES the S^T element it consumes and a packed word is written straight into its P fragment register,
 so the softmax needs no register of its own - which is what lets a tile's first eight exp units run one iteration early
 (in the previous iteration's phase 2b) and puts exactly ONE unit beside every pair of MFMAs (see attention.hip).
@@ -31,6 +34,14 @@ Schedule of iteration t (parity p = t & 1: S^T(t) in buffer p, S^T(t+1) into buf
   statement B   vmcnt(4) + s_barrier
                 phase 2b   8 fragment steps  O^T += V^T(t) frag (chunk 1, g) . P01/P11 | unit g of tile t + 1 (in buffer 1 - p)
                                              second gap: V^T(t+2) LDS-DMA piece (g = 1..4)
+No glue (v2): a tile's statements exist in SIX variants, i = t % 6 (S^T buffer parity i & 1, K / V^T ring slot i % 3), so every
+LDS address is a loop-invariant base register + an immediate and every LDS-DMA destination is `s_add_i32 m0, base, imm`;
+the DMA sources are one SGPR pair per stream + four loop-invariant VGPR offsets, and the compiler advances the pair between
+the statements - or, past the last tile, does not - with four SALU instructions (an asm OUTPUT in SGPRs is taken for
+divergent by hipcc's uniformity analysis and ends in `illegal VGPR to SGPR copy`, so the pair cannot be advanced inside).
+Between two tiles the compiler has nothing else left to compute but `l += rs` and the (out-of-line) rare branch: the MFMA-only
+ablation of v1 ran 2412 cycles per tile for 64 MFMAs (2048) - ~55 scalar instructions of address arithmetic per tile,
+issued one per ~6 cycles by the only wave of the SIMD, were the largest single loss of the kernel.
 Fragment ring: step n (0..31 over A and B) uses slot n & 3 after `s_waitcnt lgkmcnt(2)` and reads the fragment of step n + 3
 into slot (n + 3) & 3 in its first gap; the last three steps of B read the first three K fragments of the next iteration.
 """
@@ -42,6 +53,7 @@ FR0 = 48
 SBUF = (64, 96)
 Q0 = 128
 KPIECE = 1056
+KBYTES, VBYTES = 16 * KPIECE, 16384
 
 
 def vr(lo, n=1):
@@ -65,6 +77,11 @@ def frag(slot):
     return vr(FR0 + 4 * (slot & 3), 4)
 
 
+def oreg(rb, dt):
+    """O^T accumulator tile (row block rb, 32 output dims dt)"""
+    return f"a[{16 * (8 * rb + dt)}:{16 * (8 * rb + dt) + 15}]"
+
+
 def qreg(rb, ks):
     return vr(Q0 + 4 * (16 * rb + ks), 4)
 
@@ -72,15 +89,30 @@ def qreg(rb, ks):
 MF = "v_mfma_f32_32x32x16_f16"
 
 
+ABL = set()        # timing ablations (lab builds only; results are garbage): "eu", "dma", "read", "wait", "max", "pack"
+
+
 class Stmt:
     def __init__(self):
         self.lines = []
 
     def add(self, s):
+        if "read" in ABL and s.startswith("ds_read"):
+            return
+        if "wait" in ABL and s.startswith("s_waitcnt lgkmcnt"):
+            return
+        if "bar" in ABL and s.startswith("s_barrier"):
+            return
+        if "max" in ABL and (s.startswith("v_max") or s.startswith("v_cmp")):
+            if s.startswith("v_cmp"):
+                self.lines.append("s_mov_b64 %[mask], 0")
+            return
         self.lines.append(s)
 
     def eu(self, buf, u, add_from=None):
         """exp unit u of the tile in `buf`, in place; then the row-sum add of unit add_from (same buffer) if given"""
+        if "eu" in ABL:
+            return
         x = vr(sreg(buf, u))
         self.add(f"v_fma_f32 {x}, {x}, %[c], -%[m{urb(u)}]")
         self.add(f"v_exp_f32_e32 {x}, {x}")
@@ -89,30 +121,40 @@ class Stmt:
 
     def pack(self, dst, buf, units):
         """four packed words of one P fragment: word j <- (units[2j], units[2j + 1])"""
+        if "pack" in ABL:
+            return
         for j in range(4):
             self.add(f"v_cvt_pk_f16_f32 {vr(dst + j)}, {vr(sreg(buf, units[2 * j]))}, {vr(sreg(buf, units[2 * j + 1]))}")
 
+    def dma_m0(self, which, slot, i):
+        """first gap: the LDS destination of piece i (the MFMA that follows separates the M0 write from its use)"""
+        if "dma" in ABL:
+            return
+        imm = slot * (KBYTES if which == "k" else VBYTES) + i * (KPIECE if which == "k" else 1024)
+        self.add(f"s_add_i32 m0, %[{which}dst], {imm}")
+
     def dma(self, which, i):
-        self.add(f"s_mov_b32 m0, %[lds{which}{i}]")
-        self.add("s_nop 0")
-        self.add(f"global_load_lds_dwordx4 %[{which}off], %[gb{which}{i}]")
+        if "dma" in ABL:
+            return
+        self.add(f"global_load_lds_dwordx4 %[{which}off{i}], %[{which}g]")
 
     def text(self):
         return "\n".join(f'      "{ln}\\n\\t"' for ln in self.lines)
 
 
-def read_for_step(n):
-    """(address operand, immediate) of the fragment that step n of an iteration consumes; n >= 32: next iteration's K"""
+def read_for_step(n, slot):
+    """(address operand, immediate) of the fragment that step n of tile t consumes (slot = t % 3); n >= 32: the next tile's"""
     if n < 16:
-        return "kcur", n * 32
+        return "kaddr", ((slot + 1) % 3) * KBYTES + n * 32            # K(t+1)
     if n < 24:
-        return "vrd0", (n - 16) * 2048
+        return "vrel0", slot * VBYTES + (n - 16) * 2048                # V^T(t), chunk 0
     if n < 32:
-        return "vrd1", (n - 24) * 2048
-    return "knext", (n - 32) * 32
+        return "vrel1", slot * VBYTES + (n - 24) * 2048                # V^T(t), chunk 1
+    return "kaddr", ((slot + 2) % 3) * KBYTES + (n - 32) * 32         # K(t+2)
 
 
-def stmt_a(par):
+def stmt_a(var):
+    par, slot = var & 1, var % 3
     sc, sn = par, 1 - par
     s = Stmt()
     sn0, sn1 = vr(SBUF[sn], 16), vr(SBUF[sn] + 16, 16)
@@ -121,8 +163,10 @@ def stmt_a(par):
         s.add("s_waitcnt lgkmcnt(2)")
         c_in = "0" if f == 0 else sn0
         s.add(f"{MF} {sn0}, {frag(n)}, {qreg(0, f)}, {c_in}")
-        a, off = read_for_step(n + 3)
+        a, off = read_for_step(n + 3, slot)
         s.add(f"ds_read_b128 {frag(n + 3)}, %[{a}] offset:{off}")
+        if f in (3, 7, 11, 15):
+            s.dma_m0("k", slot, f >> 2)                  # K(t+3) -> K slot t % 3
         s.eu(sc, 8 + f, add_from=7 + f)
         c_in = "0" if f == 0 else sn1
         s.add(f"{MF} {sn1}, {frag(n)}, {qreg(1, f)}, {c_in}")
@@ -136,11 +180,11 @@ def stmt_a(par):
     for g in range(8):                                    # ---- phase 2a
         n = 16 + g
         s.add("s_waitcnt lgkmcnt(2)")
-        s.add(f"{MF} %[o0_{g}], {frag(n)}, {vr(P00, 4)}, %[o0_{g}]")
-        a, off = read_for_step(n + 3)
+        s.add(f"{MF} {oreg(0, g)}, {frag(n)}, {vr(P00, 4)}, {oreg(0, g)}")
+        a, off = read_for_step(n + 3, slot)
         s.add(f"ds_read_b128 {frag(n + 3)}, %[{a}] offset:{off}")
         s.eu(sc, 24 + g, add_from=23 + g)
-        s.add(f"{MF} %[o1_{g}], {frag(n)}, {vr(P10, 4)}, %[o1_{g}]")
+        s.add(f"{MF} {oreg(1, g)}, {frag(n)}, {vr(P10, 4)}, {oreg(1, g)}")
         if g == 0:      # four chains: a = elements 0..6, b = 7..13 of each row block
             s.add(f"v_max3_f32 %[a0], v{S0 + 0}, v{S0 + 1}, v{S0 + 2}")
             s.add(f"v_max3_f32 %[b0], v{S0 + 7}, v{S0 + 8}, v{S0 + 9}")
@@ -169,7 +213,8 @@ def stmt_a(par):
     return s
 
 
-def stmt_b(par):
+def stmt_b(var):
+    par, slot = var & 1, var % 3
     sn = 1 - par
     s = Stmt()
     s.add("s_waitcnt vmcnt(4)")
@@ -177,11 +222,13 @@ def stmt_b(par):
     for g in range(8):                                    # ---- phase 2b
         n = 24 + g
         s.add("s_waitcnt lgkmcnt(2)")
-        s.add(f"{MF} %[o0_{g}], {frag(n)}, {vr(P01, 4)}, %[o0_{g}]")
-        a, off = read_for_step(n + 3)
+        s.add(f"{MF} {oreg(0, g)}, {frag(n)}, {vr(P01, 4)}, {oreg(0, g)}")
+        a, off = read_for_step(n + 3, slot)
         s.add(f"ds_read_b128 {frag(n + 3)}, %[{a}] offset:{off}")
+        if 1 <= g <= 4:
+            s.dma_m0("v", (slot + 2) % 3, g - 1)         # V^T(t+2) -> V slot (t + 2) % 3
         s.eu(sn, g, add_from=(g - 1) if g else None)
-        s.add(f"{MF} %[o1_{g}], {frag(n)}, {vr(P11, 4)}, %[o1_{g}]")
+        s.add(f"{MF} {oreg(1, g)}, {frag(n)}, {vr(P11, 4)}, {oreg(1, g)}")
         if 1 <= g <= 4:
             s.dma("v", g - 1)
     return s
@@ -216,7 +263,7 @@ def prologue_units():
     """units 0..7 of tile 0 in place (buffer 0), the row sums of units 0..6, and the ring primed with K(1) frags 0..2"""
     s = Stmt()
     for f in range(3):
-        s.add(f"ds_read_b128 {frag(f)}, %[kcur] offset:{f * 32}")
+        s.add(f"ds_read_b128 {frag(f)}, %[kaddr] offset:{KBYTES + f * 32}")
     for u in range(8):
         s.eu(0, u, add_from=(u - 1) if u else None)
     return s
@@ -226,29 +273,8 @@ def drain_text():
     return None
 
 
-# Every hand-allocated register is ALSO an operand with a physical-register constraint ("{v[64:79]}"): the compiler then
-# knows these values live there between the statements (it may not park a temporary of its own in them) and would copy
-# rather than corrupt if it ever disagreed - correctness never rests on the compiler leaving registers alone.
-def pinned(io):
-    """operand list of the pinned state; io = '+' (in/out) or '' (input only, Q)"""
-    ops = []
-    for rb in range(2):
-        ops.append(f'"+{{v[{SBUF[0] + 16 * rb}:{SBUF[0] + 16 * rb + 15}]}}"(st.sa[{rb}])')
-    for rb in range(2):
-        ops.append(f'"+{{v[{SBUF[1] + 16 * rb}:{SBUF[1] + 16 * rb + 15}]}}"(st.sb[{rb}])')
-    for i in range(4):
-        ops.append(f'"+{{v[{P00 + 4 * i}:{P00 + 4 * i + 3}]}}"(st.p[{i}])')
-    for i in range(4):
-        ops.append(f'"+{{v[{FR0 + 4 * i}:{FR0 + 4 * i + 3}]}}"(st.fr[{i}])')
-    return ops
-
-
-def pinned_q():
-    return [f'"{{v[{Q0 + 4 * (16 * rb + ks)}:{Q0 + 4 * (16 * rb + ks) + 3}]}}"(st.q[{rb}][{ks}])' for rb in range(2)
-            for ks in range(16)]
-
-
-O_OPS = ", ".join(f'[o{rb}_{dt}] "+a"(o[{rb}][{dt}])' for rb in range(2) for dt in range(8))
+VARIANTS = [("", ()), ("noeu", ("eu", "pack")), ("nobar", ("bar",)), ("mfmaonly_nobar", ("eu", "pack", "dma", "read", "wait", "max", "bar")),
+            ("mfmaonly", ("eu", "pack", "dma", "read", "wait", "max"))]
 
 
 def wrap(items, indent="        ", width=150):
@@ -263,101 +289,134 @@ def wrap(items, indent="        ", width=150):
 
 
 def emit():
-    out = []
+    """-> (product file text, lab file text: the timing ablations)"""
+    out, lab = [], []
+    lab.append("// GENERATED by dvd_amd/csrc/gen_attn_r64m.py - do not edit.  TIMING ABLATIONS of the r64m statements (lab builds only:")
+    lab.append("// they compute garbage) - which part of a tile costs what: see attention.hip (DVD_ATTN_R64M_ABL).")
+    lab.append("// clang-format off")
     w = out.append
     w("// GENERATED by gen_attn_r64m.py - do not edit; see that file for the register plan and the schedule.")
     w("// clang-format off")
-    w("struct R64mState {        // the hand-allocated registers, as the compiler sees them (pinned operands)")
-    w("  floatx16 sa[2], sb[2];  // S^T buffers A / B             v[64:95] / v[96:127]")
-    w("  u32x4 p[4];             // packed P: p00 p10 p01 p11    v[32:47]")
-    w("  half8 fr[4];            // fragment ring                v[48:63]")
-    w("  half8 q[2][16];         // Q fragments                  v[128:255]")
-    w("};")
+    w(f"#define R64M_COMPILER_VGPRS {P00}   // the kernel carries __attribute__((amdgpu_num_vgpr(R64M_COMPILER_VGPRS)))")
     w("")
     # Q load: 32 x 16 bytes per lane, two row pointers
-    w("__device__ __forceinline__ void r64m_load_q(R64mState& st, const _Float16* q0, const _Float16* q1) {")
+    w("__device__ __forceinline__ void r64m_load_q(const _Float16* q0, const _Float16* q1) {")
     w("  asm volatile(")
     for rb in range(2):
         for ks in range(16):
             w(f'      "global_load_dwordx4 {qreg(rb, ks)}, %[q{rb}], off offset:{32 * ks}\\n\\t"')
     w('      "s_waitcnt vmcnt(0)"')
-    w("      : " + wrap([x.replace('"{', '"={') for x in pinned_q()], "        ").lstrip())
-    w('      : [q0] "v"(q0), [q1] "v"(q1) : "memory");')
+    w('      : : [q0] "v"(q0), [q1] "v"(q1) : "memory", "v255", "a255");   // the clobbers make the kernel descriptor allocate 256 + 256')
     w("}")
     w("")
-    w("__device__ __forceinline__ void r64m_prologue_s0(R64mState& st, unsigned kaddr, float& a0, float& a1) {")
+    w("__device__ __forceinline__ void r64m_prologue_s0(unsigned kaddr, float& a0, float& a1) {")
     w("  asm volatile(")
     w(prologue_s0().text())
-    w('      : [a0] "=&v"(a0), [a1] "=&v"(a1),')
-    w(wrap([x.replace('"+{', '"=&{') for x in pinned("+")[:2]] + [x.replace('"+{', '"=&{') for x in pinned("+")[8:]]))
-    w('      : [kaddr] "v"(kaddr),')
-    w(wrap(pinned_q()))
+    w('      : [a0] "=&v"(a0), [a1] "=&v"(a1)')
+    w('      : [kaddr] "v"(kaddr)')
     w('      : "memory");')
     w("}")
     w("")
-    w("__device__ __forceinline__ void r64m_prologue_units(R64mState& st, unsigned kcur, float c, float m0, float m1, float& rs0,")
+    w("__device__ __forceinline__ void r64m_prologue_units(unsigned kaddr, float c, float m0, float m1, float& rs0,")
     w("                                                    float& rs1) {")
     w("  asm volatile(")
     w(prologue_units().text())
-    w('      : [rs0] "+v"(rs0), [rs1] "+v"(rs1),')
-    w(wrap(pinned("+")[:2] + [x.replace('"+{', '"=&{') for x in pinned("+")[8:]]))
-    w('      : [kcur] "v"(kcur), [c] "s"(c), [m0] "v"(m0), [m1] "v"(m1)')
+    w('      : [rs0] "+v"(rs0), [rs1] "+v"(rs1)')
+    w('      : [kaddr] "v"(kaddr), [c] "s"(c), [m0] "v"(m0), [m1] "v"(m1)')
     w('      : "memory");')
     w("}")
     w("")
-    for par in range(2):
-        w(f"// ---- statement A, parity {par}: phase 1 (S^T(t+1) into buffer {1 - par}, units 8..23 of buffer {par}) and phase 2a")
-        w(f"__device__ __forceinline__ void r64m_A{par}(R64mState& st, floatx16 (&o)[2][8], float& rs0, float& rs1, float& a0, float& a1,")
-        w("    unsigned long long& mask, unsigned kcur, unsigned vrd0, unsigned vrd1, unsigned koff, float c, float m0, float m1,")
-        w("    float thr0, float thr1, const char* gbk0, const char* gbk1, const char* gbk2, const char* gbk3, unsigned ldsk0,")
-        w("    unsigned ldsk1, unsigned ldsk2, unsigned ldsk3) {")
-        w("  float b0, b1;")
+    for abl_name, abl in VARIANTS:
+        ABL.clear()
+        ABL.update(abl)
+        sfx = "" if not abl_name else "_" + abl_name
+        tgt = out if not abl_name else lab
+        w = tgt.append
+        for var in range(6):
+            w(f"// ---- statement A{sfx}, tile variant {var} (S^T(t) in buffer {var & 1}, ring slot {var % 3}): phase 1 and phase 2a")
+            w(f"__device__ __forceinline__ void r64m_A{var}{sfx}(float& rs0, float& rs1, float& a0, float& a1,")
+            w("    unsigned long long& mask, const char* kg, unsigned kaddr, unsigned vrel0, unsigned vrel1, const unsigned (&koff)[4],")
+            w("    float c, float m0, float m1, float thr0, float thr1, unsigned kdst) {")
+            w("  float b0, b1;")
+            w("  asm volatile(")
+            w(stmt_a(var).text())
+            w('      : [rs0] "+v"(rs0), [rs1] "+v"(rs1), [a0] "=&v"(a0), [a1] "=&v"(a1), [b0] "=&v"(b0), [b1] "=&v"(b1), [mask] "=&s"(mask)')
+            w('      : [kaddr] "v"(kaddr), [vrel0] "v"(vrel0), [vrel1] "v"(vrel1), [koff0] "v"(koff[0]), [koff1] "v"(koff[1]), [koff2] "v"(koff[2]),')
+            w('        [koff3] "v"(koff[3]), [c] "s"(c), [m0] "v"(m0), [m1] "v"(m1), [thr0] "v"(thr0), [thr1] "v"(thr1), [kdst] "s"(kdst),')
+            w('        [kg] "s"(kg)')
+            w('      : "memory");')
+            w("}")
+            w("")
+            w(f"// ---- statement B{sfx}, tile variant {var}: barrier, phase 2b (chunk 1 of tile t; units 0..7 of tile t + 1 in buffer {1 - (var & 1)})")
+            w(f"__device__ __forceinline__ void r64m_B{var}{sfx}(float& rs0, float& rs1, const char* vg,")
+            w("    unsigned kaddr, unsigned vrel1, const unsigned (&voff)[4], float c, float m0, float m1, unsigned vdst) {")
+            w("  asm volatile(")
+            w(stmt_b(var).text())
+            w('      : [rs0] "+v"(rs0), [rs1] "+v"(rs1)')
+            w('      : [kaddr] "v"(kaddr), [vrel1] "v"(vrel1), [voff0] "v"(voff[0]), [voff1] "v"(voff[1]), [voff2] "v"(voff[2]), [voff3] "v"(voff[3]),')
+            w('        [c] "s"(c), [m0] "v"(m0), [m1] "v"(m1), [vdst] "s"(vdst), [vg] "s"(vg)')
+            w('      : "memory");')
+            w("}")
+            w("")
+    w = out.append
+    ABL.clear()
+    w("__device__ __forceinline__ void r64m_zero_o() {")
+    w("  asm volatile(")
+    for i in range(256):
+        w(f'      "v_accvgpr_write_b32 a{i}, 0\\n\\t"')
+    w('      "s_nop 1" ::: "memory");')
+    w("}")
+    w("")
+    w("// one accumulator tile of O^T for the compiler (the epilogue): 16 registers of its own; BASE = 16 * (8 * rb + dt)")
+    w("template <int BASE>")
+    w("__device__ __forceinline__ floatx16 r64m_read_o() {")
+    w("  floatx16 x;")
+    w("  asm volatile(")
+    for i in range(16):
+        w(f'      "v_accvgpr_read_b32 %{i}, a[%{16 + i}]\\n\\t"')
+    w('      "s_nop 0"')
+    w("      : " + ", ".join(f'"=&v"(x[{i}])' for i in range(16)))
+    w("      : " + ", ".join(f'"n"(BASE + {i})' for i in range(16)) + " : \"memory\");")
+    w("  return x;")
+    w("}")
+    w("")
+    w("// rare branch: O^T of one row block *= alpha (through eight compiler temporaries)")
+    for rb in range(2):
+        w(f"__device__ __forceinline__ void r64m_scale_o{rb}(float alpha) {{")
+        w("  float t0, t1, t2, t3, t4, t5, t6, t7;")
         w("  asm volatile(")
-        w(stmt_a(par).text())
-        w(f"      : {O_OPS},")
-        w('        [rs0] "+v"(rs0), [rs1] "+v"(rs1), [a0] "=&v"(a0), [a1] "=&v"(a1), [b0] "=&v"(b0), [b1] "=&v"(b1), [mask] "=&s"(mask),')
-        w(wrap(pinned("+")))
-        w('      : [kcur] "v"(kcur), [vrd0] "v"(vrd0), [vrd1] "v"(vrd1), [koff] "v"(koff), [c] "s"(c), [m0] "v"(m0), [m1] "v"(m1),')
-        w('        [thr0] "v"(thr0), [thr1] "v"(thr1), [gbk0] "s"(gbk0), [gbk1] "s"(gbk1), [gbk2] "s"(gbk2), [gbk3] "s"(gbk3),')
-        w('        [ldsk0] "s"(ldsk0), [ldsk1] "s"(ldsk1), [ldsk2] "s"(ldsk2), [ldsk3] "s"(ldsk3),')
-        w(wrap(pinned_q()))
-        w('      : "memory");')
+        for base in range(128 * rb, 128 * rb + 128, 8):
+            for i in range(8):
+                w(f'      "v_accvgpr_read_b32 %[t{i}], a{base + i}\\n\\t"')
+            for i in range(8):
+                w(f'      "v_mul_f32_e32 %[t{i}], %[alpha], %[t{i}]\\n\\t"')
+            for i in range(8):
+                w(f'      "v_accvgpr_write_b32 a{base + i}, %[t{i}]\\n\\t"')
+        w('      "s_nop 1"')
+        w("      : " + ", ".join(f'[t{i}] "=&v"(t{i})' for i in range(8)))
+        w('      : [alpha] "v"(alpha) : "memory");')
         w("}")
-        w("")
-        w(f"// ---- statement B, parity {par}: barrier, phase 2b (chunk 1 of tile t; units 0..7 of tile t + 1 in buffer {1 - par})")
-        w(f"__device__ __forceinline__ void r64m_B{par}(R64mState& st, floatx16 (&o)[2][8], float& rs0, float& rs1, unsigned vrd1,")
-        w("    unsigned knext, unsigned voff, float c, float m0, float m1, const char* gbv0, const char* gbv1, const char* gbv2,")
-        w("    const char* gbv3, unsigned ldsv0, unsigned ldsv1, unsigned ldsv2, unsigned ldsv3) {")
-        w("  asm volatile(")
-        w(stmt_b(par).text())
-        w(f"      : {O_OPS},")
-        w('        [rs0] "+v"(rs0), [rs1] "+v"(rs1),')
-        w(wrap(pinned("+")))
-        w('      : [vrd1] "v"(vrd1), [knext] "v"(knext), [voff] "v"(voff), [c] "s"(c), [m0] "v"(m0), [m1] "v"(m1),')
-        w('        [gbv0] "s"(gbv0), [gbv1] "s"(gbv1), [gbv2] "s"(gbv2), [gbv3] "s"(gbv3),')
-        w('        [ldsv0] "s"(ldsv0), [ldsv1] "s"(ldsv1), [ldsv2] "s"(ldsv2), [ldsv3] "s"(ldsv3),')
-        w(wrap(pinned_q()))
-        w('      : "memory");')
-        w("}")
-        w("")
+    w("")
     # rare branch: scale the packed chunk 1 of one row block
     for rb, idx, base in ((0, 2, P01), (1, 3, P11)):
-        w(f"__device__ __forceinline__ void r64m_scale_p{rb}(R64mState& st, unsigned a2) {{")
+        w(f"__device__ __forceinline__ void r64m_scale_p{rb}(unsigned a2) {{")
         w("  asm volatile(")
         for j in range(4):
             w(f'      "v_pk_mul_f16 v{base + j}, v{base + j}, %[a2]\\n\\t"')
         w('      "s_nop 1"')
-        w(f'      : "+{{v[{base}:{base + 3}]}}"(st.p[{idx}]) : [a2] "v"(a2));')
+        w('      : : [a2] "v"(a2) : "memory");')
         w("}")
     w("// clang-format on")
-    return "\n".join(out) + "\n"
+    lab.append("// clang-format on")
+    return "\n".join(out) + "\n", "\n".join(lab) + "\n"
 
 
 if __name__ == "__main__":
     here = os.path.dirname(os.path.abspath(__file__))
-    text = emit()
-    path = os.path.join(here, "attn_r64m_body.inc")
+    files = dict(zip((os.path.join(here, "attn_r64m_body.inc"),
+                      os.path.join(here, "..", "..", "benchmarks", "lab", "csrc", "attn_r64m_abl.inc")), emit()))
     if len(sys.argv) > 1 and sys.argv[1] == "--check":
-        sys.exit(0 if os.path.exists(path) and open(path).read() == text else 1)
-    open(path, "w").write(text)
-    print(f"wrote {path}: {text.count(chr(10))} lines")
+        sys.exit(0 if all(os.path.exists(p) and open(p).read() == t for p, t in files.items()) else 1)
+    for p, t in files.items():
+        open(p, "w").write(t)
+        print(f"wrote {os.path.normpath(p)}: {t.count(chr(10))} lines")
