@@ -4,8 +4,7 @@ kernel exit (four stamps per wave, all OUTSIDE the tile loop - the loop runs unp
 many workgroups each CU ran and the gaps between one workgroup's exit and the next one's entry on the same CU.
 usage: [B=16] [ablation 0..4]   (lab build)"""
 import os, sys
-os.environ["DVD_ATTN_R64M"] = "1"
-if len(sys.argv) > 2:
+if len(sys.argv) > 2 and sys.argv[2] != "0":
     os.environ["DVD_ATTN_R64M_ABL"] = sys.argv[2]
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__))); import _lab; _lab.use_lab()
 sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))

@@ -1,3 +1,4 @@
 #!/bin/bash
 mkdir -p gpurun_out/r4
-for a in 0; do echo "== ablation $a"; timeout 200 python benchmarks/attn_stamps_r64m.py 16 $a 2>&1 | grep -v amdgpu.ids; done | tee gpurun_out/r4/c24_stamps.txt
+timeout 1500 python -m pytest tests -m gpu -q -x 2>&1 | tail -8 | tee gpurun_out/r4/c26_gpu_tests.txt
+timeout 900 python bench.py --steps 1 --warmup 1 2>gpurun_out/r4/c26_bench.err | tee gpurun_out/r4/c26_bench.json

@@ -1178,17 +1178,23 @@ __global__ void __launch_bounds__(256, 1) flash_attn_r64p_kernel(AttnArgs p) {
 
 
 // ================================================================================================
-// r64m = r64p with HAND-ALLOCATED registers and ONE exp unit per fragment step (round 4, second step).
-// In r64p the 32 exponential units of a tile must be finished before that tile's second PV chunk starts, so 24 of them sit
-// in phase 1 - two per fragment step: gaps of 40+ issue cycles beside 32-cycle MFMAs (stamps: 37 cycles per MFMA in phase
-// 1, 32-33 in phase 2) - and phase 2b has none.  Letting a tile's first 8 units run one iteration EARLY (in the previous
-// iteration's phase 2b) gives every one of the 32 fragment steps exactly one unit, but with compiler-allocated registers it
-// cost 8 + live values and hipcc answered with 193 scratch reloads of Q inside the loop (the kernel sits at 256 + 256).
-// Here the loop's state lives in registers chosen by hand (gen_attn_r64m.py: the plan, the schedule and the generator of
-// attn_r64m_body.inc): an exponential OVERWRITES the S^T element it consumes, a packed word is written straight into its
-// P fragment register, so the softmax owns no register at all, and an iteration is TWO asm statements (phase 1 + 2a | the
-// compiler's l update and rare rescale | barrier + phase 2b) with every register also passed as a physical-register
-// operand, so the compiler knows what lives where.
+// r64m (round 4; the PRODUCTION kernel for head_dim 256 at tq >= R64_MIN_TQ) = r64p's data movement and pipeline with
+// HAND-ALLOCATED registers, ONE exp unit per fragment step, and the whole key-tile loop as ONE generated asm statement.
+//  * r64p keeps 24 of a tile's 32 exponential units in phase 1 (two per fragment step) and none in phase 2b.  Letting a
+//    tile's first 8 units run one tile EARLY (in the previous tile's phase 2b) gives each of the 32 steps exactly one, but
+//    with compiler-allocated registers that cost 8+ live values and hipcc answered with 193 scratch reloads of Q inside
+//    the loop (the kernel sits at 256 + 256).  Here an exponential OVERWRITES the S^T element it consumes and a packed
+//    word is written straight into its P fragment register: the softmax owns no register at all.
+//  * The registers v[32:255] and a[0:255] belong to the statements (the kernel is compiled with amdgpu_num_vgpr(32));
+//    tests/test_abi.py checks on the ISA that the compiler's code never touches them.
+//  * No glue: the MFMA-only ABLATION of the first version ran 2412 cycles per tile for 2048 cycles of MFMA - ~55 scalar
+//    instructions of address arithmetic per tile, issued one per ~6 cycles by the SIMD's only wave, cost more than the
+//    whole softmax.  Six tile variants (t % 6) turn every LDS address into base + immediate; the loop, the pointer
+//    advance and the rare rescale are inside the statement.  Stamps (benchmarks/attn_stamps_r64m.py): 2126 cycles per
+//    tile (r64p ~2400), MFMA-only ablation 2052; PMC: 45.8 M cycles, MFMA busy 88 % (r64p: 49.0 M, 82 %).
+//  * What the cycles buy is bounded by the POWER CAP: -6.4 % cycles came out as -1.9 % time (the clock fell from 1.51 to
+//    1.44 GHz); over all variants of this kernel, throughput ~ (MFMA duty)^0.44.
+// gen_attn_r64m.py holds the register plan, the schedule and the generator of attn_r64m_body.inc.
 // ================================================================================================
 #include "attn_r64m_body.inc"
 #ifdef DVD_LAB
@@ -1293,10 +1299,9 @@ __global__ void __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(R64M_CO
     }
   }
   // Rings.  Tile t reads K(t+1) from K slot (t+1) % 3, pre-reads K(t+2) from slot (t+2) % 3 and refills slot t % 3 with
-  // K(t+3); it reads V^T(t) from V slot t % 3 and refills slot (t+2) % 3 with V^T(t+2).  The statements come in six
-  // variants (t % 6): every LDS address in them is a loop-invariant base + an immediate, the DMA source pairs kg / vg
-  // are advanced by the compiler between the statements (no further once they reach the last tile, which is then simply
-  // re-loaded), so that between two tiles it has only that, `l += rs` and the out-of-line rare branch to emit.
+  // K(t+3); it reads V^T(t) from V slot t % 3 and refills slot (t+2) % 3 with V^T(t+2).  A tile comes in six variants
+  // (t % 6): every LDS address in them is a loop-invariant base + an immediate; the DMA source pairs start at kg / vg and
+  // advance inside the loop (no further once they reach the last tile, which is then simply re-loaded).
   unsigned koff[4], voff[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -1305,77 +1310,28 @@ __global__ void __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(R64M_CO
   }
   const char* kg = uniform_ptr(Kg + (size_t)min(3, nt - 1) * ktile);
   const char* vg = uniform_ptr(Vg + (size_t)min(2, nt - 1) * (KB * 2));
-  int tc = 0;
   const int klim = nt - 4, vlim = nt - 3;
   const unsigned kstep = (unsigned)ktile, vstep = KB * 2;
-  float rs0 = 0.f, rs1 = 0.f;
-  r64m_prologue_units(kaddr, p.c, sm[0].m, sm[1].m, rs0, rs1);       // units 0..7 of tile 0; the ring: K(1) fragments 0..2
-#define R64M_A_ARGS rs0, rs1, a0, a1, mask, kg, kaddr, vrel0, vrel1, koff, p.c, sm[0].m, sm[1].m, sm[0].thr, sm[1].thr, kdst
-#define R64M_B_ARGS rs0, rs1, vg, kaddr, vrel1, voff, p.c, sm[0].m, sm[1].m, vdst
-#ifdef DVD_LAB
-#define R64M_STEP(S, V, ARGS)                                         \
-  do {                                                                \
-    if constexpr (DBG == 0) r64m_##S##V(ARGS);                        \
-    else if constexpr (DBG == 1) r64m_##S##V##_noeu(ARGS);            \
-    else if constexpr (DBG == 2) r64m_##S##V##_nobar(ARGS);           \
-    else if constexpr (DBG == 3) r64m_##S##V##_mfmaonly_nobar(ARGS);          \
-    else r64m_##S##V##_mfmaonly(ARGS);                                \
-  } while (0)
-#else
-#define R64M_STEP(S, V, ARGS) r64m_##S##V(ARGS)
-#endif
-  // deferred rescale (rare): some lane saw its row's maximum over its 16 keys of tile t + 1 exceed m + THR.  O^T holds the
-  // tiles up to t's chunk 0 and l the row sums up to t, both at the old reference - and so does the packed chunk 1 of P(t),
-  // which enters O^T in phase 2b: all three are scaled.
-#define R64M_TILE(V)                                                                                   \
-  {                                                                                                    \
-    unsigned long long mask;                                                                           \
-    R64M_STEP(A, V, R64M_A_ARGS);                                                                      \
-    kg += tc < klim ? kstep : 0u;                                                                      \
-    sm[0].l += rs0;                                                                                    \
-    sm[1].l += rs1;                                                                                    \
-    rs0 = 0.f;                                                                                         \
-    rs1 = 0.f;                                                                                         \
-    if (__builtin_expect(mask != 0, 0)) {                                                              \
-      asm volatile("s_nop 15\n\ts_nop 7" ::: "memory"); /* the last PV MFMAs must have written O^T */  \
-      const float mloc[2] = {a0, a1};                                                                  \
-      _Pragma("unroll") for (int r_ = 0; r_ < 2; ++r_) {                                               \
-        const float mx = half_swap_max(mloc[r_] * p.c);                                                \
-        const float m_new = fmaxf(sm[r_].m, mx);                                                       \
-        const float alpha = __builtin_amdgcn_exp2f(sm[r_].m - m_new);                                  \
-        sm[r_].m = m_new;                                                                              \
-        sm[r_].thr = m_new + RESCALE_THR;                                                              \
-        sm[r_].l *= alpha;                                                                             \
-        if (r_ == 0) r64m_scale_o0(alpha);                                                             \
-        else r64m_scale_o1(alpha);                                                                     \
-        const half2v a2 = {(_Float16)alpha, (_Float16)alpha};                                          \
-        if (r_ == 0) r64m_scale_p0(__builtin_bit_cast(unsigned, a2));                              \
-        else r64m_scale_p1(__builtin_bit_cast(unsigned, a2));                                      \
-      }                                                                                                \
-    }                                                                                                  \
-    R64M_STEP(B, V, R64M_B_ARGS);                                                                      \
-    vg += tc < vlim ? vstep : 0u;                                                                      \
-    ++tc;                                                                                              \
-  }
+  float e0, e1;                          // side sums of a tile's early exp units (0..6), joined to l by the tile itself
+  r64m_prologue_units(kaddr, p.c, sm[0].m, sm[1].m, e0, e1);             // units 0..7 of tile 0; the ring: K(1) fragments 0..2
 #ifdef DVD_LAB
   if (p.stamps) ts[1] = __builtin_readcyclecounter();
 #endif
-  for (int t = 0; t < nt; t += 6) {         // nt is even
-    R64M_TILE(0) R64M_TILE(1)
-    if (t + 2 >= nt) break;
-    R64M_TILE(2) R64M_TILE(3)
-    if (t + 4 >= nt) break;
-    R64M_TILE(4) R64M_TILE(5)
-  }
-#undef R64M_TILE
-#undef R64M_STEP
+#define R64M_LOOP_ARGS sm[0].l, sm[1].l, sm[0].m, sm[1].m, sm[0].thr, sm[1].thr, e0, e1, kg, vg, nt, kaddr, vrel0, vrel1, koff, voff, p.c, \
+                       kdst, vdst, kstep, vstep, klim, vlim
+  // the whole key-tile loop, the rare rescale block and the drain: ONE statement (gen_attn_r64m.py)
+#ifdef DVD_LAB
+  if constexpr (DBG == 1) r64m_loop_noeu(R64M_LOOP_ARGS);
+  else if constexpr (DBG == 2) r64m_loop_nobar(R64M_LOOP_ARGS);
+  else if constexpr (DBG == 3) r64m_loop_mfmaonly_nobar(R64M_LOOP_ARGS);
+  else if constexpr (DBG == 4) r64m_loop_mfmaonly(R64M_LOOP_ARGS);
+  else
+#endif
+    r64m_loop(R64M_LOOP_ARGS);
+#undef R64M_LOOP_ARGS
 #ifdef DVD_LAB
   if (p.stamps) ts[2] = __builtin_readcyclecounter();
 #endif
-  // drain the LDS-DMA and the fragment reads still in flight (the last iterations re-load clamped tiles, and the last phase
-  // 2b formed the early units of a tile that does not exist - never added to l): LDS must not be written after the workgroup
-  // has ended; and the last PV MFMAs must have written O^T before the compiler's code reads it
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_nop 15\n\ts_nop 7" ::: "memory");
 
 #pragma unroll
   for (int rb = 0; rb < RB; ++rb) {
@@ -1429,7 +1385,7 @@ static constexpr int R64_MIN_TQ = 5376;
 extern "C" const char* dvd_flash_attn_kernel_name(int head_dim, int tq, int tk) {
   if (head_dim != 64 && head_dim != 256) return "";
   if (tk % 64 != 0) return head_dim == 256 ? "flash_attn_kernel<256>" : "flash_attn_kernel<64>";
-  if (head_dim == 256) return tq >= R64_MIN_TQ ? "flash_attn_r64p_kernel<0>" : "flash_attn_glds_kernel<256, 0>";
+  if (head_dim == 256) return tq >= R64_MIN_TQ ? "flash_attn_r64m_kernel<0>" : "flash_attn_glds_kernel<256, 0>";
   return "flash_attn_glds_kernel<64, 0>";
 }
 
@@ -1470,7 +1426,7 @@ extern "C" int dvd_flash_attn(const dvd_attn_desc* d, void* stream) {
   const bool first_on_device = attr_done.need(dev_bit);
   if (first_on_device) {
     allow_lds(flash_attn_glds_kernel<256, 0>, 2 * (64 * 512 + 256 * 128));
-    allow_lds(flash_attn_r64p_kernel<0>, r64p::LDS_BYTES);
+    allow_lds(flash_attn_r64m_kernel<0>, r64p::LDS_BYTES);
     allow_lds(flash_attn_kernel<256>, 2 * (64 * (2 * 256 + 16) + 256 * (2 * 64 + 16)));
     attr_done.done(dev_bit);
   }
@@ -1479,7 +1435,7 @@ extern "C" int dvd_flash_attn(const dvd_attn_desc* d, void* stream) {
   p.stamps = g_attn_stamps;
   const bool dbg = getenv("DVD_ATTN_DEBUG"), bulk = getenv("DVD_ATTN_BULK");
   if (getenv("DVD_ATTN_V1")) fast = false;
-  if (getenv("DVD_ATTN_R64") || getenv("DVD_ATTN_R64P") || getenv("DVD_ATTN_R64M") || getenv("DVD_ATTN_R64OLD")) r64 = d->head_dim == 256;
+  if (getenv("DVD_ATTN_R64") || getenv("DVD_ATTN_R64P") || getenv("DVD_ATTN_R64M_ABL") || getenv("DVD_ATTN_R64OLD")) r64 = d->head_dim == 256;
   if (getenv("DVD_ATTN_R32") || getenv("DVD_ATTN_PIPE") || bulk) r64 = false;
   if (first_on_device) {
     constexpr int LDS = 2 * (64 * 512 + 256 * 128);
@@ -1491,8 +1447,8 @@ extern "C" int dvd_flash_attn(const dvd_attn_desc* d, void* stream) {
     allow_lds(flash_attn_pipe_kernel<1>, LDS);
     allow_lds(flash_attn_r64_kernel<0>, 2 * (32 * 512 + 256 * 64));
     allow_lds(flash_attn_r64_kernel<1>, 2 * (32 * 512 + 256 * 64));
+    allow_lds(flash_attn_r64p_kernel<0>, r64p::LDS_BYTES);
     allow_lds(flash_attn_r64p_kernel<1>, r64p::LDS_BYTES);
-    allow_lds(flash_attn_r64m_kernel<0>, r64p::LDS_BYTES);
     allow_lds(flash_attn_r64m_kernel<1>, r64p::LDS_BYTES);
     allow_lds(flash_attn_r64m_kernel<2>, r64p::LDS_BYTES);
     allow_lds(flash_attn_r64m_kernel<3>, r64p::LDS_BYTES);
@@ -1504,18 +1460,26 @@ extern "C" int dvd_flash_attn(const dvd_attn_desc* d, void* stream) {
       flash_attn_dsplit_kernel<<<(unsigned)nwg, 512, LDS, st>>>(p);
       return check_launch("flash_attn(lab dsplit)");
     }
-    if (r64 && getenv("DVD_ATTN_R64M")) {     // r64p's schedule with hand-allocated registers, one exp unit per step
+    if (r64 && getenv("DVD_ATTN_R64M_ABL")) {
+      // TIMING ABLATIONS of the production kernel's loop (garbage results): 1 no exp units | 2 no barrier | 3 MFMAs only,
+      // no barrier | 4 MFMAs only
       p.nqb = cdiv(d->tq, 256);
       const unsigned g = (unsigned)((long)p.nqb * d->heads * d->batch);
-      // DVD_ATTN_R64M_ABL = 1..4: TIMING ABLATIONS (garbage results): no exp units | no barrier | MFMAs only, no barrier | MFMAs only
-      switch (getenv("DVD_ATTN_R64M_ABL") ? atoi(getenv("DVD_ATTN_R64M_ABL")) : 0) {
+      switch (atoi(getenv("DVD_ATTN_R64M_ABL"))) {
         case 1: flash_attn_r64m_kernel<1><<<g, 256, r64p::LDS_BYTES, st>>>(p); break;
         case 2: flash_attn_r64m_kernel<2><<<g, 256, r64p::LDS_BYTES, st>>>(p); break;
         case 3: flash_attn_r64m_kernel<3><<<g, 256, r64p::LDS_BYTES, st>>>(p); break;
         case 4: flash_attn_r64m_kernel<4><<<g, 256, r64p::LDS_BYTES, st>>>(p); break;
         default: flash_attn_r64m_kernel<0><<<g, 256, r64p::LDS_BYTES, st>>>(p);
       }
-      return check_launch("flash_attn(lab r64m)");
+      return check_launch("flash_attn(lab r64m ablation)");
+    }
+    if (r64 && getenv("DVD_ATTN_R64P")) {     // round 4's first step (compiler-allocated registers), with or without stamps
+      p.nqb = cdiv(d->tq, 256);
+      const unsigned g = (unsigned)((long)p.nqb * d->heads * d->batch);
+      if (dbg) flash_attn_r64p_kernel<1><<<g, 256, r64p::LDS_BYTES, st>>>(p);
+      else flash_attn_r64p_kernel<0><<<g, 256, r64p::LDS_BYTES, st>>>(p);
+      return check_launch("flash_attn(lab r64p)");
     }
     if (r64 && getenv("DVD_ATTN_R64OLD")) {   // rounds 1-3's production kernel (lab include), with or without its stamps
       p.nqb = cdiv(d->tq, 256);
@@ -1523,11 +1487,6 @@ extern "C" int dvd_flash_attn(const dvd_attn_desc* d, void* stream) {
       if (dbg) flash_attn_r64_kernel<1><<<g, 256, 2 * (32 * 512 + 256 * 64), st>>>(p);
       else flash_attn_r64_kernel<0><<<g, 256, 2 * (32 * 512 + 256 * 64), st>>>(p);
       return check_launch("flash_attn(lab r64 old)");
-    }
-    if (r64 && dbg) {                         // the production kernel with its s_memtime stamps
-      p.nqb = cdiv(d->tq, 256);
-      flash_attn_r64p_kernel<1><<<(unsigned)((long)p.nqb * d->heads * d->batch), 256, r64p::LDS_BYTES, st>>>(p);
-      return check_launch("flash_attn(lab r64p stamps)");
     }
     if (!r64 && getenv("DVD_ATTN_PIPE")) {   // slower (830 vs 975 TF/s): see the kernel's header
       if (dbg) flash_attn_pipe_kernel<1><<<(unsigned)nwg, 256, LDS, st>>>(p);
@@ -1557,7 +1516,7 @@ extern "C" int dvd_flash_attn(const dvd_attn_desc* d, void* stream) {
   // ---- product dispatch: four kernels, chosen by (head_dim, tq, tk) ----
   if (fast && r64) {
     p.nqb = cdiv(d->tq, 256);
-    flash_attn_r64p_kernel<0><<<(unsigned)((long)p.nqb * d->heads * d->batch), 256, r64p::LDS_BYTES, st>>>(p);
+    flash_attn_r64m_kernel<0><<<(unsigned)((long)p.nqb * d->heads * d->batch), 256, r64p::LDS_BYTES, st>>>(p);
   } else if (fast && d->head_dim == 256) {
     flash_attn_glds_kernel<256, 0><<<(unsigned)nwg, 256, 2 * (64 * 512 + 256 * 128), st>>>(p);
   } else if (fast) {

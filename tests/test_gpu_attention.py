@@ -69,8 +69,8 @@ def test_attention_fused_qkv_views(ops):
 
 
 VARIANTS = {
-    "r64p (64 query rows per wave, software-pipelined across key tiles; the default at production sizes)": {"DVD_ATTN_R64": "1"},
-    "r64m (hand-allocated registers, one exp unit per fragment step)": {"DVD_ATTN_R64M": "1"},
+    "r64m (64 query rows per wave, pipelined across key tiles, generated loop; the default at production sizes)": {"DVD_ATTN_R64": "1"},
+    "r64p (round 4's first step: compiler-allocated registers; superseded)": {"DVD_ATTN_R64P": "1"},
     "r64 of rounds 1-3 (superseded, lab include)": {"DVD_ATTN_R64OLD": "1"},
     "r32 (flash_attn_glds_kernel)": {"DVD_ATTN_R32": "1"},
     "bulk LDS-DMA issue": {"DVD_ATTN_BULK": "1"},
