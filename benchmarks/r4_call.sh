@@ -1,4 +1,3 @@
 #!/bin/bash
 mkdir -p gpurun_out/r4
-timeout 1500 python -m pytest tests -m gpu -q -x 2>&1 | tail -8 | tee gpurun_out/r4/c26_gpu_tests.txt
-timeout 900 python bench.py --steps 1 --warmup 1 2>gpurun_out/r4/c26_bench.err | tee gpurun_out/r4/c26_bench.json
+timeout 600 python benchmarks/attn_ab.py 16 5 256 "r64m=" "noeu=DVD_ATTN_R64M_ABL:5" "nodma=DVD_ATTN_R64M_ABL:6" "noread=DVD_ATTN_R64M_ABL:7" "mfmaonly=DVD_ATTN_R64M_ABL:4" "nobar=DVD_ATTN_R64M_ABL:2" 2>&1 | grep -v "max |" | tail -7 | tee gpurun_out/r4/c28_ab.txt

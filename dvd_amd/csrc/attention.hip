@@ -1321,10 +1321,13 @@ __global__ void __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(R64M_CO
                        kdst, vdst, kstep, vstep, klim, vlim
   // the whole key-tile loop, the rare rescale block and the drain: ONE statement (gen_attn_r64m.py)
 #ifdef DVD_LAB
-  if constexpr (DBG == 1) r64m_loop_noeu(R64M_LOOP_ARGS);
+  if constexpr (DBG == 1) r64m_loop_m16(R64M_LOOP_ARGS);
   else if constexpr (DBG == 2) r64m_loop_nobar(R64M_LOOP_ARGS);
   else if constexpr (DBG == 3) r64m_loop_mfmaonly_nobar(R64M_LOOP_ARGS);
   else if constexpr (DBG == 4) r64m_loop_mfmaonly(R64M_LOOP_ARGS);
+  else if constexpr (DBG == 5) r64m_loop_noeu(R64M_LOOP_ARGS);
+  else if constexpr (DBG == 6) r64m_loop_nodma(R64M_LOOP_ARGS);
+  else if constexpr (DBG == 7) r64m_loop_noread(R64M_LOOP_ARGS);
   else
 #endif
     r64m_loop(R64M_LOOP_ARGS);
@@ -1453,6 +1456,9 @@ extern "C" int dvd_flash_attn(const dvd_attn_desc* d, void* stream) {
     allow_lds(flash_attn_r64m_kernel<2>, r64p::LDS_BYTES);
     allow_lds(flash_attn_r64m_kernel<3>, r64p::LDS_BYTES);
     allow_lds(flash_attn_r64m_kernel<4>, r64p::LDS_BYTES);
+    allow_lds(flash_attn_r64m_kernel<5>, r64p::LDS_BYTES);
+    allow_lds(flash_attn_r64m_kernel<6>, r64p::LDS_BYTES);
+    allow_lds(flash_attn_r64m_kernel<7>, r64p::LDS_BYTES);
   }
   if (fast && d->head_dim == 256) {
     constexpr int LDS = 2 * (64 * 512 + 256 * 128);
@@ -1461,8 +1467,8 @@ extern "C" int dvd_flash_attn(const dvd_attn_desc* d, void* stream) {
       return check_launch("flash_attn(lab dsplit)");
     }
     if (r64 && getenv("DVD_ATTN_R64M_ABL")) {
-      // TIMING ABLATIONS of the production kernel's loop (garbage results): 1 no exp units | 2 no barrier | 3 MFMAs only,
-      // no barrier | 4 MFMAs only
+      // TIMING ABLATIONS of the production kernel's loop (garbage results): 1 16x16x32 MFMAs, same FLOPs (power) | 2 no barrier | 3 MFMAs only,
+      // no barrier | 4 MFMAs only | 5 no softmax VALU | 6 no LDS-DMA | 7 no fragment reads
       p.nqb = cdiv(d->tq, 256);
       const unsigned g = (unsigned)((long)p.nqb * d->heads * d->batch);
       switch (atoi(getenv("DVD_ATTN_R64M_ABL"))) {
@@ -1470,6 +1476,9 @@ extern "C" int dvd_flash_attn(const dvd_attn_desc* d, void* stream) {
         case 2: flash_attn_r64m_kernel<2><<<g, 256, r64p::LDS_BYTES, st>>>(p); break;
         case 3: flash_attn_r64m_kernel<3><<<g, 256, r64p::LDS_BYTES, st>>>(p); break;
         case 4: flash_attn_r64m_kernel<4><<<g, 256, r64p::LDS_BYTES, st>>>(p); break;
+        case 5: flash_attn_r64m_kernel<5><<<g, 256, r64p::LDS_BYTES, st>>>(p); break;
+        case 6: flash_attn_r64m_kernel<6><<<g, 256, r64p::LDS_BYTES, st>>>(p); break;
+        case 7: flash_attn_r64m_kernel<7><<<g, 256, r64p::LDS_BYTES, st>>>(p); break;
         default: flash_attn_r64m_kernel<0><<<g, 256, r64p::LDS_BYTES, st>>>(p);
       }
       return check_launch("flash_attn(lab r64m ablation)");
