@@ -594,7 +594,10 @@ __global__ void __launch_bounds__(256, (D == 256 ? 1 : DVD_ATTN64_OCC)) flash_at
     }
     float rs = 0.f;
     half8 pf[4];
-    // chunk c of P = registers 8 (c & 1) .. +7 of s[c >> 1]
+    // chunk c of P = registers 8 (c & 1) .. +7 of s[c >> 1].  Row sums stay one v_add_f32 per element: 16 v_dot2c_f32_f16 on the
+    // packed words instead of the 32 adds (17 fewer VALU instructions per tile) measured 1.4 % SLOWER at head_dim 64 (10.447 vs
+    // 10.304 ms, round 4), 16 v_pk_add_f32 on pairs of exponentials 2.3 % slower (10.342 vs 10.108 ms): at 1.45 GHz the kernel is held
+    // by the power cap, not by its instruction count (benchmarks/lab/valu_lab.hip: two waves per SIMD issue VALU work concurrently).
 #define PEXP(c_, e_)                                                                             \
   {                                                                                              \
     const float sv_ = s[(c_) >> 1][8 * ((c_) & 1) + (e_)];                                       \
