@@ -1369,6 +1369,183 @@ __global__ void __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(R64M_CO
 #endif
 }
 
+
+// ================================================================================================
+// r64x = r64m on v_mfma_f32_16x16x32_f16 (round 4, third step).  Same pipeline, rings, DMA and register
+// ownership; what changes with the MFMA shape - the fragment maps, the key order inside a tile, the K / V^T LDS images,
+// the softmax in P-key order with packed-f32 arguments and dot2 row sums, four query blocks of 16 rows per wave instead of
+// two of 32 - is described in gen_attn_r64x.py, which generates attn_r64x_body.inc.
+// ================================================================================================
+#include "attn_r64x_body.inc"
+#ifdef DVD_LAB
+#include "../../benchmarks/lab/csrc/attn_r64x_abl.inc"
+#endif
+
+template <int QB_>
+__device__ __forceinline__ void r64x_store_rows(_Float16* op, float inv) {      // op: the lane's query row of block QB_, + 4 g dims
+#pragma unroll
+  for (int d4 = 0; d4 < 4; ++d4) {
+    floatx16 x;
+    if (d4 == 0) x = r64m_read_o<64 * QB_ + 0>();
+    else if (d4 == 1) x = r64m_read_o<64 * QB_ + 16>();
+    else if (d4 == 2) x = r64m_read_o<64 * QB_ + 32>();
+    else x = r64m_read_o<64 * QB_ + 48>();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {                      // dims 16 (4 d4 + k) + 4 g .. + 3
+      half4 v;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = (_Float16)(x[4 * k + j] * inv);
+      *(half4*)(op + 16 * (4 * d4 + k)) = v;
+    }
+  }
+}
+
+template <int DBG>
+__global__ void __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(R64X_COMPILER_VGPRS))) flash_attn_r64x_kernel(AttnArgs p) {
+  using namespace r64p;
+  constexpr int D = 256, KB = 32;
+#ifdef DVD_LAB
+  unsigned long long ts[4] = {0, 0, 0, 0};
+  if (p.stamps) ts[0] = __builtin_readcyclecounter();
+#endif
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [K0 | K1 | K2 | V0 | V1 | V2]
+  typedef __attribute__((address_space(3))) void* lptr_t;
+
+  const int nwg = gridDim.x;
+  int id = blockIdx.x;
+  {
+    const int q = nwg / 8, rr = nwg % 8, xcd = id % 8, k = id / 8;
+    id = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + k;
+  }
+  const int qb = id % p.nqb;          // 256-row query blocks
+  const int bh = id / p.nqb;
+  const int head = bh % p.heads, b = bh / p.heads;
+  const int kvb = b / p.kv_div;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c16 = lane & 15, g = lane >> 4;
+
+  const _Float16* Qg = p.Q + b * p.sQ + (size_t)head * D;
+  const char* Kg = (const char*)(p.K + kvb * p.sK + (size_t)head * D);
+  const char* Vg = (const char*)(p.Vt + kvb * p.sVt + (size_t)head * D * p.ldvt);
+
+  {
+    const int qrow = qb * 256 + wave * 64 + c16;
+    const unsigned rowb = (unsigned)(p.ldq * 2);
+    const unsigned q0 = (unsigned)min(qrow, p.tq - 1) * rowb + 16 * g, q1 = (unsigned)min(qrow + 16, p.tq - 1) * rowb + 16 * g;
+    const unsigned q2 = (unsigned)min(qrow + 32, p.tq - 1) * rowb + 16 * g, q3 = (unsigned)min(qrow + 48, p.tq - 1) * rowb + 16 * g;
+    r64x_load_q((const _Float16*)uniform_ptr((const char*)Qg), q0, q1, q2, q3);
+  }
+  // LDS-DMA sources.  K: the wave's four 1-KiB pieces are the A-rows 8 w .. 8 w + 7 of the tile = natural keys
+  // 16 (w & 1) + 4 (w >> 1) + {0, 2, 8, 10} (+ lane >> 5); chunks of the odd row XOR 1 (r64p's piece image).
+  // V^T: 16 dim rows per piece, chunk swizzle (-(row >> 2)) & 3.
+  unsigned koff[4], voff[4];
+  {
+    const unsigned krow0 = 16 * (wave & 1) + 4 * (wave >> 1) + (lane >> 5);
+    const unsigned kchunk = (unsigned)(((lane & 31) ^ (lane >> 5)) * 16);
+    const unsigned kadd[4] = {0, 2, 8, 10};
+    const unsigned vchunk = (unsigned)(((lane & 3) ^ ((0u - (unsigned)(lane >> 4)) & 3)) * 16);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      koff[j] = (krow0 + kadd[j]) * (unsigned)(p.ldk * 2) + kchunk;
+      voff[j] = (unsigned)(64 * wave + 16 * j + (lane >> 2)) * (unsigned)(p.ldvt * 2) + vchunk;
+    }
+  }
+  const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t)smem;
+  // fragment reads: K A-row c16 of key block kb2 = LDS row 16 kb2 + c16 (+ imm: slot, kb2, ks); V^T dim row 16 db + c16
+  const unsigned kaddr = lds0 + (c16 >> 1) * KPIECE + (c16 & 1) * 512 + ((g ^ (c16 & 1)) * 16);
+  const unsigned vrel = lds0 + VBASE + c16 * 64 + ((g ^ ((0u - (unsigned)(c16 >> 2)) & 3)) * 16);
+
+  r64m_zero_o();
+  const int nt = p.tk / KB;              // even (tk % 64 == 0)
+  const size_t ktile = (size_t)KB * p.ldk * 2;
+  const unsigned kdst = lds0 + (4 * wave) * KPIECE, vdst = lds0 + VBASE + (4 * wave) * 1024;
+
+  // ---- prologue: K(0), K(1), K(2) -> K slots 0, 1, 2; V(0), V(1) -> V slots 0, 1
+  {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const char* kj = Kg + (size_t)min(j, nt - 1) * ktile;
+      const char* vj = Vg + (size_t)min(j, nt - 1) * (KB * 2);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        glds_piece(kj, koff[i], kdst + j * KBYTES + i * KPIECE);
+        if (j < 2) glds_piece(vj, voff[i], vdst + j * VBYTES + i * 1024);
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+
+  float a[4];
+  r64x_prologue_s0(kaddr, a[0], a[1], a[2], a[3]);                      // S^T(0) -> buffer A; lane-local maxima
+  asm volatile("s_barrier" ::: "memory");                                // every wave has read K(0) before K slot 0 is refilled
+  float m[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {                                           // a query's 32 keys live in lanes c16 + 16 g, g = 0..3
+    float x = a[q] * p.c;
+    x = fmaxf(x, __shfl_xor(x, 16));
+    x = fmaxf(x, __shfl_xor(x, 32));
+    m[q] = x;
+  }
+  const char* kg = uniform_ptr(Kg + (size_t)min(3, nt - 1) * ktile);
+  const char* vg = uniform_ptr(Vg + (size_t)min(2, nt - 1) * (KB * 2));
+  const int klim = nt - 4, vlim = nt - 3;
+  const unsigned kstep = (unsigned)ktile, vstep = KB * 2;
+  r64x_prologue_units(kaddr, p.c, m[0], m[1], m[2], m[3]);              // m -> v[28:31]; tile 0: arguments, exp units 0..15
+  float l[4] = {0.f, 0.f, 0.f, 0.f};
+#ifdef DVD_LAB
+  if (p.stamps) ts[1] = __builtin_readcyclecounter();
+#endif
+#define R64X_LOOP_ARGS l[0], l[1], l[2], l[3], kg, vg, nt, kaddr, vrel, koff, voff, p.c, kdst, vdst, kstep, vstep, klim, vlim
+#ifdef DVD_LAB
+  if constexpr (DBG == 1) r64x_loop_novalu(R64X_LOOP_ARGS);
+  else if constexpr (DBG == 2) r64x_loop_nobar(R64X_LOOP_ARGS);
+  else if constexpr (DBG == 3) r64x_loop_mfmaonly(R64X_LOOP_ARGS);
+  else
+#endif
+    r64x_loop(R64X_LOOP_ARGS);
+#undef R64X_LOOP_ARGS
+#ifdef DVD_LAB
+  if (p.stamps) ts[2] = __builtin_readcyclecounter();
+#endif
+
+  // the lane index is recomputed (mbcnt) so that nothing per-lane has to stay live across the loop: with 28 VGPRs the compiler
+  // otherwise parks such values in AGPRs - which belong to the statements (tests/test_abi.py checks the ISA for exactly that)
+  const int lane_e = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+  const int c16e = lane_e & 15, ge = lane_e >> 4;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    float lt = l[q];
+    lt += __shfl_xor(lt, 16);
+    lt += __shfl_xor(lt, 32);
+    const float inv = 1.f / lt;
+    const int qglob = qb * 256 + wave * 64 + 16 * q + c16e;
+    if (qglob < p.tq) {
+      _Float16* op = p.O + b * p.sO + (size_t)qglob * p.ldo + (size_t)head * D + 4 * ge;
+      if (q == 0) r64x_store_rows<0>(op, inv);
+      else if (q == 1) r64x_store_rows<1>(op, inv);
+      else if (q == 2) r64x_store_rows<2>(op, inv);
+      else r64x_store_rows<3>(op, inv);
+    }
+  }
+#ifdef DVD_LAB
+  if (p.stamps) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    ts[3] = __builtin_readcyclecounter();
+    if (lane == 0) {
+      unsigned long long* o_ = p.stamps + ((size_t)blockIdx.x * 4 + wave) * 6;
+      o_[0] = ts[1] - ts[0];
+      o_[1] = ts[2] - ts[1];
+      o_[2] = ts[3] - ts[2];
+      o_[3] = ts[0];
+      o_[4] = ts[3];
+      o_[5] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) |
+              ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | 20) << 32);
+    }
+  }
+#endif
+}
+
 #ifdef DVD_LAB
 #include "../../benchmarks/lab/csrc/attention_lab.inc"
 #endif
@@ -1441,7 +1618,9 @@ extern "C" int dvd_flash_attn(const dvd_attn_desc* d, void* stream) {
   p.stamps = g_attn_stamps;
   const bool dbg = getenv("DVD_ATTN_DEBUG"), bulk = getenv("DVD_ATTN_BULK");
   if (getenv("DVD_ATTN_V1")) fast = false;
-  if (getenv("DVD_ATTN_R64") || getenv("DVD_ATTN_R64P") || getenv("DVD_ATTN_R64M_ABL") || getenv("DVD_ATTN_R64OLD")) r64 = d->head_dim == 256;
+  if (getenv("DVD_ATTN_R64") || getenv("DVD_ATTN_R64P") || getenv("DVD_ATTN_R64M_ABL") || getenv("DVD_ATTN_R64X") ||
+      getenv("DVD_ATTN_R64OLD"))
+    r64 = d->head_dim == 256;
   if (getenv("DVD_ATTN_R32") || getenv("DVD_ATTN_PIPE") || bulk) r64 = false;
   if (first_on_device) {
     constexpr int LDS = 2 * (64 * 512 + 256 * 128);
@@ -1455,6 +1634,10 @@ extern "C" int dvd_flash_attn(const dvd_attn_desc* d, void* stream) {
     allow_lds(flash_attn_r64_kernel<1>, 2 * (32 * 512 + 256 * 64));
     allow_lds(flash_attn_r64p_kernel<0>, r64p::LDS_BYTES);
     allow_lds(flash_attn_r64p_kernel<1>, r64p::LDS_BYTES);
+    allow_lds(flash_attn_r64x_kernel<0>, r64p::LDS_BYTES);
+    allow_lds(flash_attn_r64x_kernel<1>, r64p::LDS_BYTES);
+    allow_lds(flash_attn_r64x_kernel<2>, r64p::LDS_BYTES);
+    allow_lds(flash_attn_r64x_kernel<3>, r64p::LDS_BYTES);
     allow_lds(flash_attn_r64m_kernel<1>, r64p::LDS_BYTES);
     allow_lds(flash_attn_r64m_kernel<2>, r64p::LDS_BYTES);
     allow_lds(flash_attn_r64m_kernel<3>, r64p::LDS_BYTES);
@@ -1468,6 +1651,17 @@ extern "C" int dvd_flash_attn(const dvd_attn_desc* d, void* stream) {
     if (getenv("DVD_ATTN_DSPLIT")) {   // measured slower (732 vs 812 TF/s)
       flash_attn_dsplit_kernel<<<(unsigned)nwg, 512, LDS, st>>>(p);
       return check_launch("flash_attn(lab dsplit)");
+    }
+    if (r64 && getenv("DVD_ATTN_R64X")) {     // the 16x16x32-MFMA sibling of the production kernel; DVD_ATTN_R64X_ABL: timing ablations
+      p.nqb = cdiv(d->tq, 256);
+      const unsigned g = (unsigned)((long)p.nqb * d->heads * d->batch);
+      switch (getenv("DVD_ATTN_R64X_ABL") ? atoi(getenv("DVD_ATTN_R64X_ABL")) : 0) {
+        case 1: flash_attn_r64x_kernel<1><<<g, 256, r64p::LDS_BYTES, st>>>(p); break;
+        case 2: flash_attn_r64x_kernel<2><<<g, 256, r64p::LDS_BYTES, st>>>(p); break;
+        case 3: flash_attn_r64x_kernel<3><<<g, 256, r64p::LDS_BYTES, st>>>(p); break;
+        default: flash_attn_r64x_kernel<0><<<g, 256, r64p::LDS_BYTES, st>>>(p);
+      }
+      return check_launch("flash_attn(lab r64x)");
     }
     if (r64 && getenv("DVD_ATTN_R64M_ABL")) {
       // TIMING ABLATIONS of the production kernel's loop (garbage results): 1 16x16x32 MFMAs, same FLOPs (power) | 2 no barrier | 3 MFMAs only,

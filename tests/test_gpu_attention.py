@@ -71,6 +71,7 @@ def test_attention_fused_qkv_views(ops):
 VARIANTS = {
     "r64m (64 query rows per wave, pipelined across key tiles, generated loop; the default at production sizes)": {"DVD_ATTN_R64": "1"},
     "r64p (round 4's first step: compiler-allocated registers; superseded)": {"DVD_ATTN_R64P": "1"},
+    "r64x (the production kernel's sibling on the 16x16x32 MFMA shape)": {"DVD_ATTN_R64X": "1"},
     "r64 of rounds 1-3 (superseded, lab include)": {"DVD_ATTN_R64OLD": "1"},
     "r32 (flash_attn_glds_kernel)": {"DVD_ATTN_R32": "1"},
     "bulk LDS-DMA issue": {"DVD_ATTN_BULK": "1"},

@@ -2,14 +2,14 @@
 """Checks the contract between flash_attn_r64m_kernel and the compiler on the kernel's ISA (hipcc -S): outside the
 `asm volatile` statements (;;#ASMSTART .. ;;#ASMEND) no instruction of the kernel may name a VGPR above v31 or any AGPR -
 those belong to the hand-allocated statements (dvd_amd/csrc/gen_attn_r64m.py) - and the kernel uses no scratch.
-usage: check_r64m_isa.py <file.s>   (exit 0 = holds; prints the offending lines otherwise)"""
+usage: check_r64m_isa.py <file.s> [<compiler vgprs> <kernel name>]   (exit 0 = holds; prints the offending lines otherwise)"""
 import re
 import sys
 
 
-def check(text, compiler_vgprs=32):
+def check(text, compiler_vgprs=32, kernel="flash_attn_r64m_kernel"):
     bad, kernels = [], 0
-    for m in re.finditer(r"^(_ZN3dvd22flash_attn_r64m_kernel\w+):[^\n]*\n(.*?)s_endpgm", text, re.S | re.M):
+    for m in re.finditer(r"^(_ZN3dvd\d+" + kernel + r"\w+):[^\n]*\n(.*?)s_endpgm", text, re.S | re.M):
         kernels += 1
         inside = False
         for ln in m.group(2).split("\n"):
@@ -33,7 +33,7 @@ def check(text, compiler_vgprs=32):
 
 
 if __name__ == "__main__":
-    k, bad = check(open(sys.argv[1]).read())
+    k, bad = check(open(sys.argv[1]).read(), *([int(sys.argv[2]), sys.argv[3]] if len(sys.argv) > 3 else []))
     for name, ln in bad[:40]:
         print(f"{name}: {ln}")
     print(f"{k} kernel(s) checked, {len(bad)} violation(s)")
