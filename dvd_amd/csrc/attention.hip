@@ -501,6 +501,10 @@ __global__ void __launch_bounds__(256, (D == 256 ? 1 : DVD_ATTN64_OCC)) flash_at
   // BULK (DBG 2/3, DVD_ATTN_BULK=1): the burst at the top of the tile, kept for A/B runs.
   constexpr bool SPREAD = (DBG < 2);
   constexpr bool STAMPS = (DBG & 1);
+  // (Round 4 tried the loop unrolled by the LDS buffer - every LDS address base + immediate, the next tile's pointers advanced
+  // by an add, 34 -> ~15 SALU and no v_add_u32 per tile, same bits - after the decoder kernel's ablations had shown what such
+  // glue costs ITS single wave per SIMD: head_dim 64, two waves per SIMD, measured 11.36 vs 11.23 ms, i.e. slightly slower, like
+  // the v_dot2 / v_pk_add row sums.  This kernel runs at 1.45 GHz under the power cap; removing issue work does not speed it up.)
   for (int t = 0; t < nt; ++t) {
     if constexpr (!SPREAD) {
       if (t + 1 < nt) DVD_GLDS_ISSUE(t + 1, cur ^ 1)
