@@ -95,9 +95,21 @@ def test_attention_kernel_variants(ops, lab, monkeypatch, variant, hd, scale):
     assert err < 3e-3 * max(1.0, mag), (variant, err, mag)
 
 
+@pytest.mark.parametrize("tk", [64, 128, 192, 256, 320, 448])
+@pytest.mark.parametrize("switch", ["DVD_ATTN_R64", "DVD_ATTN_R64X"])
+def test_generated_loops_at_every_exit(ops, lab, monkeypatch, switch, tk):
+    """The generated key-tile loops (six tile variants per trip, exits after the 2nd, 4th and 6th) at 2, 4, 6, 8, 10 and 14
+    key tiles: every exit, the first trip's and a later trip's; fewer tiles than the K / V^T rings are deep (the LDS-DMA
+    pointers then stay on the last tile)."""
+    monkeypatch.setenv(switch, "1")
+    err, mag = run(ops, 2, 2, 300, tk, 6, 256, 0.0625)
+    assert err < 2e-3 * max(1.0, mag), (switch, tk, err, mag)
+
+
 PRODUCT_SHAPES = {
     # the product library picks its kernel from (head_dim, tq, tk) alone - never from the batch, never from the environment
     "hd256 r64 (tq >= 5376, ragged tq)": (256, 0.0625, 5500, 512),
+    "hd256 r64, two key tiles": (256, 0.0625, 5500, 64),
     "hd256 glds (tq < 5376)": (256, 0.0625, 1024, 512),
     "hd256 register-staged (tk % 64 != 0)": (256, 0.0625, 300, 1000),
     "hd64 glds": (64, 0.125, 5500, 512),
