@@ -1,4 +1,5 @@
 #!/bin/bash
 mkdir -p gpurun_out/r4
-(timeout 600 python -m pytest tests/test_gpu_tokens.py -q -x -k dwconv 2>&1 | tail -3
-timeout 300 python benchmarks/dwconv_bench.py 2>&1 | grep -v amdgpu.ids) | tee gpurun_out/r4/c42_dwconv.txt
+(timeout 300 python benchmarks/attn_ab.py 16 7 256 "r64m=" "r64x=DVD_ATTN_R64X" 2>&1 | tail -3
+export NOSTATS=1
+bash benchmarks/pmc_attn_ab.sh "r64m=" "r64x=DVD_ATTN_R64X") 2>&1 | tee gpurun_out/r4/c45_x_vs_m.txt

@@ -7,9 +7,8 @@ Why the other MFMA shape: every MFMA kernel of the step runs against the board's
 clock on v_mfma_f32_16x16x32_f16 than on 32x32x16 for the same FLOPs (benchmarks/lab/shape_lab.hip: +17 % in bare loops;
 priced inside r64m by an ablation that issues two 16x16x32 for every 32x32x16: 1.90 instead of 1.50 GHz, but 57.0 M
 instead of 45.8 M cycles, because one wave per SIMD has to ISSUE 128 instead of 64 MFMAs per tile beside ~1600 issue-cycles
-of other instructions).  So this kernel also cuts the other instructions: packed-f32 softmax argument (16 v_pk_fma_f32
-instead of 32 v_fma_f32), row sums as one v_dot2c_f32_f16 per packed P word (16 instead of 32 v_add_f32; they sum the
-ROUNDED values the PV product uses), no threshold registers.
+of other instructions).  So this kernel also cuts the other instructions: packed-f32 softmax argument for the even query
+blocks, no threshold registers, no side sums.  (Row sums by v_dot2c_f32_f16 on the packed words were tried: see sum_word.)
 
 Fragment maps (v_mfma_f32_16x16x32_f16; lane l: c = l & 15, g = l >> 4):
   A / B operand  row (A) or column (B) c of the 16-wide tile, k = 8 g .. 8 g + 7        (4 VGPRs = 8 halves)
@@ -130,8 +129,17 @@ def cvt_word(buf, w):
     return f"v_cvt_pk_f16_f32 v{P0 + w}, v{SBUF[buf] + 2 * w}, v{SBUF[buf] + 2 * w + 1}"
 
 
-def sum_word(w):
-    return f"v_dot2c_f32_f16 %[l{w >> 2}], {ONES_F16X2}, v{P0 + w}"
+SUM_BY_DOT2 = os.environ.get("R64X_SUM_BY_DOT2") == "1"    # experiment switch of the generator (not a product option)
+
+
+def sum_word(w, buf):
+    """row sum of the two exponentials of word w.  Two v_add_f32 on the f32 values: one v_dot2c_f32_f16 on the packed word
+    (with the literal (1, 1)) measured ~20 issue cycles where an add costs 5 - 2711 instead of 2460 cycles per tile here, and
+    the same 300 cycles in r64m when its row sums were moved to dot2 (round 4)."""
+    if SUM_BY_DOT2:
+        return f"v_dot2c_f32_f16 %[l{w >> 2}], {ONES_F16X2}, v{P0 + w}"
+    return (f"v_add_f32_e32 %[l{w >> 2}], %[l{w >> 2}], v{SBUF[buf] + 2 * w}\\n\\t"
+            f"v_add_f32_e32 %[l{w >> 2}], %[l{w >> 2}], v{SBUF[buf] + 2 * w + 1}")
 
 
 def max_chain(buf):
@@ -207,7 +215,7 @@ def tile(s, var):
     for f in range(16):
         gaps[4 * f + 0].append(exp_unit(cur, 16 + f))
         gaps[4 * f + 1].append(cvt_word(cur, f))          # words 8..15 follow their second exponential by >= one MFMA
-        gaps[4 * f + 3].append(sum_word(f))
+        gaps[4 * f + 3].append(sum_word(f, cur))
     for f in range(16):
         n, ks, kb2 = f, f >> 1, f & 1
         s.add("s_waitcnt lgkmcnt(2)")
