@@ -7,8 +7,8 @@ Why the other MFMA shape: every MFMA kernel of the step runs against the board's
 clock on v_mfma_f32_16x16x32_f16 than on 32x32x16 for the same FLOPs (benchmarks/lab/shape_lab.hip: +17 % in bare loops;
 priced inside r64m by an ablation that issues two 16x16x32 for every 32x32x16: 1.90 instead of 1.50 GHz, but 57.0 M
 instead of 45.8 M cycles, because one wave per SIMD has to ISSUE 128 instead of 64 MFMAs per tile beside ~1600 issue-cycles
-of other instructions).  So this kernel also cuts the other instructions: packed-f32 softmax argument for the even query
-blocks, no threshold registers, no side sums.  (Row sums by v_dot2c_f32_f16 on the packed words were tried: see sum_word.)
+of other instructions).  So this kernel also cuts the other instructions: no threshold registers, no side sums - but NOT by
+packed-f32 or DOT instructions, which serialise with the matrix pipe (see pk_arg, sum_word).
 
 Fragment maps (v_mfma_f32_16x16x32_f16; lane l: c = l & 15, g = l >> 4):
   A / B operand  row (A) or column (B) c of the 16-wide tile, k = 8 g .. 8 g + 7        (4 VGPRs = 8 halves)
@@ -112,13 +112,14 @@ class Stmt:
 # ---- VALU items (strings; "valu" ablation drops them all, the test then never fires) ----
 def pk_arg(buf, k):
     """s * c - m for elements 2k, 2k + 1 of the tile in `buf` (query block k >> 2), in place -> list of instructions.
-    Even query blocks: one v_pk_fma_f32 with m broadcast from the LOW register of its pair (op_sel_hi 0).  Odd ones: two
-    v_fma_f32 - selecting the HIGH register of a pair for both halves (op_sel 1) gave wrong results on gfx950 for src2 of
-    v_pk_fma_f32 (round 4: rows of the odd query blocks were off while the even ones matched)."""
+    Two v_fma_f32, NOT one v_pk_fma_f32: packed-f32 and DOT instructions do not overlap with the matrix pipe on gfx950
+    (benchmarks/lab/opsel_lab.hip: MFMA 16x16x32 + v_fma_f32 = 17 cycles per pair, + v_pk_fma_f32 / v_pk_add_f32 /
+    v_dot2c_f32_f16 = 34), so a packed instruction costs three times what the two scalar ones cost beside MFMAs."""
     x, q = SBUF[buf] + 2 * k, k >> 2
-    if q & 1:
-        return [f"v_fma_f32 v{x + i}, v{x + i}, s{S_C}, -v{MREG + q}" for i in range(2)]
-    return [f"v_pk_fma_f32 {vr(x, 2)}, {vr(x, 2)}, s[{S_C}:{S_C + 1}], {vr(MREG + q, 2)} op_sel_hi:[1,1,0] neg_lo:[0,0,1] neg_hi:[0,0,1]"]
+    if PK_ARGS:       # experiment switch (even query blocks only: the odd ones, m in the high register of its pair, came out wrong)
+        if not q & 1:
+            return [f"v_pk_fma_f32 {vr(x, 2)}, {vr(x, 2)}, s[{S_C}:{S_C + 1}], {vr(MREG + q, 2)} op_sel_hi:[1,1,0] neg_lo:[0,0,1] neg_hi:[0,0,1]"]
+    return [f"v_fma_f32 v{x + i}, v{x + i}, s{S_C}, -v{MREG + q}" for i in range(2)]
 
 
 def exp_unit(buf, u):
@@ -129,13 +130,14 @@ def cvt_word(buf, w):
     return f"v_cvt_pk_f16_f32 v{P0 + w}, v{SBUF[buf] + 2 * w}, v{SBUF[buf] + 2 * w + 1}"
 
 
-SUM_BY_DOT2 = os.environ.get("R64X_SUM_BY_DOT2") == "1"    # experiment switch of the generator (not a product option)
+SUM_BY_DOT2 = os.environ.get("R64X_SUM_BY_DOT2") == "1"    # experiment switches of the generator (not product options)
+PK_ARGS = os.environ.get("R64X_PK_ARGS") == "1"
 
 
 def sum_word(w, buf):
     """row sum of the two exponentials of word w.  Two v_add_f32 on the f32 values: one v_dot2c_f32_f16 on the packed word
-    (with the literal (1, 1)) measured ~20 issue cycles where an add costs 5 - 2711 instead of 2460 cycles per tile here, and
-    the same 300 cycles in r64m when its row sums were moved to dot2 (round 4)."""
+    measured 2711 instead of 2460 cycles per tile here, and the same 300 cycles in r64m when its row sums were moved to dot2
+    (round 4) - DOT instructions wait for the matrix pipe (see pk_arg)."""
     if SUM_BY_DOT2:
         return f"v_dot2c_f32_f16 %[l{w >> 2}], {ONES_F16X2}, v{P0 + w}"
     return (f"v_add_f32_e32 %[l{w >> 2}], %[l{w >> 2}], v{SBUF[buf] + 2 * w}\\n\\t"
@@ -241,8 +243,8 @@ def tile(s, var):
     order = [("pk", 0), ("pk", 1), ("e", 0), ("e", 1), ("pk", 2), ("e", 2), ("e", 3), ("pk", 3), ("e", 4), ("e", 5), ("pk", 4),
              ("e", 6), ("e", 7), ("pk", 5), ("e", 8), ("e", 9), ("pk", 6), ("e", 10), ("e", 11), ("pk", 7), ("e", 12), ("e", 13),
              ("e", 14), ("e", 15)] + [("pk", k) for k in range(8, 16)]
-    for kind, i in order:
-        seq.extend(pk_arg(nxt, i) if kind == "pk" else [exp_unit(nxt, i)])
+    for kind, i in order:                                  # one gap each: the two v_fma of a pair share a gap
+        seq.append("\\n\\t".join(pk_arg(nxt, i)) if kind == "pk" else exp_unit(nxt, i))
     gaps = [[] for _ in range(64)]
     pos = 1                                                # gap 0 stays empty: the last S^T MFMA must have written its tile
     for it in seq:
