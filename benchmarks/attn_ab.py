@@ -11,7 +11,7 @@ from dvd_amd import ops
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 7
 hd = int(sys.argv[3]) if len(sys.argv) > 3 else 256
-specs = sys.argv[4:] or ["r64m=", "r64p=DVD_ATTN_R64P"]
+specs = sys.argv[4:] or ["r64x=", "r64m=DVD_ATTN_R64M"]
 variants = []
 for sp in specs:
     name, _, envs = sp.partition("=")

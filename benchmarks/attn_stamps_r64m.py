@@ -1,15 +1,15 @@
 #!/usr/bin/env python3
-"""Where a workgroup of flash_attn_r64m_kernel spends its cycles: s_memtime at kernel entry, loop entry, loop exit and
+"""Where a workgroup of flash_attn_r64x_kernel (or, with `r64m`, of its 32x32x16 sibling) spends its cycles: s_memtime at kernel entry, loop entry, loop exit and
 kernel exit (four stamps per wave, all OUTSIDE the tile loop - the loop runs unperturbed), and the dispatch picture: how
 many workgroups each CU ran and the gaps between one workgroup's exit and the next one's entry on the same CU.
-usage: [B=16] [ablation] [r64x]   (lab build)"""
+usage: [B=16] [ablation] [r64m]   (lab build; default: the production kernel r64x)"""
 import os, sys
-if len(sys.argv) > 3 and sys.argv[3] == "r64x":     # the 16x16x32 sibling (same stamps); ablation numbers are then r64x's
-    os.environ["DVD_ATTN_R64X"] = "1"
+if len(sys.argv) > 3 and sys.argv[3] == "r64m":     # the 32x32x16 sibling (same stamps); ablation numbers are then r64m's
+    os.environ["DVD_ATTN_R64M"] = "1"
     if sys.argv[2] != "0":
-        os.environ["DVD_ATTN_R64X_ABL"] = sys.argv[2]
+        os.environ["DVD_ATTN_R64M_ABL"] = sys.argv[2]
 elif len(sys.argv) > 2 and sys.argv[2] != "0":
-    os.environ["DVD_ATTN_R64M_ABL"] = sys.argv[2]
+    os.environ["DVD_ATTN_R64X_ABL"] = sys.argv[2]
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__))); import _lab; _lab.use_lab()
 sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
 import ctypes as C

@@ -1185,7 +1185,8 @@ __global__ void __launch_bounds__(256, 1) flash_attn_r64p_kernel(AttnArgs p) {
 
 
 // ================================================================================================
-// r64m (round 4; the PRODUCTION kernel for head_dim 256 at tq >= R64_MIN_TQ) = r64p's data movement and pipeline with
+// r64m (round 4, second step; superseded as the production kernel by its 16x16x32 sibling r64x below; lab switch
+// DVD_ATTN_R64M) = r64p's data movement and pipeline with
 // HAND-ALLOCATED registers, ONE exp unit per fragment step, and the whole key-tile loop as ONE generated asm statement.
 //  * r64p keeps 24 of a tile's 32 exponential units in phase 1 (two per fragment step) and none in phase 2b.  Letting a
 //    tile's first 8 units run one tile EARLY (in the previous tile's phase 2b) gives each of the 32 steps exactly one, but
@@ -1375,10 +1376,17 @@ __global__ void __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(R64M_CO
 
 
 // ================================================================================================
-// r64x = r64m on v_mfma_f32_16x16x32_f16 (round 4, third step).  Same pipeline, rings, DMA and register
-// ownership; what changes with the MFMA shape - the fragment maps, the key order inside a tile, the K / V^T LDS images,
-// the softmax in P-key order with packed-f32 arguments and dot2 row sums, four query blocks of 16 rows per wave instead of
-// two of 32 - is described in gen_attn_r64x.py, which generates attn_r64x_body.inc.
+// r64x (round 4, third step; the PRODUCTION kernel for head_dim 256 at tq >= R64_MIN_TQ) = r64m on
+// v_mfma_f32_16x16x32_f16.  Same pipeline across key tiles, rings, LDS-DMA and register ownership (the statements own
+// v[28:255] and a[0:255]); what changes with the MFMA shape - the fragment maps, the key order inside a tile, the K / V^T LDS
+// images, four query blocks of 16 rows per wave instead of two of 32, the rare block inside the PV phase - is described in
+// gen_attn_r64x.py, which generates attn_r64x_body.inc.
+// Why it wins although it needs MORE cycles (2366 per tile against r64m's 2126; MFMA minimum 2048): every MFMA kernel of the
+// step runs against the board's power cap, and the chip holds 1.75-1.8 GHz on this shape where it holds 1.45-1.5 on
+// 32x32x16: 29.97 vs 32.36 ms on one box, 30.27 vs 30.77 on another (+1.6 .. 8 %).  Getting there took three measurements:
+// beside 128 MFMA issues per tile no VALU instruction is free any more (first version 2711 cycles); v_dot2c_f32_f16,
+// v_pk_fma_f32 and v_pk_add_f32 do not overlap with the matrix pipe at all (benchmarks/lab/opsel_lab.hip: 34 cycles per MFMA +
+// instruction pair where v_fma / v_add / v_cvt_pk / v_max3 / v_exp take 17-18) - scalar row sums: 2460, scalar arguments: 2366.
 // ================================================================================================
 #include "attn_r64x_body.inc"
 #ifdef DVD_LAB
@@ -1572,7 +1580,7 @@ static constexpr int R64_MIN_TQ = 5376;
 extern "C" const char* dvd_flash_attn_kernel_name(int head_dim, int tq, int tk) {
   if (head_dim != 64 && head_dim != 256) return "";
   if (tk % 64 != 0) return head_dim == 256 ? "flash_attn_kernel<256>" : "flash_attn_kernel<64>";
-  if (head_dim == 256) return tq >= R64_MIN_TQ ? "flash_attn_r64m_kernel<0>" : "flash_attn_glds_kernel<256, 0>";
+  if (head_dim == 256) return tq >= R64_MIN_TQ ? "flash_attn_r64x_kernel<0>" : "flash_attn_glds_kernel<256, 0>";
   return "flash_attn_glds_kernel<64, 0>";
 }
 
@@ -1613,7 +1621,7 @@ extern "C" int dvd_flash_attn(const dvd_attn_desc* d, void* stream) {
   const bool first_on_device = attr_done.need(dev_bit);
   if (first_on_device) {
     allow_lds(flash_attn_glds_kernel<256, 0>, 2 * (64 * 512 + 256 * 128));
-    allow_lds(flash_attn_r64m_kernel<0>, r64p::LDS_BYTES);
+    allow_lds(flash_attn_r64x_kernel<0>, r64p::LDS_BYTES);
     allow_lds(flash_attn_kernel<256>, 2 * (64 * (2 * 256 + 16) + 256 * (2 * 64 + 16)));
     attr_done.done(dev_bit);
   }
@@ -1622,7 +1630,7 @@ extern "C" int dvd_flash_attn(const dvd_attn_desc* d, void* stream) {
   p.stamps = g_attn_stamps;
   const bool dbg = getenv("DVD_ATTN_DEBUG"), bulk = getenv("DVD_ATTN_BULK");
   if (getenv("DVD_ATTN_V1")) fast = false;
-  if (getenv("DVD_ATTN_R64") || getenv("DVD_ATTN_R64P") || getenv("DVD_ATTN_R64M_ABL") || getenv("DVD_ATTN_R64X") ||
+  if (getenv("DVD_ATTN_R64") || getenv("DVD_ATTN_R64P") || getenv("DVD_ATTN_R64M") || getenv("DVD_ATTN_R64M_ABL") || getenv("DVD_ATTN_R64X_ABL") ||
       getenv("DVD_ATTN_R64OLD"))
     r64 = d->head_dim == 256;
   if (getenv("DVD_ATTN_R32") || getenv("DVD_ATTN_PIPE") || bulk) r64 = false;
@@ -1638,7 +1646,7 @@ extern "C" int dvd_flash_attn(const dvd_attn_desc* d, void* stream) {
     allow_lds(flash_attn_r64_kernel<1>, 2 * (32 * 512 + 256 * 64));
     allow_lds(flash_attn_r64p_kernel<0>, r64p::LDS_BYTES);
     allow_lds(flash_attn_r64p_kernel<1>, r64p::LDS_BYTES);
-    allow_lds(flash_attn_r64x_kernel<0>, r64p::LDS_BYTES);
+    allow_lds(flash_attn_r64m_kernel<0>, r64p::LDS_BYTES);
     allow_lds(flash_attn_r64x_kernel<1>, r64p::LDS_BYTES);
     allow_lds(flash_attn_r64x_kernel<2>, r64p::LDS_BYTES);
     allow_lds(flash_attn_r64x_kernel<3>, r64p::LDS_BYTES);
@@ -1656,23 +1664,25 @@ extern "C" int dvd_flash_attn(const dvd_attn_desc* d, void* stream) {
       flash_attn_dsplit_kernel<<<(unsigned)nwg, 512, LDS, st>>>(p);
       return check_launch("flash_attn(lab dsplit)");
     }
-    if (r64 && getenv("DVD_ATTN_R64X")) {     // the 16x16x32-MFMA sibling of the production kernel; DVD_ATTN_R64X_ABL: timing ablations
+    if (r64 && getenv("DVD_ATTN_R64X_ABL")) {
+      // TIMING ABLATIONS of the production kernel's loop (garbage results): 1 no VALU | 2 no barrier | 3 MFMAs only
       p.nqb = cdiv(d->tq, 256);
       const unsigned g = (unsigned)((long)p.nqb * d->heads * d->batch);
-      switch (getenv("DVD_ATTN_R64X_ABL") ? atoi(getenv("DVD_ATTN_R64X_ABL")) : 0) {
+      switch (atoi(getenv("DVD_ATTN_R64X_ABL"))) {
         case 1: flash_attn_r64x_kernel<1><<<g, 256, r64p::LDS_BYTES, st>>>(p); break;
         case 2: flash_attn_r64x_kernel<2><<<g, 256, r64p::LDS_BYTES, st>>>(p); break;
         case 3: flash_attn_r64x_kernel<3><<<g, 256, r64p::LDS_BYTES, st>>>(p); break;
         default: flash_attn_r64x_kernel<0><<<g, 256, r64p::LDS_BYTES, st>>>(p);
       }
-      return check_launch("flash_attn(lab r64x)");
+      return check_launch("flash_attn(lab r64x ablation)");
     }
-    if (r64 && getenv("DVD_ATTN_R64M_ABL")) {
-      // TIMING ABLATIONS of the production kernel's loop (garbage results): 1 16x16x32 MFMAs, same FLOPs (power) | 2 no barrier | 3 MFMAs only,
-      // no barrier | 4 MFMAs only | 5 no softmax VALU | 6 no LDS-DMA | 7 no fragment reads
+    if (r64 && (getenv("DVD_ATTN_R64M") || getenv("DVD_ATTN_R64M_ABL"))) {
+      // round 4's second step: the same pipeline on the 32x32x16 MFMA (superseded by r64x: 1.6-8 % slower by box).
+      // DVD_ATTN_R64M_ABL: timing ablations of ITS loop (garbage results): 1 16x16x32 MFMAs, same FLOPs (power) | 2 no barrier
+      // | 3 MFMAs only, no barrier | 4 MFMAs only | 5 no softmax VALU | 6 no LDS-DMA | 7 no fragment reads
       p.nqb = cdiv(d->tq, 256);
       const unsigned g = (unsigned)((long)p.nqb * d->heads * d->batch);
-      switch (atoi(getenv("DVD_ATTN_R64M_ABL"))) {
+      switch (getenv("DVD_ATTN_R64M_ABL") ? atoi(getenv("DVD_ATTN_R64M_ABL")) : 0) {
         case 1: flash_attn_r64m_kernel<1><<<g, 256, r64p::LDS_BYTES, st>>>(p); break;
         case 2: flash_attn_r64m_kernel<2><<<g, 256, r64p::LDS_BYTES, st>>>(p); break;
         case 3: flash_attn_r64m_kernel<3><<<g, 256, r64p::LDS_BYTES, st>>>(p); break;
@@ -1682,7 +1692,7 @@ extern "C" int dvd_flash_attn(const dvd_attn_desc* d, void* stream) {
         case 7: flash_attn_r64m_kernel<7><<<g, 256, r64p::LDS_BYTES, st>>>(p); break;
         default: flash_attn_r64m_kernel<0><<<g, 256, r64p::LDS_BYTES, st>>>(p);
       }
-      return check_launch("flash_attn(lab r64m ablation)");
+      return check_launch("flash_attn(lab r64m)");
     }
     if (r64 && getenv("DVD_ATTN_R64P")) {     // round 4's first step (compiler-allocated registers), with or without stamps
       p.nqb = cdiv(d->tq, 256);
@@ -1726,7 +1736,7 @@ extern "C" int dvd_flash_attn(const dvd_attn_desc* d, void* stream) {
   // ---- product dispatch: four kernels, chosen by (head_dim, tq, tk) ----
   if (fast && r64) {
     p.nqb = cdiv(d->tq, 256);
-    flash_attn_r64m_kernel<0><<<(unsigned)((long)p.nqb * d->heads * d->batch), 256, r64p::LDS_BYTES, st>>>(p);
+    flash_attn_r64x_kernel<0><<<(unsigned)((long)p.nqb * d->heads * d->batch), 256, r64p::LDS_BYTES, st>>>(p);
   } else if (fast && d->head_dim == 256) {
     flash_attn_glds_kernel<256, 0><<<(unsigned)nwg, 256, 2 * (64 * 512 + 256 * 128), st>>>(p);
   } else if (fast) {

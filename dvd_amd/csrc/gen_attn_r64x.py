@@ -132,6 +132,7 @@ def cvt_word(buf, w):
 
 SUM_BY_DOT2 = os.environ.get("R64X_SUM_BY_DOT2") == "1"    # experiment switches of the generator (not product options)
 PK_ARGS = os.environ.get("R64X_PK_ARGS") == "1"
+WAIT_EVERY_STEP = os.environ.get("R64X_WAIT_EVERY_STEP") == "1"
 
 
 def sum_word(w, buf):
@@ -198,6 +199,16 @@ def advance(s, which):
     s.add(f"s_addc_u32 s{sg + 1}, s{sg + 1}, 0")
 
 
+def ring_wait(s, n):
+    """before step n uses ring slot n & 3.  Fragment reads are issued three steps ahead and return in order: at an EVEN step
+    `lgkmcnt(1)` (all but the read issued last, fragment n + 2) covers fragments n AND n + 1, so the odd steps need no wait -
+    16 instead of 32 s_waitcnt per tile, in a loop where every instruction beside the 128 MFMA issues costs its issue time."""
+    if WAIT_EVERY_STEP:
+        s.add("s_waitcnt lgkmcnt(2)")
+    elif not n & 1:
+        s.add("s_waitcnt lgkmcnt(1)")
+
+
 def emit_gap(s, items):
     for it in items:
         if it.startswith(".L") or it.startswith("s_cbranch"):
@@ -220,7 +231,7 @@ def tile(s, var):
         gaps[4 * f + 3].append(sum_word(f, cur))
     for f in range(16):
         n, ks, kb2 = f, f >> 1, f & 1
-        s.add("s_waitcnt lgkmcnt(2)")
+        ring_wait(s, n)
         for qb in range(4):
             d = stile(nxt, kb2, qb)
             s.add(f"{MF} {d}, {frag(n)}, {qreg(qb, ks)}, {'0' if ks == 0 else d}")
@@ -254,7 +265,7 @@ def tile(s, var):
     assert pos <= 64, pos
     for g in range(16):
         n = 16 + g
-        s.add("s_waitcnt lgkmcnt(2)")
+        ring_wait(s, n)
         for qb in range(4):
             s.add(f"{MF} {oreg(qb, g)}, {frag(n)}, {pfrag(qb)}, {oreg(qb, g)}")
             if qb == 0:

@@ -69,9 +69,9 @@ def test_attention_fused_qkv_views(ops):
 
 
 VARIANTS = {
-    "r64m (64 query rows per wave, pipelined across key tiles, generated loop; the default at production sizes)": {"DVD_ATTN_R64": "1"},
+    "r64x (64 query rows per wave, pipelined across key tiles, generated loop, 16x16x32 MFMA; the default at production sizes)": {"DVD_ATTN_R64": "1"},
+    "r64m (the same on the 32x32x16 MFMA; superseded)": {"DVD_ATTN_R64M": "1"},
     "r64p (round 4's first step: compiler-allocated registers; superseded)": {"DVD_ATTN_R64P": "1"},
-    "r64x (the production kernel's sibling on the 16x16x32 MFMA shape)": {"DVD_ATTN_R64X": "1"},
     "r64 of rounds 1-3 (superseded, lab include)": {"DVD_ATTN_R64OLD": "1"},
     "r32 (flash_attn_glds_kernel)": {"DVD_ATTN_R32": "1"},
     "bulk LDS-DMA issue": {"DVD_ATTN_BULK": "1"},
@@ -96,7 +96,7 @@ def test_attention_kernel_variants(ops, lab, monkeypatch, variant, hd, scale):
 
 
 @pytest.mark.parametrize("tk", [64, 128, 192, 256, 320, 448])
-@pytest.mark.parametrize("switch", ["DVD_ATTN_R64", "DVD_ATTN_R64X"])
+@pytest.mark.parametrize("switch", ["DVD_ATTN_R64", "DVD_ATTN_R64M"])
 def test_generated_loops_at_every_exit(ops, lab, monkeypatch, switch, tk):
     """The generated key-tile loops (six tile variants per trip, exits after the 2nd, 4th and 6th) at 2, 4, 6, 8, 10 and 14
     key tiles: every exit, the first trip's and a later trip's; fewer tiles than the K / V^T rings are deep (the LDS-DMA
