@@ -228,7 +228,12 @@ def tile(s, var):
     for f in range(16):
         gaps[4 * f + 0].append(exp_unit(cur, 16 + f))
         gaps[4 * f + 1].append(cvt_word(cur, f))          # words 8..15 follow their second exponential by >= one MFMA
-        gaps[4 * f + 3].append(sum_word(f, cur))
+        adds = sum_word(f, cur).split("\\n\\t")
+        if len(adds) == 2:                                # one VALU instruction per MFMA gap
+            gaps[4 * f + 2].append(adds[0])
+            gaps[4 * f + 3].append(adds[1])
+        else:
+            gaps[4 * f + 3].append(adds[0])
     for f in range(16):
         n, ks, kb2 = f, f >> 1, f & 1
         ring_wait(s, n)
@@ -254,8 +259,13 @@ def tile(s, var):
     order = [("pk", 0), ("pk", 1), ("e", 0), ("e", 1), ("pk", 2), ("e", 2), ("e", 3), ("pk", 3), ("e", 4), ("e", 5), ("pk", 4),
              ("e", 6), ("e", 7), ("pk", 5), ("e", 8), ("e", 9), ("pk", 6), ("e", 10), ("e", 11), ("pk", 7), ("e", 12), ("e", 13),
              ("e", 14), ("e", 15)] + [("pk", k) for k in range(8, 16)]
-    for kind, i in order:                                  # one gap each: the two v_fma of a pair share a gap
-        seq.append("\\n\\t".join(pk_arg(nxt, i)) if kind == "pk" else exp_unit(nxt, i))
+    for kind, i in order:          # one instruction per gap; the arguments of units 16..31 (not needed before the next tile's
+        if kind == "e":            # phase 1) go two to a gap: 23 + 16 + 16 + 8 = the 63 gaps of the phase
+            seq.append(exp_unit(nxt, i))
+        elif i < 8:
+            seq.extend(pk_arg(nxt, i))
+        else:
+            seq.append("\\n\\t".join(pk_arg(nxt, i)))
     gaps = [[] for _ in range(64)]
     pos = 1                                                # gap 0 stays empty: the last S^T MFMA must have written its tile
     for it in seq:
