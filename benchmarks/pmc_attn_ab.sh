@@ -8,8 +8,8 @@ export PROBE_B=16
 for spec in "$@"; do
   name=${spec%%=*}; envs=${spec#*=}
   for e in ${envs//,/ }; do if [[ $e == *:* ]]; then export ${e%%:*}=${e#*:}; else export $e=1; fi; done
-  timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_MFMA GRBM_GUI_ACTIVE --output-format csv -d $out/$name -- python3 benchmarks/pmc_probe.py attn256 --lab > $out/$name.log 2>&1 || tail -3 $out/$name.log
-  [ -n "$NOSTATS" ] || timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${name}_stats -- python3 benchmarks/pmc_probe.py attn256 --lab > $out/${name}_stats.log 2>&1 || tail -3 $out/${name}_stats.log
+  timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_MFMA GRBM_GUI_ACTIVE --output-format csv -d $out/$name -- python3 benchmarks/pmc_probe.py ${PROBE_OP:-attn256} --lab > $out/$name.log 2>&1 || tail -3 $out/$name.log
+  [ -n "$NOSTATS" ] || timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${name}_stats -- python3 benchmarks/pmc_probe.py ${PROBE_OP:-attn256} --lab > $out/${name}_stats.log 2>&1 || tail -3 $out/${name}_stats.log
   for e in ${envs//,/ }; do unset ${e%%:*}; done
 done
 python3 - "$@" <<'PY'

@@ -1558,6 +1558,140 @@ __global__ void __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(R64X_CO
 #endif
 }
 
+
+// ================================================================================================
+// h64m: head_dim 64 on the decoder kernel's recipe (round 4; gen_attn_h64m.py generates attn_h64m_body.inc): 64 query rows
+// per wave, S^T(t+1) and the softmax of tile t overlapped by pipelining across 32-key tiles, the loop one asm statement with
+// hand-allocated registers - and TWO waves per SIMD (160 VGPRs + 64 AGPRs per wave), because head_dim 64 has four exp units
+// beside every pair of MFMAs.  K image: natural key rows of 128 B, chunks XOR-swizzled by (row >> 1) & 7, rows read in kappa
+// order (one fragment base per ks); V^T image as in the decoder kernel (64-byte rows, chunk ^ ((row >> 2) & 3)).
+// MEASURED (lab switch DVD_ATTN_H64M; profiles/r4_attn_h64m_*): correct on the first run and EXACTLY as fast as the
+// compiler-scheduled flash_attn_glds_kernel<64> (10.32 vs 10.32 ms, 10.49 vs 10.62 on another box): 17.3 M vs 16.4 M cycles,
+// MFMA busy 58 vs 61 %.  Its ablations say why neither moves: without the exp units 11.1 M cycles (91 % busy), i.e. the
+// softmax VALU work is not hidden at all - each of a tile's 132 VALU instructions costs the SIMD ~2.4 cycles on top of
+// the MFMAs, whichever kernel issues them, however they are ordered (interleaving the units' dependent fma -> exp pairs:
+// no change).  Head_dim 64 is bound by the SUM of matrix and VALU time, not by its schedule.  Not the product kernel.
+// ================================================================================================
+#include "attn_h64m_body.inc"
+#ifdef DVD_LAB
+#include "../../benchmarks/lab/csrc/attn_h64m_abl.inc"
+#endif
+
+namespace h64m {
+constexpr int KBYTES = 4096, VBYTES = 4096, VBASE = 3 * KBYTES, LDS_BYTES = 3 * KBYTES + 3 * VBYTES;
+}
+
+template <int DBG>
+__global__ void __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(H64M_COMPILER_VGPRS))) flash_attn_h64m_kernel(AttnArgs p) {
+  using namespace h64m;
+  constexpr int D = 64, KB = 32;
+  constexpr float RESCALE_THR = 10.f;
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [K0 | K1 | K2 | V0 | V1 | V2], 4 KiB each
+  typedef __attribute__((address_space(3))) void* lptr_t;
+
+  const int nwg = gridDim.x;
+  int id = blockIdx.x;
+  {
+    const int q = nwg / 8, rr = nwg % 8, xcd = id % 8, k = id / 8;
+    id = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + k;
+  }
+  const int qb = id % p.nqb;          // 256-row query blocks
+  const int bh = id / p.nqb;
+  const int head = bh % p.heads, b = bh / p.heads;
+  const int kvb = b / p.kv_div;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+
+  const _Float16* Qg = p.Q + b * p.sQ + (size_t)head * D;
+  const char* Kg = (const char*)(p.K + kvb * p.sK + (size_t)head * D);
+  const char* Vg = (const char*)(p.Vt + kvb * p.sVt + (size_t)head * D * p.ldvt);
+  {
+    const int q0 = min(qb * 256 + wave * 64 + r, p.tq - 1), q1 = min(qb * 256 + wave * 64 + 32 + r, p.tq - 1);
+    h64m_load_q(Qg + (size_t)q0 * p.ldq + 8 * h, Qg + (size_t)q1 * p.ldq + 8 * h);
+  }
+  // LDS-DMA sources: this wave's 1-KiB piece of a K tile = key rows 8 w .. 8 w + 7 (8 chunks each), of a V^T tile = dim rows
+  // 16 w .. 16 w + 15 (4 chunks each); the swizzles are applied to the SOURCE chunk
+  const int krow = 8 * wave + (lane >> 3);
+  const unsigned koff = (unsigned)krow * (unsigned)(p.ldk * 2) + (unsigned)(((lane & 7) ^ ((krow >> 1) & 7)) * 16);
+  const unsigned voff = (unsigned)(16 * wave + (lane >> 2)) * (unsigned)(p.ldvt * 2) + (unsigned)(((lane & 3) ^ ((lane >> 4) & 3)) * 16);
+  const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t)smem;
+  const int kr = kappa(r);
+  unsigned kf[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) kf[ks] = lds0 + kr * 128 + (((2 * ks + h) ^ ((kr >> 1) & 7)) * 16);
+  const unsigned vrel0 = lds0 + VBASE + r * 64 + ((h ^ ((r >> 2) & 3)) * 16);
+  const unsigned vrel1 = vrel0 ^ 32;
+
+  h64m_zero_o();
+  r64p::Soft sm[2] = {{-1e30f, -1e30f, 0.f}, {-1e30f, -1e30f, 0.f}};
+  const int nt = p.tk / KB;              // even (tk % 64 == 0)
+  const size_t ktile = (size_t)KB * p.ldk * 2;
+  const unsigned kdst = lds0 + wave * 1024, vdst = lds0 + VBASE + wave * 1024;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {          // prologue: K(0..2) -> K slots 0..2, V^T(0..1) -> V slots 0, 1
+    r64p::glds_piece(Kg + (size_t)min(j, nt - 1) * ktile, koff, kdst + j * KBYTES);
+    if (j < 2) r64p::glds_piece(Vg + (size_t)min(j, nt - 1) * (KB * 2), voff, vdst + j * VBYTES);
+  }
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+
+  float a0, a1;
+  h64m_prologue_s0(kf, a0, a1);                                           // S^T(0) -> buffer A; lane-local maxima
+  asm volatile("s_barrier" ::: "memory");                                // every wave has read K(0) before K slot 0 is refilled
+  {
+    const float mloc[2] = {a0, a1};
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) {
+      const float m = half_swap_max(mloc[rb] * p.c);
+      sm[rb].m = m;
+      sm[rb].thr = m + RESCALE_THR;
+    }
+  }
+  const char* kg = uniform_ptr(Kg + (size_t)min(3, nt - 1) * ktile);
+  const char* vg = uniform_ptr(Vg + (size_t)min(2, nt - 1) * (KB * 2));
+  const int klim = nt - 4, vlim = nt - 3;
+  const unsigned kstep = (unsigned)ktile, vstep = KB * 2;
+  float e0, e1;
+  h64m_prologue_units(kf, p.c, sm[0].m, sm[1].m, e0, e1);                // units 0..7 of tile 0; the ring: K(1) fragments 0..2
+#define H64M_LOOP_ARGS sm[0].l, sm[1].l, sm[0].m, sm[1].m, sm[0].thr, sm[1].thr, e0, e1, kg, vg, nt, kf, vrel0, vrel1, koff, voff, p.c, \
+                       kdst, vdst, kstep, vstep, klim, vlim
+#ifdef DVD_LAB
+  if constexpr (DBG == 1) h64m_loop_noeu(H64M_LOOP_ARGS);
+  else if constexpr (DBG == 2) h64m_loop_nobar(H64M_LOOP_ARGS);
+  else if constexpr (DBG == 3) h64m_loop_mfmaonly(H64M_LOOP_ARGS);
+  else
+#endif
+    h64m_loop(H64M_LOOP_ARGS);
+#undef H64M_LOOP_ARGS
+
+  const int lane_e = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));     // nothing per-lane kept live across the loop
+  const int re = lane_e & 31, he = lane_e >> 5;
+#pragma unroll
+  for (int rb = 0; rb < 2; ++rb) {
+    const float l_tot = sm[rb].l + __shfl_xor(sm[rb].l, 32);
+    const float inv = 1.f / l_tot;
+    const int qglob = qb * 256 + wave * 64 + rb * 32 + re;
+    if (qglob < p.tq) {
+      _Float16* op = p.O + b * p.sO + (size_t)qglob * p.ldo + (size_t)head * D + 4 * he;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        floatx16 x;
+        if (rb == 0 && dt == 0) x = r64m_read_o<0>();
+        else if (rb == 0) x = r64m_read_o<16>();
+        else if (dt == 0) x = r64m_read_o<32>();
+        else x = r64m_read_o<48>();
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          half4 v;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) v[j] = (_Float16)(x[4 * g4 + j] * inv);
+          *(half4*)(op + 32 * dt + 8 * g4) = v;
+        }
+      }
+    }
+  }
+}
+
 #ifdef DVD_LAB
 #include "../../benchmarks/lab/csrc/attention_lab.inc"
 #endif
@@ -1721,6 +1855,17 @@ extern "C" int dvd_flash_attn(const dvd_attn_desc* d, void* stream) {
     }
   } else if (fast) {
     constexpr int LDS = 2 * (64 * 128 + 64 * 128);
+    if (getenv("DVD_ATTN_H64M")) {   // head_dim 64 on the decoder kernel's recipe (generated loop, two waves per SIMD); _ABL: ablations
+      p.nqb = cdiv(d->tq, 256);
+      const unsigned g = (unsigned)((long)p.nqb * d->heads * d->batch);
+      switch (getenv("DVD_ATTN_H64M_ABL") ? atoi(getenv("DVD_ATTN_H64M_ABL")) : 0) {
+        case 1: flash_attn_h64m_kernel<1><<<g, 256, h64m::LDS_BYTES, st>>>(p); break;
+        case 2: flash_attn_h64m_kernel<2><<<g, 256, h64m::LDS_BYTES, st>>>(p); break;
+        case 3: flash_attn_h64m_kernel<3><<<g, 256, h64m::LDS_BYTES, st>>>(p); break;
+        default: flash_attn_h64m_kernel<0><<<g, 256, h64m::LDS_BYTES, st>>>(p);
+      }
+      return check_launch("flash_attn(lab h64m)");
+    }
     if (getenv("DVD_ATTN_64X2")) {   // head_dim 64, two query row blocks per wave: measured = (872 vs 895 TF/s)
       p.nqb = cdiv(d->tq, 256);
       flash_attn_glds64x2_kernel<<<(unsigned)((long)p.nqb * d->heads * d->batch), 256, LDS, st>>>(p);

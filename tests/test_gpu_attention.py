@@ -79,6 +79,7 @@ VARIANTS = {
     "half-tile software pipeline (experiment)": {"DVD_ATTN_PIPE": "1"},
     "head-dim split, two waves per SIMD (experiment)": {"DVD_ATTN_DSPLIT": "1"},
     "hd64 two row blocks per wave (experiment)": {"DVD_ATTN_64X2": "1"},
+    "h64m (head_dim 64 on the decoder kernel's recipe: generated loop, two waves per SIMD)": {"DVD_ATTN_H64M": "1"},
 }
 
 
