@@ -119,6 +119,18 @@ __global__ void __launch_bounds__(512, 1) valu_kernel(float* out, int iters, lon
       asm volatile("v_mfma_f32_32x32x16_f16 %0, %2, %3, %0\n v_fma_f32 %4, %4, %10, %10\n v_exp_f32_e32 %5, %5\n v_add_f32_e32 %6, %6, %10\n"
                    "v_mfma_f32_32x32x16_f16 %1, %2, %3, %1\n"
                    : "+v"(acc0), "+v"(acc1) : "v"(ha), "v"(hb), "v"(f[0]), "v"(f[1]), "v"(f[2]), "v"(f[3]), "v"(f[4]), "v"(f[5]), "v"(c));
+    if constexpr (V == 27)      // the head_dim-64 density: per MFMA 6 v_fma + 2 v_exp (AGPR accumulators)
+      asm volatile("v_mfma_f32_32x32x16_f16 %0, %2, %3, %0\n v_fma_f32 %4, %4, %10, %10\n v_fma_f32 %5, %5, %10, %10\n v_exp_f32_e32 %6, %6\n v_fma_f32 %7, %7, %10, %10\n"
+                   "v_fma_f32 %8, %8, %10, %10\n v_exp_f32_e32 %9, %9\n v_fma_f32 %4, %4, %10, %10\n v_fma_f32 %5, %5, %10, %10\n"
+                   "v_mfma_f32_32x32x16_f16 %1, %2, %3, %1\n v_fma_f32 %7, %7, %10, %10\n v_fma_f32 %8, %8, %10, %10\n v_exp_f32_e32 %6, %6\n v_fma_f32 %4, %4, %10, %10\n"
+                   "v_fma_f32 %5, %5, %10, %10\n v_exp_f32_e32 %9, %9\n v_fma_f32 %7, %7, %10, %10\n v_fma_f32 %8, %8, %10, %10\n"
+                   : "+a"(acc0), "+a"(acc1) : "v"(ha), "v"(hb), "v"(f[0]), "v"(f[1]), "v"(f[2]), "v"(f[3]), "v"(f[4]), "v"(f[5]), "v"(c));
+    if constexpr (V == 28)      // the same VALU work without the MFMAs
+      asm volatile("v_fma_f32 %4, %4, %10, %10\n v_fma_f32 %5, %5, %10, %10\n v_exp_f32_e32 %6, %6\n v_fma_f32 %7, %7, %10, %10\n"
+                   "v_fma_f32 %8, %8, %10, %10\n v_exp_f32_e32 %9, %9\n v_fma_f32 %4, %4, %10, %10\n v_fma_f32 %5, %5, %10, %10\n"
+                   "v_fma_f32 %7, %7, %10, %10\n v_fma_f32 %8, %8, %10, %10\n v_exp_f32_e32 %6, %6\n v_fma_f32 %4, %4, %10, %10\n"
+                   "v_fma_f32 %5, %5, %10, %10\n v_exp_f32_e32 %9, %9\n v_fma_f32 %7, %7, %10, %10\n v_fma_f32 %8, %8, %10, %10\n"
+                   : "+a"(acc0), "+a"(acc1) : "v"(ha), "v"(hb), "v"(f[0]), "v"(f[1]), "v"(f[2]), "v"(f[3]), "v"(f[4]), "v"(f[5]), "v"(c));
     if constexpr (V == 19)      // 8 SALU
       asm volatile("s_add_u32 %0, %0, 1\n s_add_u32 %1, %1, 1\n s_add_u32 %0, %0, 1\n s_add_u32 %1, %1, 1\n s_add_u32 %0, %0, 1\n s_add_u32 %1, %1, 1\n s_add_u32 %0, %0, 1\n s_add_u32 %1, %1, 1\n"
                    : "+s"(sa), "+s"(sb) : : "scc");
@@ -178,5 +190,7 @@ int main(int argc, char** argv) {
   run<20>("2 x (MFMA 32x32x16 AGPR acc, 3 v_fma)", 2, out, clk);
   run<26>("MFMA, fma, exp, add, MFMA  (VGPR acc)", 2, out, clk);
   run<25>("MFMA, fma, exp, add, MFMA  (AGPR acc)", 2, out, clk);
+  run<27>("2 x (MFMA 32x32x16, 6 v_fma + 2 v_exp)  [per MFMA]", 2, out, clk);
+  run<28>("2 x (6 v_fma + 2 v_exp), no MFMA        [per group]", 2, out, clk);
   return 0;
 }
