@@ -1,7 +1,6 @@
 #!/bin/bash
 mkdir -p gpurun_out/r4
-export NOSTATS=1
-export PROBE_OP=attn64
-(timeout 300 python -m pytest tests/test_gpu_attention.py -q -x -k "h64m" 2>&1 | tail -2
-timeout 300 python benchmarks/attn_ab.py 16 7 64 "glds64=" "h64m=DVD_ATTN_H64M" 2>&1 | tail -3
-bash benchmarks/pmc_attn_ab.sh "glds64=" "h64m=DVD_ATTN_H64M" 2>&1 | tail -2) | tee gpurun_out/r4/c56_h64m.txt
+( time python bench.py ) > gpurun_out/r4/c58_bench_default.json 2> gpurun_out/r4/c58_bench_default.err; echo "rc=$?"
+grep real gpurun_out/r4/c58_bench_default.err
+python -c "
+import json; d=json.loads(open('gpurun_out/r4/c58_bench_default.json').read().strip().splitlines()[-1]); print('bench', d['value'], d['steps'], d['warmup'], d['ms_per_step'], d['roofline']['achieved'], d['roofline']['frac'], d['roofline'].get('traffic'), d['cpu_baseline']['value'])"
