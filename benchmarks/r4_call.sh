@@ -1,3 +1,3 @@
 #!/bin/bash
 mkdir -p gpurun_out/r4
-(python benchmarks/gemm_time.py 7 plain --lab 2>&1 | grep -v amdgpu; DVD_GEMM_M16=1 python benchmarks/gemm_time.py 7 plain --lab 2>&1 | grep -v amdgpu; python benchmarks/gemm_time.py 7 plain --lab 2>&1 | grep -v amdgpu) | tee gpurun_out/r4/c59_gemm_m16.txt
+timeout 900 python -m pytest tests/test_gpu_attention.py -q 2>&1 | tail -3 | tee gpurun_out/r4/c61_tests.txt

@@ -107,6 +107,33 @@ def test_generated_loops_at_every_exit(ops, lab, monkeypatch, switch, tk):
     assert err < 2e-3 * max(1.0, mag), (switch, tk, err, mag)
 
 
+@pytest.mark.parametrize("switch,hd", [("DVD_ATTN_R64", 256), ("DVD_ATTN_R64M", 256), ("DVD_ATTN_H64M", 64)])
+def test_generated_loops_soak(ops, lab, monkeypatch, switch, hd):
+    """40 seeded cases per generated kernel: up to three dominant keys at random positions (the deferred rescale in every tile
+    variant, in first and last tiles, on either row / query block), ragged query counts, 1..13 key-tile pairs, shared K/V."""
+    monkeypatch.setenv(switch, "1")
+    heads = 2
+    C = heads * hd
+    gen = torch.Generator(device="cpu").manual_seed(1234)
+    for case in range(40):
+        B = 1 + case % 3
+        Bkv = B if case % 4 else 1
+        tq = [64, 200, 256, 300, 513][case % 5]
+        tk = 64 * (1 + (case * 7) % 13)
+        q = torch.randn(B, tq, C, generator=gen).half()
+        k = torch.randn(Bkv, tk, C, generator=gen).half()
+        v = torch.randn(Bkv, tk, C, generator=gen).half()
+        for sp in range(case % 4):
+            key, row, hh = (int(torch.randint(0, n_, (1,), generator=gen)) for n_ in (tk, tq, heads))
+            k[0, key, hh * hd:(hh + 1) * hd] = q[0, row, hh * hd:(hh + 1) * hd] * (3 + 2 * sp)
+        scale = 1.0 / hd ** 0.5
+        out = torch.zeros(B, tq, C, dtype=torch.float16, device="cuda")
+        ops.flash_attn(q.cuda(), k.cuda(), v.transpose(1, 2).contiguous().cuda(), out, heads, hd, scale, kv_batch_div=B // Bkv)
+        ref = ref_attn(q, k, v, heads, hd, scale, B // Bkv)
+        err, mag = (out.cpu().double() - ref).abs().max().item(), ref.abs().max().item()
+        assert torch.isfinite(out).all() and err < 3e-3 * max(1.0, mag), (switch, case, B, Bkv, tq, tk, err, mag)
+
+
 PRODUCT_SHAPES = {
     # the product library picks its kernel from (head_dim, tq, tk) alone - never from the batch, never from the environment
     "hd256 r64 (tq >= 5376, ragged tq)": (256, 0.0625, 5500, 512),
