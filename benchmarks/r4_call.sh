@@ -1,3 +1,5 @@
 #!/bin/bash
 mkdir -p gpurun_out/r4
-timeout 900 python -m pytest tests/test_gpu_attention.py -q 2>&1 | tail -3 | tee gpurun_out/r4/c61_tests.txt
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
+timeout 1500 python -m pytest tests -m gpu -q --durations=8 > gpurun_out/r4/c62_gpu_tests_full.txt 2>&1; echo "rc=$?"
+tail -14 gpurun_out/r4/c62_gpu_tests_full.txt
