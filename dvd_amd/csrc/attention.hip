@@ -1570,7 +1570,8 @@ __global__ void __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(R64X_CO
 // MFMA busy 58 vs 61 %.  Its ablations say why neither moves: without the exp units 11.1 M cycles (91 % busy), i.e. the
 // softmax VALU work is not hidden at all - each of a tile's 132 VALU instructions costs the SIMD ~2.4 cycles on top of
 // the MFMAs, whichever kernel issues them, however they are ordered (interleaving the units' dependent fma -> exp pairs:
-// no change).  Head_dim 64 is bound by the SUM of matrix and VALU time, not by its schedule.  Not the product kernel.
+// no change).  Head_dim 64 is bound by the SUM of matrix and VALU time, not by its schedule.  Lab build only; its sibling
+// on the other MFMA shape, h64x below, is the product kernel.
 // ================================================================================================
 #include "attn_h64m_body.inc"
 #ifdef DVD_LAB
@@ -1657,7 +1658,7 @@ __global__ void __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(H64M_CO
                        kdst, vdst, kstep, vstep, klim, vlim
 #ifdef DVD_LAB
   if constexpr (DBG == 1) h64m_loop_noeu(H64M_LOOP_ARGS);
-  else if constexpr (DBG == 2) h64m_loop_nobar(H64M_LOOP_ARGS);
+  else if constexpr (DBG == 2) h64m_loop_m16(H64M_LOOP_ARGS);
   else if constexpr (DBG == 3) h64m_loop_mfmaonly(H64M_LOOP_ARGS);
   else
 #endif
@@ -1692,6 +1693,132 @@ __global__ void __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(H64M_CO
   }
 }
 
+
+// ================================================================================================
+// h64x (round 4; the PRODUCTION kernel for head_dim 64 at tq >= R64_MIN_TQ): head_dim 64 on v_mfma_f32_16x16x32_f16 = r64x's
+// fragment maps at h64m's geometry (gen_attn_h64x.py generates attn_h64x_body.inc): 64 query rows per wave as four query
+// blocks of 16, 32-key tiles of 8 steps, two waves per SIMD (160 VGPRs + 64 AGPRs), K tiles in A-row order with 128-byte
+// rows, one LDS-DMA piece per wave, stream and tile.  Priced first by an ablation of h64m (two 16x16x32 MFMAs per 32x32x16:
+// 10.01 vs 10.53 ms), then built: correct on its first run; against flash_attn_glds_kernel<64> on four boxes +0.8, +2.2,
+// +4.0, +5.2 % (9.80-10.25 vs 10.13-10.66 ms; profiles/r4_attn_h64x_*).  19.6 M cycles against 16.7 M - the softmax VALU
+// work hides even less beside 16-cycle MFMAs - at 1.96 instead of 1.65 GHz.
+// ================================================================================================
+#include "attn_h64x_body.inc"
+#ifdef DVD_LAB
+#include "../../benchmarks/lab/csrc/attn_h64x_abl.inc"
+#endif
+
+template <int DBG>
+__global__ void __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(H64X_COMPILER_VGPRS))) flash_attn_h64x_kernel(AttnArgs p) {
+  using namespace h64m;                 // LDS geometry: 3 + 3 slots of 4 KiB
+  constexpr int D = 64, KB = 32;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef __attribute__((address_space(3))) void* lptr_t;
+
+  const int nwg = gridDim.x;
+  int id = blockIdx.x;
+  {
+    const int q = nwg / 8, rr = nwg % 8, xcd = id % 8, k = id / 8;
+    id = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + k;
+  }
+  const int qb = id % p.nqb;          // 256-row query blocks
+  const int bh = id / p.nqb;
+  const int head = bh % p.heads, b = bh / p.heads;
+  const int kvb = b / p.kv_div;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int c16 = lane & 15, g = lane >> 4;
+
+  const _Float16* Qg = p.Q + b * p.sQ + (size_t)head * D;
+  const char* Kg = (const char*)(p.K + kvb * p.sK + (size_t)head * D);
+  const char* Vg = (const char*)(p.Vt + kvb * p.sVt + (size_t)head * D * p.ldvt);
+  {
+    const int qrow = qb * 256 + wave * 64 + c16;
+    const unsigned rowb = (unsigned)(p.ldq * 2);
+    const unsigned q0 = (unsigned)min(qrow, p.tq - 1) * rowb + 16 * g, q1 = (unsigned)min(qrow + 16, p.tq - 1) * rowb + 16 * g;
+    const unsigned q2 = (unsigned)min(qrow + 32, p.tq - 1) * rowb + 16 * g, q3 = (unsigned)min(qrow + 48, p.tq - 1) * rowb + 16 * g;
+    h64x_load_q((const _Float16*)uniform_ptr((const char*)Qg), q0, q1, q2, q3);
+  }
+  // LDS-DMA sources.  K: this wave's piece = the tile's A-rows 8 w .. 8 w + 7 (row 16 kb2 + i holds the natural key
+  // 8 (i >> 2) + 4 kb2 + (i & 3)), 8 chunks each, chunk ^ ((row >> 1) & 7).  V^T: dim rows 16 w .. 16 w + 15, 4 chunks each.
+  unsigned koff, voff;
+  {
+    const int i = 8 * (wave & 1) + (lane >> 3), kb2 = wave >> 1;
+    const int key = 8 * (i >> 2) + 4 * kb2 + (i & 3);
+    koff = (unsigned)key * (unsigned)(p.ldk * 2) + (unsigned)(((lane & 7) ^ ((i >> 1) & 7)) * 16);
+    voff = (unsigned)(16 * wave + (lane >> 2)) * (unsigned)(p.ldvt * 2) + (unsigned)(((lane & 3) ^ ((0u - (unsigned)(lane >> 4)) & 3)) * 16);
+  }
+  const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t)smem;
+  // fragment reads: K A-row c16 of key block kb2 (+ imm: slot, kb2 * 2048), chunk 4 ks + g; V^T dim row 16 db + c16, chunk g
+  const unsigned kf0 = lds0 + c16 * 128 + (((0 + g) ^ ((c16 >> 1) & 7)) * 16);
+  const unsigned kf1 = lds0 + c16 * 128 + (((4 + g) ^ ((c16 >> 1) & 7)) * 16);
+  const unsigned vrel = lds0 + VBASE + c16 * 64 + ((g ^ ((0u - (unsigned)(c16 >> 2)) & 3)) * 16);
+
+  h64x_zero_o();
+  const int nt = p.tk / KB;              // even (tk % 64 == 0)
+  const size_t ktile = (size_t)KB * p.ldk * 2;
+  const unsigned kdst = lds0 + wave * 1024, vdst = lds0 + VBASE + wave * 1024;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {          // prologue: K(0..2) -> K slots 0..2, V^T(0..1) -> V slots 0, 1
+    r64p::glds_piece(Kg + (size_t)min(j, nt - 1) * ktile, koff, kdst + j * KBYTES);
+    if (j < 2) r64p::glds_piece(Vg + (size_t)min(j, nt - 1) * (KB * 2), voff, vdst + j * VBYTES);
+  }
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+
+  float a[4];
+  h64x_prologue_s0(kf0, kf1, a[0], a[1], a[2], a[3]);                     // S^T(0) -> buffer A; lane-local maxima
+  asm volatile("s_barrier" ::: "memory");                                // every wave has read K(0) before K slot 0 is refilled
+  float m[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {                                           // a query's 32 keys live in lanes c16 + 16 g, g = 0..3
+    float x = a[q] * p.c;
+    x = fmaxf(x, __shfl_xor(x, 16));
+    x = fmaxf(x, __shfl_xor(x, 32));
+    m[q] = x;
+  }
+  const char* kg = uniform_ptr(Kg + (size_t)min(3, nt - 1) * ktile);
+  const char* vg = uniform_ptr(Vg + (size_t)min(2, nt - 1) * (KB * 2));
+  const int klim = nt - 4, vlim = nt - 3;
+  const unsigned kstep = (unsigned)ktile, vstep = KB * 2;
+  h64x_prologue_units(kf0, kf1, p.c, m[0], m[1], m[2], m[3]);            // m -> v[28:31]; tile 0: arguments, exp units 0..15
+  float l[4] = {0.f, 0.f, 0.f, 0.f};
+#define H64X_LOOP_ARGS l[0], l[1], l[2], l[3], kg, vg, nt, kf0, kf1, vrel, koff, voff, p.c, kdst, vdst, kstep, vstep, klim, vlim
+#ifdef DVD_LAB
+  if constexpr (DBG == 1) h64x_loop_novalu(H64X_LOOP_ARGS);
+  else if constexpr (DBG == 2) h64x_loop_nobar(H64X_LOOP_ARGS);
+  else if constexpr (DBG == 3) h64x_loop_mfmaonly(H64X_LOOP_ARGS);
+  else
+#endif
+    h64x_loop(H64X_LOOP_ARGS);
+#undef H64X_LOOP_ARGS
+
+  const int lane_e = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));     // nothing per-lane kept live across the loop
+  const int c16e = lane_e & 15, ge = lane_e >> 4;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    float lt = l[q];
+    lt += __shfl_xor(lt, 16);
+    lt += __shfl_xor(lt, 32);
+    const float inv = 1.f / lt;
+    const int qglob = qb * 256 + wave * 64 + 16 * q + c16e;
+    if (qglob < p.tq) {
+      _Float16* op = p.O + b * p.sO + (size_t)qglob * p.ldo + (size_t)head * D + 4 * ge;
+      floatx16 x;                      // tiles (db = 0..3, q): a[16 q + 4 db + r] = dim 16 db + 4 g + r
+      if (q == 0) x = r64m_read_o<0>();
+      else if (q == 1) x = r64m_read_o<16>();
+      else if (q == 2) x = r64m_read_o<32>();
+      else x = r64m_read_o<48>();
+#pragma unroll
+      for (int db = 0; db < 4; ++db) {
+        half4 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = (_Float16)(x[4 * db + j] * inv);
+        *(half4*)(op + 16 * db) = v;
+      }
+    }
+  }
+}
+
 #ifdef DVD_LAB
 #include "../../benchmarks/lab/csrc/attention_lab.inc"
 #endif
@@ -1715,7 +1842,7 @@ extern "C" const char* dvd_flash_attn_kernel_name(int head_dim, int tq, int tk) 
   if (head_dim != 64 && head_dim != 256) return "";
   if (tk % 64 != 0) return head_dim == 256 ? "flash_attn_kernel<256>" : "flash_attn_kernel<64>";
   if (head_dim == 256) return tq >= R64_MIN_TQ ? "flash_attn_r64x_kernel<0>" : "flash_attn_glds_kernel<256, 0>";
-  return "flash_attn_glds_kernel<64, 0>";
+  return tq >= R64_MIN_TQ ? "flash_attn_h64x_kernel<0>" : "flash_attn_glds_kernel<64, 0>";
 }
 
 template <typename KernelT>
@@ -1747,7 +1874,7 @@ extern "C" int dvd_flash_attn(const dvd_attn_desc* d, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   bool fast = d->tk % 64 == 0;      // the LDS-DMA kernels stream whole 64-key tiles; ragged key counts take the
                                     // register-staged kernel (masked tail)
-  bool r64 = d->head_dim == 256 && d->tq >= R64_MIN_TQ;
+  bool r64 = d->tq >= R64_MIN_TQ;      // 64 query rows per wave (256 per workgroup): the generated kernels r64x / h64x
   // hipFuncSetAttribute is per DEVICE: remember which devices have been set up (one bit each), lock-free - the
   // attribute call is idempotent, so two threads racing on a device's first launch both set it and both are right
   static DeviceOnce attr_done;
@@ -1756,6 +1883,7 @@ extern "C" int dvd_flash_attn(const dvd_attn_desc* d, void* stream) {
   if (first_on_device) {
     allow_lds(flash_attn_glds_kernel<256, 0>, 2 * (64 * 512 + 256 * 128));
     allow_lds(flash_attn_r64x_kernel<0>, r64p::LDS_BYTES);
+    allow_lds(flash_attn_h64x_kernel<0>, h64m::LDS_BYTES);
     allow_lds(flash_attn_kernel<256>, 2 * (64 * (2 * 256 + 16) + 256 * (2 * 64 + 16)));
     attr_done.done(dev_bit);
   }
@@ -1766,8 +1894,8 @@ extern "C" int dvd_flash_attn(const dvd_attn_desc* d, void* stream) {
   if (getenv("DVD_ATTN_V1")) fast = false;
   if (getenv("DVD_ATTN_R64") || getenv("DVD_ATTN_R64P") || getenv("DVD_ATTN_R64M") || getenv("DVD_ATTN_R64M_ABL") || getenv("DVD_ATTN_R64X_ABL") ||
       getenv("DVD_ATTN_R64OLD"))
-    r64 = d->head_dim == 256;
-  if (getenv("DVD_ATTN_R32") || getenv("DVD_ATTN_PIPE") || bulk) r64 = false;
+    r64 = true;
+  if (getenv("DVD_ATTN_R32") || getenv("DVD_ATTN_PIPE") || getenv("DVD_ATTN_GLDS64") || bulk) r64 = false;
   if (first_on_device) {
     constexpr int LDS = 2 * (64 * 512 + 256 * 128);
     allow_lds(flash_attn_dsplit_kernel, LDS);
@@ -1855,6 +1983,17 @@ extern "C" int dvd_flash_attn(const dvd_attn_desc* d, void* stream) {
     }
   } else if (fast) {
     constexpr int LDS = 2 * (64 * 128 + 64 * 128);
+    if (getenv("DVD_ATTN_H64X") || (r64 && getenv("DVD_ATTN_H64X_ABL"))) {   // the production kernel forced at any size; _ABL: ablations
+      p.nqb = cdiv(d->tq, 256);
+      const unsigned g = (unsigned)((long)p.nqb * d->heads * d->batch);
+      switch (getenv("DVD_ATTN_H64X_ABL") ? atoi(getenv("DVD_ATTN_H64X_ABL")) : 0) {
+        case 1: flash_attn_h64x_kernel<1><<<g, 256, h64m::LDS_BYTES, st>>>(p); break;
+        case 2: flash_attn_h64x_kernel<2><<<g, 256, h64m::LDS_BYTES, st>>>(p); break;
+        case 3: flash_attn_h64x_kernel<3><<<g, 256, h64m::LDS_BYTES, st>>>(p); break;
+        default: flash_attn_h64x_kernel<0><<<g, 256, h64m::LDS_BYTES, st>>>(p);
+      }
+      return check_launch("flash_attn(lab h64x)");
+    }
     if (getenv("DVD_ATTN_H64M")) {   // head_dim 64 on the decoder kernel's recipe (generated loop, two waves per SIMD); _ABL: ablations
       p.nqb = cdiv(d->tq, 256);
       const unsigned g = (unsigned)((long)p.nqb * d->heads * d->batch);
@@ -1878,12 +2017,15 @@ extern "C" int dvd_flash_attn(const dvd_attn_desc* d, void* stream) {
     }
   }
 #endif
-  // ---- product dispatch: four kernels, chosen by (head_dim, tq, tk) ----
-  if (fast && r64) {
+  // ---- product dispatch: six kernels, chosen by (head_dim, tq, tk) ----
+  if (fast && r64 && d->head_dim == 256) {
     p.nqb = cdiv(d->tq, 256);
     flash_attn_r64x_kernel<0><<<(unsigned)((long)p.nqb * d->heads * d->batch), 256, r64p::LDS_BYTES, st>>>(p);
   } else if (fast && d->head_dim == 256) {
     flash_attn_glds_kernel<256, 0><<<(unsigned)nwg, 256, 2 * (64 * 512 + 256 * 128), st>>>(p);
+  } else if (fast && r64) {            // head_dim 64 at production sizes: the generated 16x16x32 loop, 256-row workgroups
+    p.nqb = cdiv(d->tq, 256);
+    flash_attn_h64x_kernel<0><<<(unsigned)((long)p.nqb * d->heads * d->batch), 256, h64m::LDS_BYTES, st>>>(p);
   } else if (fast) {
     flash_attn_glds_kernel<64, 0><<<(unsigned)nwg, 256, 2 * (64 * 128 + 64 * 128), st>>>(p);
   } else if (d->head_dim == 256) {

@@ -81,6 +81,14 @@ class Stmt:
         self.lines = []
 
     def add(self, s):
+        if "m16" in ABL and s.startswith(MF):
+            # POWER ablation: the same FLOPs from two 16x16x32 MFMAs on the first 8 accumulator registers (garbage math)
+            d, a, b, c = [x.strip() for x in s[len(MF):].split(",")]
+            lo = int(d[2:].split(":")[0])
+            for h in range(2):
+                dd = f"{d[0]}[{lo + 4 * h}:{lo + 4 * h + 3}]"
+                self.lines.append(f"v_mfma_f32_16x16x32_f16 {dd}, {a}, {b}, {dd if c != '0' else '0'}")
+            return
         if "read" in ABL and s.startswith("ds_read"):
             return
         if "wait" in ABL and s.startswith("s_waitcnt lgkmcnt"):
@@ -339,7 +347,7 @@ def prologue_units():
     return s
 
 
-VARIANTS = [("", ()), ("noeu", ("eu", "pack", "max")), ("nobar", ("bar",)), ("mfmaonly", ("eu", "pack", "dma", "read", "wait", "max"))]
+VARIANTS = [("", ()), ("noeu", ("eu", "pack", "max")), ("m16", ("m16",)), ("mfmaonly", ("eu", "pack", "dma", "read", "wait", "max"))]
 KF = ", ".join(f'[kf{i}] "v"(kf[{i}])' for i in range(4))
 
 

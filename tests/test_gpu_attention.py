@@ -80,6 +80,7 @@ VARIANTS = {
     "head-dim split, two waves per SIMD (experiment)": {"DVD_ATTN_DSPLIT": "1"},
     "hd64 two row blocks per wave (experiment)": {"DVD_ATTN_64X2": "1"},
     "h64m (head_dim 64 on the decoder kernel's recipe: generated loop, two waves per SIMD)": {"DVD_ATTN_H64M": "1"},
+    "h64x (head_dim 64, generated loop on the 16x16x32 MFMA; the default at production sizes)": {"DVD_ATTN_H64X": "1"},
 }
 
 
@@ -107,7 +108,7 @@ def test_generated_loops_at_every_exit(ops, lab, monkeypatch, switch, tk):
     assert err < 2e-3 * max(1.0, mag), (switch, tk, err, mag)
 
 
-@pytest.mark.parametrize("switch,hd", [("DVD_ATTN_R64", 256), ("DVD_ATTN_R64M", 256), ("DVD_ATTN_H64M", 64)])
+@pytest.mark.parametrize("switch,hd", [("DVD_ATTN_R64", 256), ("DVD_ATTN_R64M", 256), ("DVD_ATTN_H64M", 64), ("DVD_ATTN_H64X", 64)])
 def test_generated_loops_soak(ops, lab, monkeypatch, switch, hd):
     """40 seeded cases per generated kernel: up to three dominant keys at random positions (the deferred rescale in every tile
     variant, in first and last tiles, on either row / query block), ragged query counts, 1..13 key-tile pairs, shared K/V."""
@@ -140,7 +141,9 @@ PRODUCT_SHAPES = {
     "hd256 r64, two key tiles": (256, 0.0625, 5500, 64),
     "hd256 glds (tq < 5376)": (256, 0.0625, 1024, 512),
     "hd256 register-staged (tk % 64 != 0)": (256, 0.0625, 300, 1000),
-    "hd64 glds": (64, 0.125, 5500, 512),
+    "hd64 h64x (tq >= 5376, ragged tq)": (64, 0.125, 5500, 512),
+    "hd64 h64x, two key tiles": (64, 0.125, 5500, 64),
+    "hd64 glds (tq < 5376)": (64, 0.125, 1024, 512),
     "hd64 register-staged (tk % 64 != 0)": (64, 0.125, 300, 1000),
 }
 
