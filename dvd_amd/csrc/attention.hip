@@ -1697,11 +1697,14 @@ __global__ void __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(H64M_CO
 // ================================================================================================
 // h64x (round 4; the PRODUCTION kernel for head_dim 64 at tq >= R64_MIN_TQ): head_dim 64 on v_mfma_f32_16x16x32_f16 = r64x's
 // fragment maps at h64m's geometry (gen_attn_h64x.py generates attn_h64x_body.inc): 64 query rows per wave as four query
-// blocks of 16, 32-key tiles of 8 steps, two waves per SIMD (160 VGPRs + 64 AGPRs), K tiles in A-row order with 128-byte
+// blocks of 16, 32-key tiles of 8 steps, two waves per SIMD (176 VGPRs + 64 AGPRs), K tiles in A-row order with 128-byte
 // rows, one LDS-DMA piece per wave, stream and tile.  Priced first by an ablation of h64m (two 16x16x32 MFMAs per 32x32x16:
 // 10.01 vs 10.53 ms), then built: correct on its first run; against flash_attn_glds_kernel<64> on four boxes +0.8, +2.2,
 // +4.0, +5.2 % (9.80-10.25 vs 10.13-10.66 ms; profiles/r4_attn_h64x_*).  19.6 M cycles against 16.7 M - the softmax VALU
-// work hides even less beside 16-cycle MFMAs - at 1.96 instead of 1.65 GHz.
+// work hides even less beside 16-cycle MFMAs - at 1.96 instead of 1.65 GHz.  Then the softmax argument was taken off the
+// VALU as in flash_attn_glds_kernel<64> (Q pre-scaled by c, -m through the C operand of each chain's first MFMA: the two
+// waves per SIMD leave 16 registers for the tuples): 32 of 135 VALU instructions per tile gone, 9.11 vs 10.07 ms on one
+// box (profiles/r4_attn_h64x_negm_ab.txt) = 1161 TF/s.
 // ================================================================================================
 #include "attn_h64x_body.inc"
 #ifdef DVD_LAB
@@ -1737,7 +1740,7 @@ __global__ void __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(H64X_CO
     const unsigned rowb = (unsigned)(p.ldq * 2);
     const unsigned q0 = (unsigned)min(qrow, p.tq - 1) * rowb + 16 * g, q1 = (unsigned)min(qrow + 16, p.tq - 1) * rowb + 16 * g;
     const unsigned q2 = (unsigned)min(qrow + 32, p.tq - 1) * rowb + 16 * g, q3 = (unsigned)min(qrow + 48, p.tq - 1) * rowb + 16 * g;
-    h64x_load_q((const _Float16*)uniform_ptr((const char*)Qg), q0, q1, q2, q3);
+    h64x_load_q((const _Float16*)uniform_ptr((const char*)Qg), q0, q1, q2, q3, p.c);       // Q * c (fp32 multiply, one f16 rounding)
   }
   // LDS-DMA sources.  K: this wave's piece = the tile's A-rows 8 w .. 8 w + 7 (row 16 kb2 + i holds the natural key
   // 8 (i >> 2) + 4 kb2 + (i & 3)), 8 chunks each, chunk ^ ((row >> 1) & 7).  V^T: dim rows 16 w .. 16 w + 15, 4 chunks each.
@@ -1771,7 +1774,7 @@ __global__ void __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(H64X_CO
   float m[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) {                                           // a query's 32 keys live in lanes c16 + 16 g, g = 0..3
-    float x = a[q] * p.c;
+    float x = a[q];                                                       // Q is pre-scaled: the scores are s * c
     x = fmaxf(x, __shfl_xor(x, 16));
     x = fmaxf(x, __shfl_xor(x, 32));
     m[q] = x;
@@ -1780,9 +1783,9 @@ __global__ void __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(H64X_CO
   const char* vg = uniform_ptr(Vg + (size_t)min(2, nt - 1) * (KB * 2));
   const int klim = nt - 4, vlim = nt - 3;
   const unsigned kstep = (unsigned)ktile, vstep = KB * 2;
-  h64x_prologue_units(kf0, kf1, p.c, m[0], m[1], m[2], m[3]);            // m -> v[28:31]; tile 0: arguments, exp units 0..15
+  h64x_prologue_units(kf0, kf1, m[0], m[1], m[2], m[3]);                 // -m -> v[160:175]; tile 0: scores - m, exp units 0..15
   float l[4] = {0.f, 0.f, 0.f, 0.f};
-#define H64X_LOOP_ARGS l[0], l[1], l[2], l[3], kg, vg, nt, kf0, kf1, vrel, koff, voff, p.c, kdst, vdst, kstep, vstep, klim, vlim
+#define H64X_LOOP_ARGS l[0], l[1], l[2], l[3], kg, vg, nt, kf0, kf1, vrel, koff, voff, kdst, vdst, kstep, vstep, klim, vlim
 #ifdef DVD_LAB
   if constexpr (DBG == 1) h64x_loop_novalu(H64X_LOOP_ARGS);
   else if constexpr (DBG == 2) h64x_loop_nobar(H64X_LOOP_ARGS);

@@ -16,25 +16,29 @@ V^T image: [dim][key], 64-byte rows, chunk ^ ((-(row >> 2)) & 3), as in r64x.
 
 Register plan (per wave):
   AGPR  a[0:63]    O^T: tile (db, qb) at a[16 qb + 4 db ...]
-  VGPR  v[0:27]    the compiler's (amdgpu_num_vgpr(28)); v[28:31] running maxima m of query blocks 0..3
+  VGPR  v[0:31]    the compiler's (amdgpu_num_vgpr(32))
         v[32:47]   packed P fragments (query block qb at 32 + 4 qb); v[48:63] fragment ring
         v[64:95]   S^T buffer A (element 8 qb + 4 kb2 + r), v[96:127] buffer B
-        v[128:159] Q fragments: 128 + 4 (2 qb + ks)
+        v[128:159] Q fragments: 128 + 4 (2 qb + ks), PRE-SCALED by c = scale * log2(e) at load (fp32 multiply, one f16 rounding)
+        v[160:175] -m of query block q, four copies at 160 + 4 q: the C operand of the first MFMA of each S^T chain, so the
+                   accumulators come out as s * c - m and feed v_exp directly (as flash_attn_glds_kernel<64> does since round
+                   2): 32 v_fma per tile gone from a loop in which VALU work does not hide.  The rare block adds its delta to
+                   the tuples and subtracts it from the S^T(t+1) already formed against the old m (one block per buffer parity).
 """
 import os
 import sys
 
-MREG = 28
 P0 = 32
 FR0 = 48
 SBUF = (64, 96)
 Q0 = 128
 KBYTES, VBYTES = 4096, 4096
-S_KG, S_VG, S_TC, S_TMP, S_SEL, S_C = 80, 82, 84, 85, 86, 90
-SGPR_CLOBBERS = [f"s{i}" for i in range(80, 92)]
+S_KG, S_VG, S_TC, S_TMP, S_SEL = 80, 82, 84, 85, 86
+SGPR_CLOBBERS = [f"s{i}" for i in range(80, 88)]
 THR_BITS = "0x41200000"          # 10.0f (log2 units), as in the other attention kernels
 ONES_F16X2 = "0x3c003c00"
-COMPILER_VGPRS = MREG
+COMPILER_VGPRS = 32
+NEGM0 = 160                       # tuple of query block q at 160 + 4 q: four copies of -m_q (the C operand of a chain's first MFMA)
 
 MF = "v_mfma_f32_16x16x32_f16"
 ABL = set()        # timing ablations (lab builds only; garbage results): "valu", "dma", "read", "wait", "bar"
@@ -85,18 +89,6 @@ class Stmt:
 
 
 # ---- VALU items (strings; "valu" ablation drops them all, the test then never fires) ----
-def pk_arg(buf, k):
-    """s * c - m for elements 2k, 2k + 1 of the tile in `buf` (query block k >> 2), in place -> list of instructions.
-    Two v_fma_f32, NOT one v_pk_fma_f32: packed-f32 and DOT instructions do not overlap with the matrix pipe on gfx950
-    (benchmarks/lab/opsel_lab.hip: MFMA 16x16x32 + v_fma_f32 = 17 cycles per pair, + v_pk_fma_f32 / v_pk_add_f32 /
-    v_dot2c_f32_f16 = 34), so a packed instruction costs three times what the two scalar ones cost beside MFMAs."""
-    x, q = SBUF[buf] + 2 * k, k >> 2
-    if PK_ARGS:       # experiment switch (even query blocks only: the odd ones, m in the high register of its pair, came out wrong)
-        if not q & 1:
-            return [f"v_pk_fma_f32 {vr(x, 2)}, {vr(x, 2)}, s[{S_C}:{S_C + 1}], {vr(MREG + q, 2)} op_sel_hi:[1,1,0] neg_lo:[0,0,1] neg_hi:[0,0,1]"]
-    return [f"v_fma_f32 v{x + i}, v{x + i}, s{S_C}, -v{MREG + q}" for i in range(2)]
-
-
 def exp_unit(buf, u):
     return f"v_exp_f32_e32 v{SBUF[buf] + u}, v{SBUF[buf] + u}"
 
@@ -106,14 +98,13 @@ def cvt_word(buf, w):
 
 
 SUM_BY_DOT2 = os.environ.get("R64X_SUM_BY_DOT2") == "1"    # experiment switches of the generator (not product options)
-PK_ARGS = os.environ.get("R64X_PK_ARGS") == "1"
 WAIT_EVERY_STEP = os.environ.get("R64X_WAIT_EVERY_STEP") == "1"
 
 
 def sum_word(w, buf):
     """row sum of the two exponentials of word w.  Two v_add_f32 on the f32 values: one v_dot2c_f32_f16 on the packed word
     measured 2711 instead of 2460 cycles per tile here, and the same 300 cycles in r64m when its row sums were moved to dot2
-    (round 4) - DOT instructions wait for the matrix pipe (see pk_arg)."""
+    (round 4) - DOT instructions wait for the matrix pipe (gen_attn_r64x.py, pk_arg)."""
     if SUM_BY_DOT2:
         return f"v_dot2c_f32_f16 %[l{w >> 2}], {ONES_F16X2}, v{P0 + w}"
     return (f"v_add_f32_e32 %[l{w >> 2}], %[l{w >> 2}], v{SBUF[buf] + 2 * w}\\n\\t"
@@ -122,7 +113,7 @@ def sum_word(w, buf):
 
 def max_chain(buf):
     """lane-local maximum of each query block's 8 scores -> a0..a3 (four interleaved chains), then the test:
-    vcc = some lane's max(a_q c - m_q) > THR"""
+    vcc = some lane's maximum > THR"""
     items = []
     x = lambda q, j: f"v{SBUF[buf] + 8 * q + j}"
     for q in range(4):
@@ -132,10 +123,8 @@ def max_chain(buf):
             items.append(f"v_max3_f32 %[a{q}], %[a{q}], {x(q, j)}, {x(q, j + 1)}")
     for q in range(4):
         items.append(f"v_max_f32_e32 %[a{q}], %[a{q}], {x(q, 7)}")
-    for q in range(4):
-        items.append(f"v_fma_f32 %[t{q + 1}], %[a{q}], s{S_C}, -v{MREG + q}")
-    items.append("v_max3_f32 %[t1], %[t1], %[t2], %[t3]")
-    items.append("v_max_f32_e32 %[t1], %[t1], %[t4]")
+    items.append("v_max3_f32 %[t1], %[a0], %[a1], %[a2]")      # the scores already are s * c - m
+    items.append("v_max_f32_e32 %[t1], %[t1], %[a3]")
     items.append(f"v_cmp_lt_f32_e32 vcc, {THR_BITS}, %[t1]")
     return items
 
@@ -225,7 +214,7 @@ def tile(s, var):
         ring_wait(s, n)
         for qb in range(4):
             d = stile(nxt, kb2, qb)
-            s.add(f"{MF} {d}, {frag(n)}, {qreg(qb, ks)}, {'0' if ks == 0 else d}")
+            s.add(f"{MF} {d}, {frag(n)}, {qreg(qb, ks)}, {vr(NEGM0 + 4 * qb, 4) if ks == 0 else d}")
             if qb == 0:
                 a, off = read_for_step(n + 3, slot)
                 s.add(f"ds_read_b128 {frag(n + 3)}, %[{a}] offset:{off}")
@@ -239,13 +228,14 @@ def tile(s, var):
     s.add("s_barrier")
     # ---------------- phase 2 (steps 4..7): PV(t); maxima + test of tile t+1, its softmax argument, its exp units 0..15
     seq = max_chain(nxt)
-    seq.append(f"s_cbranch_vccnz .Lh64x_stub{var}_%=")
+    seq.append(f"s_cbranch_vccnz .Lh64x_stub{var}_%=")            # -> the rare block of this variant's buffer parity
     seq.append(f".Lh64x_back{var}_%=:")
     order = [("pk", 0), ("pk", 1), ("e", 0), ("e", 1), ("pk", 2), ("e", 2), ("e", 3), ("pk", 3), ("e", 4), ("e", 5), ("pk", 4),
              ("e", 6), ("e", 7), ("pk", 5), ("e", 8), ("e", 9), ("pk", 6), ("e", 10), ("e", 11), ("pk", 7), ("e", 12), ("e", 13),
              ("e", 14), ("e", 15)] + [("pk", k) for k in range(8, 16)]
     for kind, i in order:
-        seq += [exp_unit(nxt, i)] if kind == "e" else pk_arg(nxt, i)
+        if kind == "e":
+            seq.append(exp_unit(nxt, i))
     gaps = spread(seq, 16)
     for g in range(4):
         n = 4 + g
@@ -265,44 +255,48 @@ def tile(s, var):
             emit_gap(s, gaps[4 * g + qb])
 
 
-def rare_block(s):
-    """out of line, shared by the six variants (s[S_SEL] = the variant to return to): new reference maxima; O^T, l and the
-    packed P(t) of every query block scaled by alpha = 2^(m_old - m_new)"""
-    s.label(".Lh64x_rare_%=")
+def rare_block(s, par):
+    """out of line, one per buffer parity, shared by the three variants of that parity (s[S_SEL] = the variant to return to):
+    delta = max(row maximum of S^T(t+1), 0) per query; m += delta (the -m tuples), S^T(t+1) -= delta; O^T, l and the packed
+    P(t) of the query block scaled by alpha = 2^-delta"""
+    nxt = 1 - par
+    s.label(f".Lh64x_rare{par}_%=")
     s.add("s_nop 15")                                     # the PV MFMAs issued so far must have written O^T
     s.add("s_nop 7")
     t0, t1 = "%[t0]", "%[t1]"
     for q in range(4):
-        s.add(f"v_mul_f32_e32 {t0}, s{S_C}, %[a{q}]")
-        s.add(f"ds_swizzle_b32 {t1}, {t0} offset:swizzle(SWAP,16)")     # the query's other keys: lanes ^ 16 and ^ 32
+        s.add(f"ds_swizzle_b32 {t1}, %[a{q}] offset:swizzle(SWAP,16)")     # the query's other keys: lanes ^ 16 and ^ 32
         s.add("s_waitcnt lgkmcnt(0)")
-        s.add(f"v_max_f32_e32 {t0}, {t0}, {t1}")
+        s.add(f"v_max_f32_e32 {t0}, %[a{q}], {t1}")
         s.add(f"v_mov_b32_e32 {t1}, {t0}")
         s.add("s_nop 1")
         s.add(f"v_permlane32_swap_b32 {t0}, {t1}")
         s.add("s_nop 1")
         s.add(f"v_max_f32_e32 {t0}, {t0}, {t1}")
-        s.add(f"v_max_f32_e32 {t1}, v{MREG + q}, {t0}")    # m_new
-        s.add(f"v_sub_f32_e32 {t0}, v{MREG + q}, {t1}")
-        s.add(f"v_exp_f32_e32 {t0}, {t0}")                # alpha
-        s.add(f"v_mov_b32_e32 v{MREG + q}, {t1}")
-        s.add("s_nop 0")
-        s.add(f"v_mul_f32_e32 %[l{q}], %[l{q}], {t0}")
-        s.add(f"v_cvt_pk_f16_f32 {t1}, {t0}, {t0}")
+        s.add(f"v_max_f32_e32 {t0}, 0, {t0}")             # delta
+        s.add(f"v_exp_f32_e64 {t1}, -{t0}")               # alpha = 2^-delta
+        for i in range(4):
+            s.add(f"v_sub_f32_e32 v{NEGM0 + 4 * q + i}, v{NEGM0 + 4 * q + i}, {t0}")
+        for i in range(8):
+            s.add(f"v_sub_f32_e32 v{SBUF[nxt] + 8 * q + i}, v{SBUF[nxt] + 8 * q + i}, {t0}")
+        s.add(f"v_mul_f32_e32 %[l{q}], %[l{q}], {t1}")
+        s.add(f"v_cvt_pk_f16_f32 {t0}, {t1}, {t1}")
         for j in range(4):
-            s.add(f"v_pk_mul_f16 v{P0 + 4 * q + j}, v{P0 + 4 * q + j}, {t1}")
+            s.add(f"v_pk_mul_f16 v{P0 + 4 * q + j}, v{P0 + 4 * q + j}, {t0}")
+        tmp = ("%[t0]", "%[t2]", "%[t3]", "%[t4]")        # t1 = alpha; t0 (the packed alpha) is free again after the P words
         for a0 in range(16 * q, 16 * q + 16, 4):
             for i in range(4):
-                s.add(f"v_accvgpr_read_b32 %[t{1 + i}], a{a0 + i}")
+                s.add(f"v_accvgpr_read_b32 {tmp[i]}, a{a0 + i}")
             for i in range(4):
-                s.add(f"v_mul_f32_e32 %[t{1 + i}], {t0}, %[t{1 + i}]")
+                s.add(f"v_mul_f32_e32 {tmp[i]}, {t1}, {tmp[i]}")
             for i in range(4):
-                s.add(f"v_accvgpr_write_b32 a{a0 + i}, %[t{1 + i}]")
+                s.add(f"v_accvgpr_write_b32 a{a0 + i}, {tmp[i]}")
     s.add("s_nop 1")
-    for var in range(5):
+    mine = [v for v in range(6) if v & 1 == par]
+    for var in mine[:-1]:
         s.add(f"s_cmp_eq_u32 s{S_SEL}, {var}")
         s.add(f"s_cbranch_scc1 .Lh64x_back{var}_%=")
-    s.add("s_branch .Lh64x_back5_%=")
+    s.add(f"s_branch .Lh64x_back{mine[-1]}_%=")
 
 
 def loop_stmt():
@@ -310,8 +304,6 @@ def loop_stmt():
     s.add(f"s_mov_b64 s[{S_KG}:{S_KG + 1}], %[kg]")
     s.add(f"s_mov_b64 s[{S_VG}:{S_VG + 1}], %[vg]")
     s.add(f"s_mov_b32 s{S_TC}, 0")
-    s.add(f"s_mov_b32 s{S_C}, %[c]")
-    s.add(f"s_mov_b32 s{S_C + 1}, %[c]")
     s.label(".Lh64x_loop_%=")
     for var in range(6):
         tile(s, var)
@@ -324,8 +316,9 @@ def loop_stmt():
     for var in range(6):
         s.label(f".Lh64x_stub{var}_%=")
         s.add(f"s_mov_b32 s{S_SEL}, {var}")
-        s.add("s_branch .Lh64x_rare_%=")
-    rare_block(s)
+        s.add(f"s_branch .Lh64x_rare{var & 1}_%=")
+    rare_block(s, 0)
+    rare_block(s, 1)
     s.label(".Lh64x_end_%=")
     s.add("s_waitcnt vmcnt(0) lgkmcnt(0)")                # no LDS-DMA may land after the workgroup has ended
     s.add("s_nop 15")                                     # the last PV MFMAs must have written O^T before it is read out
@@ -352,16 +345,17 @@ def prologue_s0():
 
 
 def prologue_units():
-    """m -> v[28:31]; s * c - m for all of tile 0 and its exp units 0..15 (what phase 2 of a tile does for the next one);
-    the fragment ring primed with K(1) fragments 0..2"""
+    """-m -> the C tuples; tile 0's scores (formed with C = 0) minus m; its exp units 0..15 (what phase 2 of a tile does for the
+    next one); the fragment ring primed with K(1) fragments 0..2"""
     s = Stmt()
     for f in range(3):
         a, off = kfrag_addr(f, 1)
         s.add(f"ds_read_b128 {frag(f)}, %[{a}] offset:{off}")
     for q in range(4):
-        s.add(f"v_mov_b32_e32 v{MREG + q}, %[m{q}]")
+        for i in range(4):
+            s.add(f"v_sub_f32_e32 v{NEGM0 + 4 * q + i}, 0, %[m{q}]")
     for u in range(32):
-        s.add(f"v_fma_f32 v{SBUF[0] + u}, v{SBUF[0] + u}, %[c], -%[m{u >> 3}]")
+        s.add(f"v_sub_f32_e32 v{SBUF[0] + u}, v{SBUF[0] + u}, %[m{u >> 3}]")
     for u in range(16):
         s.add(exp_unit(0, u))
     return s
@@ -373,7 +367,7 @@ VARIANTS = [("", ()), ("novalu", ("valu",)), ("nobar", ("bar",)), ("mfmaonly", (
 def emit_loop(w, sfx):
     w(f"// ---- the key-tile loop{sfx}: six tile variants, the rare rescale block, the drain")
     w(f"__device__ __forceinline__ void h64x_loop{sfx}(float& l0, float& l1, float& l2, float& l3, const char* kg, const char* vg, int nt,")
-    w("    unsigned kf0, unsigned kf1, unsigned vrel, unsigned koff, unsigned voff, float c, unsigned kdst, unsigned vdst,")
+    w("    unsigned kf0, unsigned kf1, unsigned vrel, unsigned koff, unsigned voff, unsigned kdst, unsigned vdst,")
     w("    unsigned kstep, unsigned vstep, int klim, int vlim) {")
     w("  float a0, a1, a2, a3, t0, t1, t2, t3, t4;")
     w("  asm volatile(")
@@ -381,7 +375,7 @@ def emit_loop(w, sfx):
     w('      : [l0] "+v"(l0), [l1] "+v"(l1), [l2] "+v"(l2), [l3] "+v"(l3), [a0] "=&v"(a0), [a1] "=&v"(a1), [a2] "=&v"(a2), [a3] "=&v"(a3),')
     w('        [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [t4] "=&v"(t4)')
     w('      : [kg] "s"(kg), [vg] "s"(vg), [nt] "s"(nt), [kf0] "v"(kf0), [kf1] "v"(kf1), [vrel] "v"(vrel), [koff] "v"(koff), [voff] "v"(voff),')
-    w('        [c] "s"(c), [kdst] "s"(kdst), [vdst] "s"(vdst), [kstep] "s"(kstep), [vstep] "s"(vstep), [klim] "s"(klim), [vlim] "s"(vlim)')
+    w('        [kdst] "s"(kdst), [vdst] "s"(vdst), [kstep] "s"(kstep), [vstep] "s"(vstep), [klim] "s"(klim), [vlim] "s"(vlim)')
     w('      : "memory", "scc", "vcc", ' + ", ".join(f'"{r}"' for r in SGPR_CLOBBERS) + ");")
     w("}")
     w("")
@@ -397,15 +391,22 @@ def emit():
     w("// clang-format off")
     w(f"#define H64X_COMPILER_VGPRS {COMPILER_VGPRS}   // the kernel carries __attribute__((amdgpu_num_vgpr(H64X_COMPILER_VGPRS)))")
     w("")
-    w("// Q: 4 query blocks x 2 slabs of 32 dims; lane (c, g) holds query 16 qb + c, dims 32 ks + 8 g .. + 7")
-    w("// (one wave-uniform base + a 32-bit byte offset per query block: 4 VGPRs of the compiler's 28 instead of 8)")
-    w("__device__ __forceinline__ void h64x_load_q(const _Float16* base, unsigned q0, unsigned q1, unsigned q2, unsigned q3) {")
+    w("// Q: 4 query blocks x 2 slabs of 32 dims; lane (c, g) holds query 16 qb + c, dims 32 ks + 8 g .. + 7; scaled by c in fp32")
+    w("// (one wave-uniform base + a 32-bit byte offset per query block)")
+    w("__device__ __forceinline__ void h64x_load_q(const _Float16* base, unsigned q0, unsigned q1, unsigned q2, unsigned q3, float c) {")
+    w("  float t0, t1;")
     w("  asm volatile(")
     for qb in range(4):
         for ks in range(2):
             w(f'      "global_load_dwordx4 {qreg(qb, ks)}, %[q{qb}], %[base] offset:{64 * ks}\\n\\t"')
-    w('      "s_waitcnt vmcnt(0)"')
-    w('      : : [base] "s"(base), [q0] "v"(q0), [q1] "v"(q1), [q2] "v"(q2), [q3] "v"(q3) : "memory", "v159", "a63");   // the clobbers: 160 VGPRs + 64 AGPRs per wave')
+    w('      "s_waitcnt vmcnt(0)\\n\\t"')
+    for r in range(Q0, Q0 + 32):
+        w(f'      "v_cvt_f32_f16_e32 %[t0], v{r}\\n\\tv_cvt_f32_f16_sdwa %[t1], v{r} dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\\n\\t"')
+        w(f'      "v_mul_f32_e32 %[t0], %[c], %[t0]\\n\\tv_mul_f32_e32 %[t1], %[c], %[t1]\\n\\tv_cvt_pk_f16_f32 v{r}, %[t0], %[t1]\\n\\t"')
+    w('      "s_nop 0"')
+    w('      : [t0] "=&v"(t0), [t1] "=&v"(t1)')
+    w('      : [base] "s"(base), [q0] "v"(q0), [q1] "v"(q1), [q2] "v"(q2), [q3] "v"(q3), [c] "s"(c)')
+    w('      : "memory", "v175", "a63");   // the clobbers: 176 VGPRs + 64 AGPRs per wave')
     w("}")
     w("")
     w("__device__ __forceinline__ void h64x_zero_o() {")
@@ -423,11 +424,11 @@ def emit():
     w('      : "memory");')
     w("}")
     w("")
-    w("__device__ __forceinline__ void h64x_prologue_units(unsigned kf0, unsigned kf1, float c, float m0, float m1, float m2, float m3) {")
+    w("__device__ __forceinline__ void h64x_prologue_units(unsigned kf0, unsigned kf1, float m0, float m1, float m2, float m3) {")
     w("  asm volatile(")
     w(prologue_units().text())
     w('      :')
-    w('      : [kf0] "v"(kf0), [kf1] "v"(kf1), [c] "s"(c), [m0] "v"(m0), [m1] "v"(m1), [m2] "v"(m2), [m3] "v"(m3)')
+    w('      : [kf0] "v"(kf0), [kf1] "v"(kf1), [m0] "v"(m0), [m1] "v"(m1), [m2] "v"(m2), [m3] "v"(m3)')
     w('      : "memory");')
     w("}")
     w("")
