@@ -1836,8 +1836,11 @@ static unsigned long long* g_attn_stamps = nullptr;
 extern "C" int dvd_attn_debug_stamps(void* dev_u64) { g_attn_stamps = (unsigned long long*)dev_u64; return DVD_OK; }
 #endif
 
-// 64 query rows per wave (256 per workgroup) from this many query rows on: a (batch, head) then has >= 22 workgroups of
-// its own.  The choice depends on the problem's SHAPE only (head_dim, tq, tk) - never on the batch - so a document
+// 64 query rows per wave (256 per workgroup) from this many query rows on: a (batch, head) then has >= 21 workgroups of
+// its own, so that ONE document (two samples) already fills the 256 CUs.  At 16 samples the generated kernels also win
+// below it (profiles/r4_attn_midsize_threshold.txt: head_dim 256 +12 .. 38 % from T = 1024 on, head_dim 64 +5 .. 17 % from
+// T = 2304 on), but with one document their 256-row workgroups would leave half of the CUs idle - and the choice must not
+// depend on the batch.  The choice depends on the problem's SHAPE only (head_dim, tq, tk) - never on the batch - so a document
 // takes the same kernel, and the same online-softmax tile order, alone or in a batch (bit-identical results).
 static constexpr int R64_MIN_TQ = 5376;
 
