@@ -13,8 +13,7 @@
 //
 // The epilogue replaces what the reference does in separate ATen ops after each Linear:
 // bias, GELU(tanh) / ReLU, positional-embedding add, adaLN gate, residual add, f16/f32 stores.
-#include "common.h"
-#include "mfma.h"
+#include "gemm_common.h"
 #include <stdlib.h>
 #include <type_traits>
 
@@ -26,86 +25,6 @@
 #endif
 
 namespace dvd {
-
-struct GemmArgs {
-  const void* A;      // [M,K] lda
-  const void* B;      // [N,K] ldb
-  const void* Blo;    // optional low part of a split weight: B_true = B + lo_scale * Blo (same layout as B)
-  const void* Alo;    // ... or on the A side (swapped GEMMs put the weight in A); at most one of the two
-  float lo_scale;
-  float* C32;         // optional [M,N] ldc
-  _Float16* C16;      // optional [M,N] ldc16
-  const float* bias;  // optional, per column (bias_row = 0) or per row (bias_row = 1)
-  const float* res;   // optional residual [M,N] ldres (fp32), added last
-  const float* gate;  // optional [M / gate_rows, N] ldgate: out = gate * (acc + bias)
-  const float* pos;   // optional [pos_rows, N] ldpos: out += pos[row % pos_rows]
-  long sA, sB, sC32, sC16, sBias, sRes, sGate;  // batch strides in elements (blockIdx.y)
-  int M, N, K;
-  int lda, ldb, ldc, ldc16, ldres, ldgate, ldpos;
-  int gate_rows, pos_rows;
-  int act;       // 0 none, 1 GELU(tanh), 2 ReLU
-  int bias_row;  // bias indexed by row instead of column
-  int ntm, ntn;  // tile counts
-  int stagger;       // large-tile kernel: start-up delay quantum (x4096 cycles) of the first round of workgroups
-  int vec_epilogue;  // 1: LDS-staged row-contiguous stores (needs N % 8 == 0 and 16-byte aligned rows)
-  int debug;     // timing ablations only (DVD_GEMM_DEBUG): 1 = no operand loads in the K loop, 2 = no MFMAs,
-                 // 3 = per-wave s_memtime stamps (start, first tile landed, K loop done, epilogue done) -> stamps
-  unsigned long long* stamps;
-};
-
-// Tile walk of the persistent kernels.  Virtual id `vid` runs on XCD vid % 8 (hardware round-robin) as that XCD's k-th
-// tile, k = vid / 8; an XCD owns a contiguous range of row panels.  At any time an XCD's 32 CUs work on 32 consecutive k.
-//  * default: row-major inside the XCD's range - the 32 tiles cover ~32/ntn row panels x all N tiles, so per 32 tiles the
-//    XCD's 4 MB L2 sees (32/ntn) A panels + ntn W panels;
-//  * few row panels (ntm < 8) and many N tiles: column-major (see below);
-//  * wide outputs (ntn a multiple of 4, >= 8; needs ntm % 8 == 0): blocks of 8 row panels x 4 N tiles - 8 A panels (0.79 MB
-//    each at K = 1536) + 4 W panels (1.57 MB each, hi + lo), the minimum of a_bytes * rows + w_bytes * cols at rows * cols
-//    = 32; at N = 3072 the row-major walk streamed all 12 W panels (18.9 MB) through L2 for every 32 tiles.
-// The order changes which workgroup computes a tile, never a tile's arithmetic.
-__device__ __forceinline__ void tile_coords(int vid, int ntm, int ntn, int& tm, int& tn) {
-  const int nwg = ntm * ntn;
-  const int q = nwg / 8, rr = nwg % 8, xcd = vid % 8, k = vid / 8;
-  if (rr == 0 && (ntm & 7) == 0 && (ntn & 3) == 0 && ntn >= 8) {
-    const int rows = ntm >> 3;               // row panels per XCD
-    const int grp = 8 * ntn;                 // tiles in a group of 8 row panels (a multiple of 32)
-    const int g = k / grp, rem = k - g * grp;
-    if (g < (rows >> 3)) {
-      const int b = rem >> 5, i = rem & 31;
-      tm = xcd * rows + g * 8 + (i & 7);
-      tn = 4 * b + (i >> 3);
-    } else {                                 // the last rows % 8 row panels of the XCD: row-major
-      const int k2 = k - (rows >> 3) * grp;
-      tm = xcd * rows + (rows & ~7) + k2 / ntn;
-      tn = k2 % ntn;
-    }
-    return;
-  }
-  const int id = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + k;
-  if (ntm < 8 && ntn >= 32) {      // few row panels, many N tiles (the V^T projections: weights on the A side, M = 1536):
-    tn = id / ntm;                 // column-major - the 32 tiles an XCD works on share ALL ntm A panels and 32 / ntm B
-    tm = id % ntm;                 // panels (9 MB at ntm = 6) instead of one A panel and 32 B panels (26 MB)
-    return;
-  }
-  tm = id / ntn;
-  tn = id % ntn;
-}
-
-
-// GELU(tanh) (timm Mlp's act layer, idf/cross_model.py:163-174):  0.5 x (1 + tanh u) = x sigmoid(2 u) = x / (1 + exp(-2 u)),
-// u = k0 (x + k1 x^3).  Written with ONE exponential and one reciprocal (v_exp_f32 / v_rcp_f32, ~1 ulp each: 1e-7 relative
-// on a value that is then rounded to f16) instead of tanhf, whose library expansion is ~4x the instructions and a branch:
-// fc1's epilogue applies it to 2 G elements per evaluation and was half of that GEMM's 3.8 ms (K = 384: six K slabs per
-// tile).  Range: for x <= -10.5 the tanh form is exactly -0 in fp32 arithmetic (1 + tanh u rounds to 0) while
-// exp(-2u) overflows here (x / inf = -0 for finite x, but -inf / inf would be NaN), so that range returns -0 explicitly -
-// also at -inf, where torch's own formula 0.5 x (1 + tanh u) evaluates -inf * 0 = NaN (no finite activation gets there);
-// x -> +inf gives x, NaN propagates.  tests/test_gpu_gemm.py::test_gelu_epilogue_range checks [-12, 12], the exp-overflow
-// region and +-1e4 / +inf against torch's gelu(approximate='tanh').
-__device__ __forceinline__ float gelu_tanh(float x) {
-  const float k0 = 0.7978845608028654f, k1 = 0.044715f;
-  const float u = k0 * (x + k1 * x * x * x);
-  const float y = __fdividef(x, 1.f + __expf(-2.f * u));
-  return x < -10.5f ? -0.f : y;
-}
 
 // Epilogue of one 32x32 accumulator tile (rows row0 + cd_row(i,h), column col).  Kept as a function so the
 // callers' tile loops stay small enough to be fully unrolled (a partially unrolled epilogue indexes the
@@ -599,7 +518,8 @@ __device__ __forceinline__ void glds_group4(const char* gbase, const unsigned (&
       : "memory", "scc");
 }
 
-template <int DBG>   // DBG: timing ablations (DVD_GEMM_DEBUG) 1 = no operand loads in the K loop, 2 = no MFMAs
+template <int DBG>   // DBG: timing ablations (DVD_GEMM_DEBUG) 1 = no operand loads in the K loop, 2 = no MFMAs, 5 = no fragment
+                     // reads inside a slab, 6 = no end-of-slab wait + barrier, 7 = MFMAs only (1 + 5 + 6): profiles/r5_gemm_ablation.txt
 __global__ void __launch_bounds__(512, 2) gemm_nt_big_kernel(GemmArgs p) {
   constexpr int BK = 64, TILE = 256 * 128;   // bytes of one operand tile (256 rows x 64 halfs)
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 stages][A | B]
@@ -701,7 +621,7 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_big_kernel(GemmArgs p) {
   for (int kt = 0; kt < nk; ++kt) {
     // waves 0-3 (one per SIMD) issue their burst here, waves 4-7 after the first of the four k-steps: the two waves of
     // a SIMD then do not sit in their issue stalls at the same time
-    if (!SPREAD && DBG != 1 && kt + 1 < nk && wave < 4) BIG_ISSUE(kt + 1, cur ^ 1)
+    if (!SPREAD && DBG != 1 && DBG != 7 && kt + 1 < nk && wave < 4) BIG_ISSUE(kt + 1, cur ^ 1)
     const int tnx = min(kt + 1, nk - 1);
     const bool lo_nx = tnx < nlo;
     const size_t kb_nx = (size_t)(lo_nx ? tnx : tnx - nlo) * (BK * 2);
@@ -717,6 +637,7 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_big_kernel(GemmArgs p) {
     }
     half8 fa[2][4], fb[2][2];
     LDFRAG(0, 0)
+    if constexpr (DBG == 5 || DBG == 7) { LDFRAG(1, 1) }   // ablation: both register sets filled once per slab, none inside
     SB();
 #pragma unroll
     for (int s4 = 0; s4 < 4; ++s4) {
@@ -726,7 +647,7 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_big_kernel(GemmArgs p) {
       for (int m = 0; m < 4; ++m) {
 #pragma unroll
         for (int n = 0; n < 2; ++n) acc[m][n] = mfma32_f16(fa[cs][m], fb[cs][n], acc[m][n]);
-        if (s4 < 3) {
+        if (s4 < 3 && DBG != 5 && DBG != 7) {
           fa[cs ^ 1][m] = *(const half8*)(base + a_base + m * 32 * 128 + frag[s4 + 1]);
           if (m < 2) fb[cs ^ 1][m] = *(const half8*)(base + b_base + m * 32 * 128 + frag[s4 + 1]);
         }
@@ -742,7 +663,7 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_big_kernel(GemmArgs p) {
         SB();
       }
       if (s4 == 0) {
-        if (!SPREAD && DBG != 1 && kt + 1 < nk && wave >= 4) BIG_ISSUE(kt + 1, cur ^ 1)
+        if (!SPREAD && DBG != 1 && DBG != 7 && kt + 1 < nk && wave >= 4) BIG_ISSUE(kt + 1, cur ^ 1)
         SB();
       }
     }
@@ -754,8 +675,10 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_big_kernel(GemmArgs p) {
 #pragma unroll
           for (int i = 0; i < 16; ++i) acc[m][n][i] *= p.lo_scale;
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    if constexpr (DBG != 6 && DBG != 7) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
     cur ^= 1;
   }
 #undef BIG_ISSUE
@@ -1598,10 +1521,10 @@ extern "C" int dvd_gemm_nt(const dvd_gemm_desc* d, void* stream) {
   p.stamps = g_gemm_stamps;
   const bool lab_scalar_epi = getenv("DVD_GEMM_SCALAR_EPILOGUE"), lab_v1 = getenv("DVD_GEMM_V1"),
              lab_twopass = getenv("DVD_GEMM_TWOPASS"), lab_nonpersistent = getenv("DVD_GEMM_NONPERSISTENT"),
-             lab_spread = getenv("DVD_GEMM_SPREAD");
+             lab_spread = getenv("DVD_GEMM_SPREAD"), lab_no_t384 = getenv("DVD_GEMM_NO_T384") || p.debug;
 #else
   p.debug = 0; p.stagger = 0; p.stamps = nullptr;
-  constexpr bool lab_scalar_epi = false, lab_v1 = false, lab_twopass = false, lab_nonpersistent = false;
+  constexpr bool lab_scalar_epi = false, lab_v1 = false, lab_twopass = false, lab_nonpersistent = false, lab_no_t384 = false;
 #endif
   {
     auto al = [](const void* q, size_t a) { return ((uintptr_t)q % a) == 0; };
@@ -1702,6 +1625,16 @@ extern "C" int dvd_gemm_nt(const dvd_gemm_desc* d, void* stream) {
     return check_launch("gemm_nt(big2)");
   }
 #endif
+  if (big && !d->B_lo && !d->A_lo && !small_many && p.vec_epilogue && !d->pos && !d->gate && !(d->bias && d->bias_row) &&
+      !(d->res && d->act == 1) && d->K % 128 == 0 && d->K >= 256 && !lab_no_t384) {
+    // round 5: 384 x 256 tiles, 4-slot half-slab ring, generated K loop; bit-identical to gemm_nt_big_kernel
+    p.ntm = cdiv(d->M, 384); p.ntn = d->N / 256;
+    int tdbg = 0;
+#ifdef DVD_LAB
+    if (const char* e = getenv("DVD_GEMM_T384_DBG")) tdbg = atoi(e);
+#endif
+    return launch_gemm_t384(p, d->batch, tdbg, stream);
+  }
   if (big) {
     p.ntm = cdiv(d->M, 256); p.ntn = d->N / 256;
     constexpr int LDS = 2 * 2 * 256 * 128;
@@ -1713,6 +1646,9 @@ extern "C" int dvd_gemm_nt(const dvd_gemm_desc* d, void* stream) {
       (void)hipFuncSetAttribute((const void*)gemm_nt_big_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
       (void)hipFuncSetAttribute((const void*)gemm_nt_big_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
       (void)hipFuncSetAttribute((const void*)gemm_nt_big_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+      (void)hipFuncSetAttribute((const void*)gemm_nt_big_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+      (void)hipFuncSetAttribute((const void*)gemm_nt_big_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+      (void)hipFuncSetAttribute((const void*)gemm_nt_big_kernel<7>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
 #endif
       once.done(bit);
     }
@@ -1723,6 +1659,9 @@ extern "C" int dvd_gemm_nt(const dvd_gemm_desc* d, void* stream) {
     if (p.debug == 1) gemm_nt_big_kernel<1><<<gridb, 512, LDS, (hipStream_t)stream>>>(p);
     else if (p.debug == 2) gemm_nt_big_kernel<2><<<gridb, 512, LDS, (hipStream_t)stream>>>(p);
     else if (p.debug == 3) gemm_nt_big_kernel<3><<<gridb, 512, LDS, (hipStream_t)stream>>>(p);
+    else if (p.debug == 5) gemm_nt_big_kernel<5><<<gridb, 512, LDS, (hipStream_t)stream>>>(p);
+    else if (p.debug == 6) gemm_nt_big_kernel<6><<<gridb, 512, LDS, (hipStream_t)stream>>>(p);
+    else if (p.debug == 7) gemm_nt_big_kernel<7><<<gridb, 512, LDS, (hipStream_t)stream>>>(p);
     else if (lab_spread) gemm_nt_big_kernel<4><<<gridb, 512, LDS, (hipStream_t)stream>>>(p);
     else
 #endif

@@ -399,3 +399,68 @@ def test_gemm_small_family_many_rows_same_bits(ops, side):
     want = (a.double() @ w.double().t())
     got = o32.cpu().double() - (res.double() if side == "B" else 0)
     assert ((got if side == "B" else got.t()) - want).abs().max().item() < 2e-5
+
+
+@pytest.mark.parametrize("M,N,K", [(1536, 1536, 1536), (1100, 512, 256), (2304, 3072, 1536), (777, 256, 384), (4000, 2048, 1536),
+                                   (1152, 1536, 2048), (384, 256, 256), (5, 768, 384)])
+def test_gemm_t384_kernel(ops, lab, monkeypatch, M, N, K):
+    """Round 5's 384 x 256 kernel (gemm_nt_t384_kernel: 4-slot half-slab ring, generated K loop; N % 256 == 0, K % 128 == 0,
+    K >= 256) on full and ragged row tiles (M % 384 != 0, M < one tile), the ring's shortest K (first + final block only) and the
+    steady loop: exact integers, random data vs float64, plain / bias + ReLU -> f16 / bias + GELU -> f16 / residual / bias +
+    ReLU + residual (in place) epilogues - and THE SAME BITS as gemm_nt_big_kernel (lab switch DVD_GEMM_NO_T384), which runs
+    the same MFMA sequence per accumulator and the same epilogue arithmetic."""
+    rng = np.random.RandomState(M + N + K)
+    ai = torch.from_numpy(rng.randint(-4, 5, (M, K)).astype(np.float32)).half()
+    bi = torch.from_numpy(rng.randint(-4, 5, (N, K)).astype(np.float32)).half()
+    out = torch.full((M, N), 7.0, device="cuda")
+    ops.gemm_nt(ai.cuda(), bi.cuda(), out32=out)
+    assert torch.equal(out.cpu(), ai.float() @ bi.float().t())
+    a, b = rnd(f"t3a{M}{K}", (M, K)).half().cuda(), rnd(f"t3b{N}{K}", (N, K)).half().cuda()
+    bias, res = rnd("t3bias", (N,)).cuda(), rnd("t3res", (M, N)).cuda()
+    ref = a.cpu().double() @ b.cpu().double().t()
+
+    def run_all():
+        o32 = torch.zeros(M, N, device="cuda")
+        ops.gemm_nt(a, b, out32=o32)
+        o16 = torch.zeros(M, N, dtype=torch.float16, device="cuda")
+        ops.gemm_nt(a, b, out16=o16, bias=bias, act=2)
+        g16 = torch.zeros(M, N, dtype=torch.float16, device="cuda")
+        ops.gemm_nt(a, b, out16=g16, bias=bias, act=1)
+        r32 = res.clone()
+        ops.gemm_nt(a, b, out32=r32, res=r32)
+        br32 = res.clone()
+        ops.gemm_nt(a, b, out32=br32, bias=bias, act=2, res=br32)
+        both = torch.zeros(M, N, device="cuda")
+        both16 = torch.zeros(M, N, dtype=torch.float16, device="cuda")
+        ops.gemm_nt(a, b, out32=both, out16=both16, bias=bias)
+        torch.cuda.synchronize()
+        return [t.cpu() for t in (o32, o16, g16, r32, br32, both, both16)]
+
+    new = run_all()
+    tol = 1e-4 * K ** 0.5
+    assert (new[0].double() - ref).abs().max().item() < tol
+    assert (new[1].double() - torch.relu(ref + bias.cpu().double())).abs().max().item() < 4e-2
+    assert (new[2].double() - torch.nn.functional.gelu(ref + bias.cpu().double(), approximate="tanh")).abs().max().item() < 4e-2
+    assert (new[3].double() - (ref + res.cpu().double())).abs().max().item() < tol + 1e-5
+    assert (new[4].double() - (torch.relu(ref + bias.cpu().double()) + res.cpu().double())).abs().max().item() < tol + 1e-5
+    assert (new[5].double() - (ref + bias.cpu().double())).abs().max().item() < tol + 1e-5
+    monkeypatch.setenv("DVD_GEMM_NO_T384", "1")
+    old = run_all()
+    for i, (x, y) in enumerate(zip(new, old)):
+        assert torch.equal(x, y), f"output {i}: t384 and the 256 x 256 kernel must give the same bits"
+
+
+def test_gemm_t384_batched_weights_on_a_side(ops, lab, monkeypatch):
+    """The decoder's V^T projection form: weights on the A side (M = 1536 = 4 row tiles of 384), one batch entry per sample,
+    N = tokens (a multiple of 256), f16 output with ldc = tokens; and an odd steady-loop count (K = 640)."""
+    Bn, M, N, K = 3, 1536, 1280, 640
+    w = rnd("t3vw", (M, K)).half().cuda()
+    x = rnd("t3vx", (Bn, N, K)).half().cuda()
+    out = torch.zeros(Bn, M, N, dtype=torch.float16, device="cuda")
+    ops.gemm_nt(w, x, out16=out, batch=Bn, N=N, strides={"B": N * K, "C16": M * N})
+    ref = torch.einsum("mk,bnk->bmn", w.cpu().double(), x.cpu().double())
+    assert (out.cpu().double() - ref).abs().max().item() < 4e-2
+    monkeypatch.setenv("DVD_GEMM_NO_T384", "1")
+    old = torch.zeros_like(out)
+    ops.gemm_nt(w, x, out16=old, batch=Bn, N=N, strides={"B": N * K, "C16": M * N})
+    assert torch.equal(out.cpu(), old.cpu())
