@@ -1538,8 +1538,11 @@ extern "C" int dvd_gemm_nt(const dvd_gemm_desc* d, void* stream) {
     p.vec_epilogue = ok ? 1 : 0;
   }
   // large-tile kernel for the big f16 GEMMs (decoder): N a multiple of 256, at least a few row tiles
-  // kernel choice depends on (dtype, N, K, split) only, never on M: a document then takes the same kernels - and the
-  // same fp32 summation order - whether it is sampled alone or in a batch (bit-identical results, tested)
+  // A document must get the same bits whether it is sampled alone or in a batch.  Two ways this holds here: (a) within a
+  // problem family the kernel is chosen from (dtype, N, K, split) only, never from M - same kernel, same fp32 summation order;
+  // (b) where the choice DOES follow the row count (small_tiles 1 vs 2 below: the engine switches at 16 384 token rows; the
+  // 384 x 256 kernel of round 5 vs gemm_nt_big_kernel), the kernels on both sides accumulate every output in the same MFMA
+  // sequence and run the same epilogue arithmetic - bit-identical by construction, and tested as such (tests/test_gpu_gemm.py).
   // small_tiles 1: the caller's problem family is small: 128x128 tiles everywhere.  small_tiles 2: the same family with MANY
   // rows (a large batch of small grids): shapes with N % 256 == 0 take the 256x256 kernel in its TWO-SWEEP form - low parts
   // first, scale, high parts, k ascending in 16-deep MFMA steps: exactly the 128x128 kernel's accumulation sequence, so a

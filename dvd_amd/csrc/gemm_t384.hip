@@ -143,12 +143,140 @@ __device__ __forceinline__ void epilogue(const GemmArgs& p, float* stage, const 
   block<EPI, 4>(p, sa, sbias, acc[8], acc[9], row_w, col_w, lane, C32, C16, res, hb, rs0, rs1);
   block<EPI, 5>(p, sb, sbias, acc[10], acc[11], row_w, col_w, lane, C32, C16, res, hb, rs0, rs1);
 }
+
+// ---- fast epilogue 1: f32 output (optional residual, optional ReLU / bias), NO LDS.  Register i of a 32 x 32 accumulator is
+// one row per lane half and 32 consecutive columns across the lanes: a global_store_dword of it writes two full 128-byte
+// row segments (MI355X_MICROARCH.md: "two 128-B segments in two rows: full rate"), the residual is read the same way.  The
+// residual of tile t + 1 is requested before tile t's stores are issued (vmcnt counts stores and retires in order).
+// Arithmetic per element as in epilogue_readback: ((acc + bias) + 0), ReLU, + residual.
+typedef __attribute__((address_space(1))) float gfloat;
+typedef __attribute__((address_space(1))) char gchar;
+
+template <bool RES, bool FULL>
+__device__ __forceinline__ void direct_f32(const GemmArgs& p, const floatx16 (&acc)[12], int row_w, int col_w, int lane, float* C32,
+                                           const float* bias, const float* res) {
+  const int r = lane & 31, h = lane >> 5;
+  float bv[4] = {0.f, 0.f, 0.f, 0.f};
+  if (bias) {
+#pragma unroll
+    for (int n = 0; n < 4; ++n) bv[n] = bias[col_w + 32 * n + r];
+  }
+  const bool relu = p.act == 2, hb = bias != nullptr;
+  // every address = wave-uniform base of the half tile (SGPR pair) + one of 8 per-lane 32-bit offsets (rows 4 h + {0..3, 8..11},
+  // column r) that are the same for all 24 half tiles: global_load/store_dword v, v_off, s[base]
+  unsigned oc[8], orr[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int ro = 4 * h + (k & 3) + 8 * (k >> 2);
+    oc[k] = (unsigned)(ro * p.ldc + r) * 4u;
+    orr[k] = (unsigned)(ro * p.ldres + r) * 4u;
+  }
+  const gchar* cb = (const gchar*)uniform_ptr((const char*)(C32 + (size_t)row_w * p.ldc + col_w));
+  const gchar* rb = RES ? (const gchar*)uniform_ptr((const char*)(res + (size_t)row_w * p.ldres + col_w)) : nullptr;
+  const int rows_left = p.M - row_w - 4 * h;          // rows of this lane half that exist (ragged last row tile)
+  // half tiles (registers 8 u .. 8 u + 7 of accumulator t): 24 steps; the residual of step s + 2 is requested before step s stores
+  // (waiting for a load also waits for every OLDER store: two steps of slack for their acknowledgements)
+  float rv[3][8];
+  auto load_res = [&](int s, float (&dst)[8]) {
+    const int t = s >> 1, u = s & 1, m = t >> 2, n = t & 3;
+    const gchar* sb = rb + ((size_t)(32 * m + 16 * u) * p.ldres + 32 * n) * 4;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int ro = 32 * m + 16 * u + (k & 3) + 8 * (k >> 2);
+      dst[k] = (FULL || ro < rows_left) ? *(const gfloat*)(sb + (size_t)orr[k]) : 0.f;
+    }
+  };
+  if constexpr (RES) { load_res(0, rv[0]); load_res(1, rv[1]); }
+#pragma unroll
+  for (int s = 0; s < 24; ++s) {
+    const int t = s >> 1, u = s & 1, m = t >> 2, n = t & 3;
+    __builtin_amdgcn_sched_barrier(0);     // one half tile at a time: the scheduler must not pull all the read-outs forward
+    if constexpr (RES) {
+      if (s + 2 < 24) load_res(s + 2, rv[(s + 2) % 3]);
+    }
+    float v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {                 // (no `+ 0.f`: an accumulator that starts at +0 is never -0; bv = 0 without a bias)
+      float x = acc[t][8 * u + k] + bv[n];
+      x = relu ? fmaxf(x, 0.f) : x;
+      if constexpr (RES) x += rv[s % 3][k];
+      v[k] = x;
+    }
+    gchar* sb = const_cast<gchar*>(cb) + ((size_t)(32 * m + 16 * u) * p.ldc + 32 * n) * 4;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int ro = 32 * m + 16 * u + (k & 3) + 8 * (k >> 2);
+      if (FULL || ro < rows_left) *(gfloat*)(sb + (size_t)oc[k]) = v[k];
+    }
+  }
+}
+
+// ---- fast epilogue 2: f16 output only (bias, ReLU / GELU), NO LDS either.  Bias, activation and the f16 rounding happen in
+// the accumulator layout (a lane = one column); neighbouring lanes then trade one value per register PAIR through a DPP
+// quad permute, so that an even lane holds (row a: columns r, r + 1) and its odd neighbour (row a + 1: columns r - 1, r) as
+// one packed dword each: a global_store_dword writes four 64-byte row segments, 8 stores per 32 x 32 accumulator.
+template <bool FULL>
+__device__ __forceinline__ void packed_f16(const GemmArgs& p, const floatx16 (&acc)[12], int row_w, int col_w, int lane,
+                                           _Float16* C16, const float* bias) {
+  const int r = lane & 31, h = lane >> 5;
+  const bool odd = r & 1;
+  float bv[4] = {0.f, 0.f, 0.f, 0.f};
+  if (bias) {
+#pragma unroll
+    for (int n = 0; n < 4; ++n) bv[n] = bias[col_w + 32 * n + r];
+  }
+  const int act = p.act;
+  const bool hb = bias != nullptr;
+  // per-lane byte offsets of the 8 packed registers of a tile (register pair (2 j, 2 j + 1) = rows a, a + 1): the same for all tiles
+  unsigned oc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) oc[j] = (unsigned)((cd_row(2 * j, h) + (odd ? 1 : 0)) * p.ldc16 + (r & ~1)) * 2u;
+  const gchar* cb = (const gchar*)uniform_ptr((const char*)(C16 + (size_t)row_w * p.ldc16 + col_w));
+  const int rows_left = p.M - row_w;
+#pragma unroll
+  for (int t = 0; t < 12; ++t) {
+    const int m = t >> 2, n = t & 3;
+    __builtin_amdgcn_sched_barrier(0);     // one accumulator at a time: the scheduler must not pull all twelve read-outs forward
+    // (the old kernel's `+ 0.f`s are dropped: an accumulator that starts at +0 is never -0, so they change no bit)
+    float v[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) v[i] = acc[t][i] + bv[n];      // bv = 0 without a bias: x + 0 = x for every x that is not -0
+    if (act == 1) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) v[i] = gelu_tanh(v[i]);
+    }
+    if (act == 2) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) v[i] = fmaxf(v[i], 0.f);
+    }
+    gchar* sb = const_cast<gchar*>(cb) + ((size_t)(32 * m) * p.ldc16 + 32 * n) * 2;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      // an odd lane takes its left neighbour's value of the odd row, an even lane its right neighbour's of the even row
+      // (quad permutes (0,0,2,2) / (1,1,3,3): the compiler folds each into the v_cndmask that selects by lane parity)
+      const float from_left = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v[2 * j + 1]), 0xA0, 0xF, 0xF, true));
+      const float from_right = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v[2 * j]), 0xF5, 0xF, 0xF, true));
+      const half2v pk = {(_Float16)(odd ? from_left : v[2 * j]), (_Float16)(odd ? v[2 * j + 1] : from_right)};
+      const int ro = 32 * m + cd_row(2 * j, h) + (odd ? 1 : 0);
+      if (FULL || ro < rows_left) *(__attribute__((address_space(1))) unsigned*)(sb + (size_t)oc[j]) = __builtin_bit_cast(unsigned, pk);
+    }
+  }
+}
 }  // namespace t384
 
-template <int DBG>   // lab: 1 no LDS-DMA in the loop, 2 no fragment reads, 3 no barrier, 4 MFMAs only, 5 s_memtime stamps
+// FL: the epilogue compiled into this instance (one per instance keeps the function small and its registers un-spilled):
+//   0 f16 output only: packed_f16       1 f32 output only: direct_f32       2 f32 output only + residual: direct_f32
+//   3 anything else without residual: the staged generic path       4 ... with residual
+// FULL: M % 384 == 0, no row masks.  DBG (lab): 1 no LDS-DMA in the loop, 2 no fragment reads, 3 no barrier, 4 MFMAs only,
+// 5 s_memtime stamps
+template <int DBG, int FL, bool FULL>
 __global__ void __launch_bounds__(512, 2) gemm_nt_t384_kernel(GemmArgs p) {
   using namespace t384;
-  extern __shared__ __attribute__((aligned(1024))) char smem[];   // 4 x [A half slab | B half slab]; then the epilogue's staging
+  // XT: the ring never drains between the tiles of a workgroup (gen_gemm_t384.py, loop_stmt(xt=True)): the next tile's first
+  // three half slabs land while this tile's epilogue runs.  Needs an epilogue that leaves LDS alone (FL 0-2) and per-lane DMA
+  // offsets that do not depend on the tile (no clamped rows: FULL).
+  constexpr bool XT = FULL && FL <= 2;
+  extern __shared__ __attribute__((aligned(1024))) char smem[];   // 4 x [A half slab | B half slab]; (FL 3, 4: then the staging)
   typedef __attribute__((address_space(3))) void* lptr_t;
   const int nwg = p.ntm * p.ntn;
   const int z = blockIdx.y;
@@ -157,6 +285,10 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_t384_kernel(GemmArgs p) {
   const int wr = wave >> 1, wc = wave & 1;
   const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t)smem;
   const int nloop = p.K / 128 - 2;
+  const _Float16* A = (const _Float16*)p.A + z * p.sA;
+  const _Float16* B = (const _Float16*)p.B + z * p.sB;
+  const unsigned pda = lds0 + (3 * wave) * 1024, pdb = lds0 + BOFF + (2 * wave) * 1024;
+  bool first = true;
   for (int vid = blockIdx.x; vid < nwg; vid += gridDim.x) {
     int tm, tn;
     tile_coords(vid, p.ntm, p.ntn, tm, tn);
@@ -168,57 +300,81 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_t384_kernel(GemmArgs p) {
 #endif
     floatx16 acc[12];
     {
-      const _Float16* A = (const _Float16*)p.A + z * p.sA;
-      const _Float16* B = (const _Float16*)p.B + z * p.sB;
       // per-lane source offsets of the wave's 3 + 2 pieces of a half slab: piece = 16 rows x 64 B, LDS slot (row, pos = lane & 3)
-      // <- chunk pos ^ ((row >> 2) & 3); rows clamped into the matrix (ragged last tiles)
+      // <- chunk pos ^ ((row >> 2) & 3); rows clamped into the matrix (ragged last tiles; FULL: no row is ever clamped)
+      // (everything per-lane is derived here from a laundered lane id: hoisted out of the tile loop it would stay live across
+      //  the epilogue, which has no register to spare)
+      int lane_l = lane;
+      asm volatile("" : "+v"(lane_l));
+#define lane lane_l
+      // fragment read bases in slot 0: row r of the wave's first 32-row block, chunk (2 s + h) ^ ((r >> 2) & 3)
+      const unsigned ch = (unsigned)((((lane >> 5) ^ (((lane & 31) >> 2) & 3))) * 16);
+      const unsigned fa0 = lds0 + (96 * wr + (lane & 31)) * 64 + ch, fa1 = fa0 ^ 32;
+      const unsigned fb0 = lds0 + BOFF + (128 * wc + (lane & 31)) * 64 + ch, fb1 = fb0 ^ 32;
       unsigned va[3], vb[2];
       const int pos = lane & 3;
 #pragma unroll
       for (int i = 0; i < 3; ++i) {
         const int row = 16 * (3 * wave + i) + (lane >> 2);
-        const int ra = min(bm0 + row, p.M - 1) - bm0;
+        const int ra = FULL ? row : min(bm0 + row, p.M - 1) - bm0;
         va[i] = (unsigned)ra * (unsigned)(p.lda * 2) + (pos ^ ((row >> 2) & 3)) * 16;
       }
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int row = 16 * (2 * wave + i) + (lane >> 2);
-        const int rb = min(bn0 + row, p.N - 1) - bn0;
-        vb[i] = (unsigned)rb * (unsigned)(p.ldb * 2) + (pos ^ ((row >> 2) & 3)) * 16;
+        vb[i] = (unsigned)row * (unsigned)(p.ldb * 2) + (pos ^ ((row >> 2) & 3)) * 16;     // N % 256 == 0: never clamped
       }
       const char* Atile = uniform_ptr((const char*)(A + (size_t)bm0 * p.lda));
       const char* Btile = uniform_ptr((const char*)(B + (size_t)bn0 * p.ldb));
-      const unsigned pda = lds0 + (3 * wave) * 1024, pdb = lds0 + BOFF + (2 * wave) * 1024;
-      // prologue: half slabs 0, 1, 2 -> slots 0, 1, 2
+      if (!XT || first) {
+        // prologue: half slabs 0, 1, 2 -> slots 0, 1, 2
 #pragma unroll
-      for (int j = 0; j < 3; ++j) {
+        for (int j = 0; j < 3; ++j) {
 #pragma unroll
-        for (int i = 0; i < 3; ++i) dma_piece(Atile + j * 64, va[i], pda + j * HALF + i * 1024);
+          for (int i = 0; i < 3; ++i) dma_piece(Atile + j * 64, va[i], pda + j * HALF + i * 1024);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) dma_piece(Btile + j * 64, vb[i], pdb + j * HALF + i * 1024);
+          for (int i = 0; i < 2; ++i) dma_piece(Btile + j * 64, vb[i], pdb + j * HALF + i * 1024);
+        }
+        asm volatile("s_waitcnt vmcnt(10)\n\ts_barrier" ::: "memory");      // half slab 0 has landed
+        first = false;
       }
-      // fragment read bases in slot 0: row r of the wave's first 32-row block, chunk (2 s + h) ^ ((r >> 2) & 3)
-      const int r = lane & 31, h = lane >> 5;
-      const unsigned ch = (unsigned)((h ^ ((r >> 2) & 3)) * 16);
-      const unsigned fa0 = lds0 + (96 * wr + r) * 64 + ch, fa1 = fa0 ^ 32;
-      const unsigned fb0 = lds0 + BOFF + (128 * wc + r) * 64 + ch, fb1 = fb0 ^ 32;
-      asm volatile("s_waitcnt vmcnt(10)\n\ts_barrier" ::: "memory");      // half slab 0 has landed
 #ifdef DVD_LAB
       if constexpr (DBG == 5) t1 = __builtin_amdgcn_s_memtime();
 #endif
 #define T384_ARGS acc, Atile + 3 * 64, Btile + 3 * 64, nloop, pda, pdb, va[0], va[1], va[2], vb[0], vb[1], fa0, fa1, fb0, fb1
+      if constexpr (XT) {
+        // the next tile of this workgroup (the last one re-loads its own first half slabs: valid addresses, never read)
+        const int vnext = vid + (int)gridDim.x < nwg ? vid + (int)gridDim.x : vid;
+        int tm2, tn2;
+        tile_coords(vnext, p.ntm, p.ntn, tm2, tn2);
+        tm2 = __builtin_amdgcn_readfirstlane(tm2); tn2 = __builtin_amdgcn_readfirstlane(tn2);
+        const char* Anext = uniform_ptr((const char*)(A + (size_t)tm2 * 384 * p.lda));
+        const char* Bnext = uniform_ptr((const char*)(B + (size_t)tn2 * 256 * p.ldb));
 #ifdef DVD_LAB
-      if constexpr (DBG == 1) t384_loop_nodma(T384_ARGS);
-      else if constexpr (DBG == 2) t384_loop_noread(T384_ARGS);
-      else if constexpr (DBG == 3) t384_loop_nobar(T384_ARGS);
-      else if constexpr (DBG == 4) t384_loop_mfmaonly(T384_ARGS);
-      else
+        if constexpr (DBG == 1) t384_loop_xt_nodma(T384_ARGS, Anext, Bnext);
+        else if constexpr (DBG == 2) t384_loop_xt_noread(T384_ARGS, Anext, Bnext);
+        else if constexpr (DBG == 3) t384_loop_xt_nobar(T384_ARGS, Anext, Bnext);
+        else if constexpr (DBG == 4) t384_loop_xt_mfmaonly(T384_ARGS, Anext, Bnext);
+        else
 #endif
-        t384_loop(T384_ARGS);
+          t384_loop_xt(T384_ARGS, Anext, Bnext);
+      } else {
+#ifdef DVD_LAB
+        if constexpr (DBG == 1) t384_loop_nodma(T384_ARGS);
+        else if constexpr (DBG == 2) t384_loop_noread(T384_ARGS);
+        else if constexpr (DBG == 3) t384_loop_nobar(T384_ARGS);
+        else if constexpr (DBG == 4) t384_loop_mfmaonly(T384_ARGS);
+        else
+#endif
+          t384_loop(T384_ARGS);
+      }
 #undef T384_ARGS
+#undef lane
     }
-    // every wave has read its last fragments: LDS becomes the epilogue's staging area
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if constexpr (!XT) {
+      // every wave has read its last fragments: LDS becomes the epilogue's staging area
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
 #ifdef DVD_LAB
     if constexpr (DBG == 5) t2 = __builtin_amdgcn_s_memtime();
 #endif
@@ -231,34 +387,53 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_t384_kernel(GemmArgs p) {
       const int lane_e = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
       float* stage = (float*)smem + wave * STAGE;
       const int row_w = bm0 + 96 * wr, col_w = bn0 + 128 * wc;
-      if (res) epilogue<1>(p, stage, acc, row_w, col_w, lane_e, C32, C16, bias, res);
-      else epilogue<0>(p, stage, acc, row_w, col_w, lane_e, C32, C16, bias, res);
+      if constexpr (FL == 0) packed_f16<FULL>(p, acc, row_w, col_w, lane_e, C16, bias);
+      else if constexpr (FL == 1) direct_f32<false, FULL>(p, acc, row_w, col_w, lane_e, C32, bias, res);
+      else if constexpr (FL == 2) direct_f32<true, FULL>(p, acc, row_w, col_w, lane_e, C32, bias, res);
+      else if constexpr (FL == 3) epilogue<0>(p, stage, acc, row_w, col_w, lane_e, C32, C16, bias, res);
+      else epilogue<1>(p, stage, acc, row_w, col_w, lane_e, C32, C16, bias, res);
     }
 #ifdef DVD_LAB
     if constexpr (DBG == 5) {
       const unsigned long long t3 = __builtin_amdgcn_s_memtime();
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      const unsigned long long t4 = __builtin_amdgcn_s_memtime();
       if (lane == 0 && p.stamps && vid < 256 * 64) {
         unsigned long long* o = p.stamps + ((size_t)vid * 8 + wave) * 8;
-        o[0] = t0; o[1] = t1; o[2] = t2; o[3] = t3; o[4] = t4; o[5] = t2; o[6] = t2; o[7] = t2;
+        o[0] = t0; o[1] = t1; o[2] = t2; o[3] = t3; o[4] = t3; o[5] = t2; o[6] = t2; o[7] = t2;
       }
     }
 #endif
-    __syncthreads();   // every wave has read its staging region back: the next tile's LDS-DMA may overwrite it
+    if constexpr (FL >= 3) __syncthreads();   // every wave has read its staging region back: the next tile's LDS-DMA may overwrite it
   }
+  // no LDS-DMA may land after the workgroup has ended (XT: the last tile's look-ahead pieces are still in flight)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+template <int DBG>
+static void launch_fl(const GemmArgs& p, int fl, bool full, dim3 grid, hipStream_t st) {
+#define T384_GO(FL_, FULL_) gemm_nt_t384_kernel<DBG, FL_, FULL_><<<grid, 512, t384::LDS_BYTES, st>>>(p)
+  if (full) {
+    switch (fl) { case 0: T384_GO(0, true); break; case 1: T384_GO(1, true); break; case 2: T384_GO(2, true); break;
+                  case 3: T384_GO(3, true); break; default: T384_GO(4, true); }
+  } else {
+    switch (fl) { case 0: T384_GO(0, false); break; case 1: T384_GO(1, false); break; case 2: T384_GO(2, false); break;
+                  case 3: T384_GO(3, false); break; default: T384_GO(4, false); }
+  }
+#undef T384_GO
+}
+template <int DBG>
+static void allow_lds() {
+#define T384_AL(FL_, FULL_) (void)hipFuncSetAttribute((const void*)gemm_nt_t384_kernel<DBG, FL_, FULL_>, hipFuncAttributeMaxDynamicSharedMemorySize, t384::LDS_BYTES)
+  T384_AL(0, true); T384_AL(1, true); T384_AL(2, true); T384_AL(3, true); T384_AL(4, true);
+  T384_AL(0, false); T384_AL(1, false); T384_AL(2, false); T384_AL(3, false); T384_AL(4, false);
+#undef T384_AL
 }
 
 int launch_gemm_t384(const GemmArgs& p, int batch, int dbg, void* stream) {
   static DeviceOnce once_t;
   if (const auto bit = DeviceOnce::current_bit(); once_t.need(bit)) {
-    (void)hipFuncSetAttribute((const void*)gemm_nt_t384_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, t384::LDS_BYTES);
+    allow_lds<0>();
 #ifdef DVD_LAB
-    (void)hipFuncSetAttribute((const void*)gemm_nt_t384_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, t384::LDS_BYTES);
-    (void)hipFuncSetAttribute((const void*)gemm_nt_t384_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, t384::LDS_BYTES);
-    (void)hipFuncSetAttribute((const void*)gemm_nt_t384_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, t384::LDS_BYTES);
-    (void)hipFuncSetAttribute((const void*)gemm_nt_t384_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, t384::LDS_BYTES);
-    (void)hipFuncSetAttribute((const void*)gemm_nt_t384_kernel<5>, hipFuncAttributeMaxDynamicSharedMemorySize, t384::LDS_BYTES);
+    allow_lds<1>(); allow_lds<2>(); allow_lds<3>(); allow_lds<4>(); allow_lds<5>();
 #endif
     once_t.done(bit);
   }
@@ -266,18 +441,21 @@ int launch_gemm_t384(const GemmArgs& p, int batch, int dbg, void* stream) {
   if (nblk > 256) nblk = 256;
   const dim3 grid(nblk, batch);
   hipStream_t st = (hipStream_t)stream;
+  // the epilogue flavour is a function of the descriptor (never of the data): see gemm_nt_t384_kernel
+  const int fl = (p.C16 && !p.C32 && !p.res) ? 0 : (p.C32 && !p.C16 && p.act != 1) ? (p.res ? 2 : 1) : (p.res ? 4 : 3);
+  const bool full = p.M % 384 == 0;
 #ifdef DVD_LAB
   switch (dbg) {
-    case 1: gemm_nt_t384_kernel<1><<<grid, 512, t384::LDS_BYTES, st>>>(p); break;
-    case 2: gemm_nt_t384_kernel<2><<<grid, 512, t384::LDS_BYTES, st>>>(p); break;
-    case 3: gemm_nt_t384_kernel<3><<<grid, 512, t384::LDS_BYTES, st>>>(p); break;
-    case 4: gemm_nt_t384_kernel<4><<<grid, 512, t384::LDS_BYTES, st>>>(p); break;
-    case 5: gemm_nt_t384_kernel<5><<<grid, 512, t384::LDS_BYTES, st>>>(p); break;
-    default: gemm_nt_t384_kernel<0><<<grid, 512, t384::LDS_BYTES, st>>>(p);
+    case 1: launch_fl<1>(p, fl, full, grid, st); break;
+    case 2: launch_fl<2>(p, fl, full, grid, st); break;
+    case 3: launch_fl<3>(p, fl, full, grid, st); break;
+    case 4: launch_fl<4>(p, fl, full, grid, st); break;
+    case 5: launch_fl<5>(p, fl, full, grid, st); break;
+    default: launch_fl<0>(p, fl, full, grid, st);
   }
 #else
   (void)dbg;
-  gemm_nt_t384_kernel<0><<<grid, 512, t384::LDS_BYTES, st>>>(p);
+  launch_fl<0>(p, fl, full, grid, st);
 #endif
   return check_launch("gemm_nt(t384)");
 }

@@ -118,9 +118,12 @@ def prime(e):
             e.read(BQ + 4 * i, "fb0", 0, 2048 * i)
 
 
-def iteration(e, slot, first=False, dma=True, vm=5, last=False):
+def iteration(e, slot, first=False, dma=True, vm=5, last=False, barrier=None):
     """one half slab in `slot`; first: the accumulators start from the constant 0 (no zeroing pass); dma: issue the pieces of
-    the half slab three ahead; vm: the vmcnt in front of the barrier (None: nothing left to wait for); last: no next half slab"""
+    the half slab three ahead; vm: the vmcnt in front of the barrier (None: nothing left to wait for); last: no next half slab
+    to read fragments of; barrier: default = not last (the cross-tile loop keeps it: its last iteration still issues pieces)"""
+    if barrier is None:
+        barrier = not last
     nslot = (slot + 1) % RING
     # ---- phase 1: k-step 0; reads of k-step 1 of this slot
     rd1 = {0: [("a", 0)], 1: [("a", 1)], 2: [("b", 0)], 3: [("a", 2)], 5: [("b", 1)], 8: [("b", 2)], 11: [("b", 3)]}
@@ -136,7 +139,7 @@ def iteration(e, slot, first=False, dma=True, vm=5, last=False):
                 e.read(BQ + 4 * k, "fb1", slot, 2048 * k)
     if vm is not None and "dma" not in ABL:
         e.add(f"s_waitcnt vmcnt({vm})")
-    if not last and "bar" not in ABL:
+    if barrier and "bar" not in ABL:
         e.add("s_barrier")
     # ---- phase 2: k-step 1; reads of k-step 0 of the next slot; the pieces of half slab j + 3 -> slot (j - 1) % 4
     rd2 = {0: [("a", 0)], 2: [("b", 0)], 3: [("a", 1)], 4: [("a", 2)], 5: [("b", 1)], 8: [("b", 2)], 11: [("b", 3)]}
@@ -162,9 +165,14 @@ def iteration(e, slot, first=False, dma=True, vm=5, last=False):
         e.add(f"s_addc_u32 s{S_B + 1}, s{S_B + 1}, 0")
 
 
-def loop_stmt():
-    """first block (half slabs 0-3) | steady block x nloop | final block (the last four half slabs: no pieces left to issue
-    after its first iteration, the waits shrink with the queue).  K = 128 (2 + nloop)."""
+def loop_stmt(xt=False):
+    """first block (half slabs 0-3) | steady block x nloop | final block.  K = 128 (2 + nloop).
+    xt = False: the tile's own prologue has put half slabs 0-2 into slots 0-2; the final block issues no pieces after its first
+    iteration and its waits shrink with the queue.
+    xt = True (cross-tile): the ring never drains - the final block keeps the steady pattern with the DMA sources switched to the
+    NEXT tile of this workgroup, whose half slabs 0, 1, 2 land in slots 0, 1, 2 while this tile's epilogue runs (LDS-free
+    epilogues only); the statement ends with half slab 0 of the next tile landed for every wave (vmcnt(10) + barrier), so the
+    next statement can prime its fragments at once."""
     e = Emit()
     e.add(f"s_mov_b64 s[{S_A}:{S_A + 1}], %[asrc]")
     e.add(f"s_mov_b64 s[{S_B}:{S_B + 1}], %[bsrc]")
@@ -186,9 +194,21 @@ def loop_stmt():
     e.label(".Lt384_final_%=")
     e.done = -1
     iteration(e, 0)                               # issues the pieces of the last half slab
-    iteration(e, 1, dma=False)                    # outstanding: the two last groups -> vmcnt(5) still right
-    iteration(e, 2, dma=False, vm=0)              # outstanding: the last group
-    iteration(e, 3, dma=False, vm=None, last=True)
+    if xt:
+        if "dma" not in ABL:
+            e.add(f"s_mov_b64 s[{S_A}:{S_A + 1}], %[anext]")
+            e.add(f"s_mov_b64 s[{S_B}:{S_B + 1}], %[bnext]")
+        iteration(e, 1)                           # ... of the NEXT tile's half slab 0 -> slot 0
+        iteration(e, 2)                           # ... 1 -> slot 1
+        iteration(e, 3, last=True, barrier=True)  # ... 2 -> slot 2 (after the barrier: every wave has left slot 2)
+        if "dma" not in ABL:
+            e.add("s_waitcnt vmcnt(10)")          # the next tile's half slab 0 has landed (its groups 1 and 2 stay in flight)
+        if "bar" not in ABL:
+            e.add("s_barrier")
+    else:
+        iteration(e, 1, dma=False)                # outstanding: the two last groups -> vmcnt(5) still right
+        iteration(e, 2, dma=False, vm=0)          # outstanding: the last group
+        iteration(e, 3, dma=False, vm=None, last=True)
     e.add("s_nop 15")                             # the last MFMAs must have written their accumulators before the read-out
     e.add("s_nop 7")
     return e
@@ -197,17 +217,18 @@ def loop_stmt():
 VARIANTS = [("", ()), ("nodma", ("dma",)), ("noread", ("read",)), ("nobar", ("bar",)), ("mfmaonly", ("dma", "read", "bar"))]
 
 
-def emit_loop(w, sfx):
-    w(f"// ---- the K loop{sfx}: prime, first block, steady block, final block; acc[4 m + n] = accumulator (m, n), written from 0")
-    w(f"__device__ __forceinline__ void t384_loop{sfx}(floatx16 (&acc)[12], const char* asrc, const char* bsrc, int nloop, unsigned pda,")
+def emit_loop(w, sfx, xt=False):
+    name = f"t384_loop{'_xt' if xt else ''}{sfx}"
+    w(f"// ---- the K loop {name}: prime, first block, steady block, final block; acc[4 m + n] = accumulator (m, n), written from 0")
+    w(f"__device__ __forceinline__ void {name}(floatx16 (&acc)[12], const char* asrc, const char* bsrc, int nloop, unsigned pda,")
     w("    unsigned pdb, unsigned va0, unsigned va1, unsigned va2, unsigned vb0, unsigned vb1, unsigned fa0, unsigned fa1, unsigned fb0,")
-    w("    unsigned fb1) {")
+    w("    unsigned fb1" + (", const char* anext, const char* bnext" if xt else "") + ") {")
     w("  asm volatile(")
-    w(loop_stmt().text())
+    w(loop_stmt(xt).text())
     w("      : " + ", ".join(f'[c{m}{n}] "=&{"v" if m == 0 else "a"}"(acc[{4 * m + n}])' for m in range(3) for n in range(4)) + ",")
     w('        [fa0] "+v"(fa0), [fa1] "+v"(fa1), [fb0] "+v"(fb0), [fb1] "+v"(fb1)')
     w('      : [asrc] "s"(asrc), [bsrc] "s"(bsrc), [nloop] "s"(nloop), [pda] "s"(pda), [pdb] "s"(pdb), [va0] "v"(va0), [va1] "v"(va1),')
-    w('        [va2] "v"(va2), [vb0] "v"(vb0), [vb1] "v"(vb1)')
+    w('        [va2] "v"(va2), [vb0] "v"(vb0), [vb1] "v"(vb1)' + (', [anext] "s"(anext), [bnext] "s"(bnext)' if xt else ""))
     clob = ['"memory"', '"scc"'] + [f'"{r}"' for r in SGPR_CLOBBERS] + [f'"v{i}"' for i in range(AX, 128)]
     rows = [", ".join(clob[i:i + 16]) for i in range(0, len(clob), 16)]
     w("      : " + ",\n        ".join(rows) + ");")
@@ -226,6 +247,7 @@ def emit():
         ABL.clear()
         ABL.update(abl)
         emit_loop(out.append if not name else lab.append, "" if not name else "_" + name)
+        emit_loop(out.append if not name else lab.append, "" if not name else "_" + name, xt=True)
     ABL.clear()
     w("// clang-format on")
     head = ["// GENERATED by dvd_amd/csrc/gen_gemm_t384.py --lab - do not edit.  TIMING ABLATIONS of the t384 K loop (lab builds only:",

@@ -14,8 +14,18 @@
 
 namespace dvd {
 
-// Unnormalise with align_corners=True: ((g + 1) / 2) * (size - 1)
-__device__ __forceinline__ float unnorm(float g, int size) { return ((g + 1.f) * 0.5f) * (float)(size - 1); }
+// Unnormalise with align_corners=True in ATen's order (aten/src/ATen/native/cpu/GridSamplerKernel.cpp, ComputeLocation:
+// (g + 1) * scaling_factor, scaling_factor = (size - 1) / 2; two roundings).  Round 5: every arithmetic step of the warps
+// follows the CPU kernels the reference runs (found by bit-exact probing of torch 2.10 CPU, tests/tools/aten_order_probe.py),
+// so that the f32 results - and with them the truncated u8 bytes - are the reference's, not merely close to them.
+__device__ __forceinline__ float unnorm(float g, int size) { return (g + 1.f) * ((float)(size - 1) * 0.5f); }
+
+// The four-tap sum in ATen's order: nw * w_nw, then fused multiply-adds of ne, sw, se (GridSamplerKernel.cpp's
+// `nw_val * nw + ne_val * ne + sw_val * sw + se_val * se`, whose additions the CPU build contracts into FMAs).
+__device__ __forceinline__ float tap_sum(float v_nw, float w_nw, float v_ne, float w_ne, float v_sw, float w_sw, float v_se,
+                                         float w_se) {
+  return fmaf(v_se, w_se, fmaf(v_sw, w_sw, fmaf(v_ne, w_ne, __fmul_rn(v_nw, w_nw))));
+}
 
 // Branch-free bilinear taps (zeros padding): out-of-range taps get weight 0 and a clamped (always valid)
 // address, so all four loads of a pixel issue unconditionally and back-to-back.  A NaN / infinite coordinate gives a
@@ -103,7 +113,7 @@ __device__ __forceinline__ f32x2 load_pair(const float* base, uint32_t byte_off)
   return f32x2{v.a, v.b};
 }
 __device__ __forceinline__ float blend(f32x2 u, f32x2 d, const PTaps& t) {
-  return ((u[0] * t.a00 + u[1] * t.a01) + d[0] * t.a10) + d[1] * t.a11;
+  return tap_sum(u[0], t.a00, u[1], t.a01, d[0], t.a10, d[1], t.a11);
 }
 
 constexpr int KR = 4;    // rows per wave of the f32 fast kernels (vertically adjacent pixels per lane)
@@ -146,7 +156,7 @@ __global__ void __launch_bounds__(256) grid_sample_nchw_kernel(const float* __re
     for (int k = 0; k < PX; ++k)
       if (y0 + k < h)
         o[(size_t)ch * hw + (size_t)(y0 + k) * w] =
-            ((v[k][0] * t[k].w00 + v[k][1] * t[k].w01) + v[k][2] * t[k].w10) + v[k][3] * t[k].w11;
+            tap_sum(v[k][0], t[k].w00, v[k][1], t[k].w01, v[k][2], t[k].w10, v[k][3], t[k].w11);
   }
 }
 
@@ -267,7 +277,7 @@ __device__ __forceinline__ PTapsB make_ptaps_box(float gx, float gy, int hin, in
 }
 
 __device__ __forceinline__ float blend_b(f32x2 u, f32x2 d, const PTapsB& t) {
-  return ((u[0] * t.a00 + u[1] * t.a01) + d[0] * t.a10) + d[1] * t.a11;
+  return tap_sum(u[0], t.a00, u[1], t.a01, d[0], t.a10, d[1], t.a11);
 }
 
 __device__ __forceinline__ int wave_min(int v) {
@@ -436,32 +446,63 @@ __global__ void __launch_bounds__(256) grid_sample_lds_kernel(
 // ---------------------------------------------------------------------------------------
 struct UpParams {
   int g, h, w;
-  float sy, sx;   // (g-1)/(h-1), (g-1)/(w-1): ATen area_pixel_compute_scale, align_corners=True
-  float inv_w1, inv_h1;
+  float sy, sx;     // (g-1)/(h-1), (g-1)/(w-1): ATen area_pixel_compute_scale, align_corners=True
+  float sby, sbx;   // 511/(h-1), 511/(w-1): the same for the 512 x 512 base grid (train_settings/dvd/evaluation.py:304)
   float scale;
+  int small;        // h + w <= 128: torch's CPU dispatch takes its channels-last kernel, whose sum has another order (below)
 };
+
+// One axis of F.interpolate(bilinear, align_corners=True) as ATen's CPU kernel computes it (UpSampleKernel.cpp,
+// compute_source_index_and_lambda): src = scale * dst; i0 = min(floor(src), in - 1); l1 = clamp(src - i0, 0, 1); l0 = 1 - l1.
+__device__ __forceinline__ void interp_axis(float scale, int dst, int in, int& i0, int& i1, float& l0, float& l1) {
+  const float s = __fmul_rn(scale, (float)dst);
+  i0 = min((int)s, in - 1);
+  i1 = min(i0 + 1, in - 1);
+  l1 = fminf(fmaxf(__fsub_rn(s, (float)i0), 0.f), 1.f);
+  l0 = __fsub_rn(1.f, l1);
+}
+// ... and its four-value sum.  torch picks one of two CPU kernels by the OUTPUT size (UpSampleKernel.cpp,
+// _use_vectorized_kernel_cond_2d; both orders found by bit-exact probing, oracle/aten_order.py restates them):
+//   h + w > 128   separable: t = fma(left, lx0, right * lx1) per row, then fma(t_upper, ly0, t_lower * ly1)
+//   h + w <= 128  channels-last kernel: weights w_rc = l_y(r) * l_x(c), sum fma(d, w11, fma(c, w10, fma(a, w00, b * w01)))
+__device__ __forceinline__ float interp_sum(float a, float b, float c, float d, float lx0, float lx1, float ly0, float ly1,
+                                            int small) {
+  if (small) {
+    const float w00 = __fmul_rn(ly0, lx0), w01 = __fmul_rn(ly0, lx1), w10 = __fmul_rn(ly1, lx0), w11 = __fmul_rn(ly1, lx1);
+    return fmaf(d, w11, fmaf(c, w10, fmaf(a, w00, __fmul_rn(b, w01))));
+  }
+  const float t0 = fmaf(a, lx0, __fmul_rn(b, lx1)), t1 = fmaf(c, lx0, __fmul_rn(d, lx1));
+  return fmaf(t0, ly0, __fmul_rn(t1, ly1));
+}
 
 __device__ __forceinline__ void flow_grid_at(const float* __restrict__ flow, const UpParams& p, int i, int j,
                                              float& gx, float& gy) {
-  // F.interpolate(bilinear, align_corners=True): src = scale * dst
-  float fy = p.sy * (float)i, fx = p.sx * (float)j;
-  int y0 = (int)fy, x0 = (int)fx;
-  y0 = min(y0, p.g - 1);
-  x0 = min(x0, p.g - 1);
-  int y1 = min(y0 + 1, p.g - 1), x1 = min(x0 + 1, p.g - 1);
-  float ly1 = fy - (float)y0, lx1 = fx - (float)x0;
-  float ly0 = 1.f - ly1, lx0 = 1.f - lx1;
+  // sample = F.interpolate(flow, (H, W), bilinear, align_corners=True)                       (evaluation.py:301)
+  int y0, y1, x0, x1;
+  float ly0, ly1, lx0, lx1;
+  interp_axis(p.sy, i, p.g, y0, y1, ly0, ly1);
+  interp_axis(p.sx, j, p.g, x0, x1, lx0, lx1);
   const int gg = p.g * p.g;
   float v[2];
 #pragma unroll
   for (int ch = 0; ch < 2; ++ch) {
     const float* f = flow + ch * gg;
-    v[ch] = ly0 * (lx0 * f[y0 * p.g + x0] + lx1 * f[y0 * p.g + x1]) +
-            ly1 * (lx0 * f[y1 * p.g + x0] + lx1 * f[y1 * p.g + x1]);
+    v[ch] = interp_sum(f[y0 * p.g + x0], f[y0 * p.g + x1], f[y1 * p.g + x0], f[y1 * p.g + x1], lx0, lx1, ly0, ly1, p.small);
   }
-  float bx = (float)j * p.inv_w1, by = (float)i * p.inv_h1;
-  gx = (((v[0] + bx) * 1.f) * 2.f - 1.f) * p.scale;
-  gy = (((v[1] + by) * 1.f) * 2.f - 1.f) * p.scale;
+  // base = F.interpolate(coords_grid_tensor((512, 512)) / 511., (H, W), bilinear, align_corners=True)   (evaluation.py:304):
+  // channel 0 holds column / 511, channel 1 row / 511 of the 512 x 512 grid - interpolated like any other image, so the
+  // value is NOT j / (W - 1) to the last bit
+  int yb0, yb1, xb0, xb1;
+  float lby0, lby1, lbx0, lbx1;
+  interp_axis(p.sby, i, 512, yb0, yb1, lby0, lby1);
+  interp_axis(p.sbx, j, 512, xb0, xb1, lbx0, lbx1);
+  const float cx0 = __fdiv_rn((float)xb0, 511.f), cx1 = __fdiv_rn((float)xb1, 511.f);
+  const float cy0 = __fdiv_rn((float)yb0, 511.f), cy1 = __fdiv_rn((float)yb1, 511.f);
+  const float bx = interp_sum(cx0, cx1, cx0, cx1, lbx0, lbx1, lby0, lby1, p.small);
+  const float by = interp_sum(cy0, cy0, cy1, cy1, lbx0, lbx1, lby0, lby1, p.small);
+  // sample = (((sample + base) * 1) * 2 - 1) * 0.987                                         (evaluation.py:306)
+  gx = __fmul_rn(__fsub_rn(__fmul_rn(__fmul_rn(__fadd_rn(v[0], bx), 1.f), 2.f), 1.f), p.scale);
+  gy = __fmul_rn(__fsub_rn(__fmul_rn(__fmul_rn(__fadd_rn(v[1], by), 1.f), 2.f), 1.f), p.scale);
 }
 
 __global__ void __launch_bounds__(256) unwarp_grid_kernel(const float* __restrict__ flow, float* __restrict__ grid,
@@ -507,7 +548,7 @@ __global__ void __launch_bounds__(256) unwarp_f32_kernel(const float* __restrict
     float* o = out + ((size_t)(i0 + k) * p.w + j) * 3;
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch)
-      o[ch] = ((v[ch][k][0] * t[k].w00 + v[ch][k][1] * t[k].w01) + v[ch][k][2] * t[k].w10) + v[ch][k][3] * t[k].w11;
+      o[ch] = tap_sum(v[ch][k][0], t[k].w00, v[ch][k][1], t[k].w01, v[ch][k][2], t[k].w10, v[ch][k][3], t[k].w11);
   }
 }
 
@@ -543,8 +584,8 @@ __global__ void __launch_bounds__(256) unwarp_u8_kernel(const float* __restrict_
     uint8_t* o = out + ((size_t)(i0 + k) * p.w + j) * 3;
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) {
-      const float a = (((float)v[k][0][ch] * t[k].w00 + (float)v[k][1][ch] * t[k].w01) +
-                       (float)v[k][2][ch] * t[k].w10) + (float)v[k][3][ch] * t[k].w11;
+      const float a = tap_sum((float)v[k][0][ch], t[k].w00, (float)v[k][1][ch], t[k].w01, (float)v[k][2][ch], t[k].w10,
+                              (float)v[k][3][ch], t[k].w11);
       o[ch] = (uint8_t)(int)a;   // truncation, as numpy .astype(uint8) for 0 <= a < 256
     }
   }
@@ -640,7 +681,7 @@ __global__ void __launch_bounds__(256) unwarp_u8_rows_kernel(const float* __rest
     const float dr[3] = {(float)(dlo[k] >> 24), (float)(dhi[k] & 255u), (float)((dhi[k] >> 8) & 255u)};
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) {
-      const float a = ((ul[ch] * t[k].a00 + ur[ch] * t[k].a01) + dl[ch] * t[k].a10) + dr[ch] * t[k].a11;
+      const float a = tap_sum(ul[ch], t[k].a00, ur[ch], t[k].a01, dl[ch], t[k].a10, dr[ch], t[k].a11);
       ob[k * 3 + ch] = (uint32_t)(int)a & 255u;             // truncation, as numpy .astype(uint8) for 0 <= a < 256
     }
   }
@@ -658,9 +699,10 @@ static UpParams make_up(int g, int h, int w, float scale) {
   p.w = w;
   p.sy = h > 1 ? (float)(g - 1) / (float)(h - 1) : 0.f;
   p.sx = w > 1 ? (float)(g - 1) / (float)(w - 1) : 0.f;
-  p.inv_w1 = w > 1 ? 1.f / (float)(w - 1) : 0.f;
-  p.inv_h1 = h > 1 ? 1.f / (float)(h - 1) : 0.f;
+  p.sby = h > 1 ? 511.f / (float)(h - 1) : 0.f;
+  p.sbx = w > 1 ? 511.f / (float)(w - 1) : 0.f;
   p.scale = scale;
+  p.small = (h + w <= 128) ? 1 : 0;
   return p;
 }
 

@@ -17,6 +17,19 @@ def get_named_beta_schedule(schedule_name, num_diffusion_timesteps):
     return schedule.named_betas(schedule_name, num_diffusion_timesteps)
 
 
+def _accepts_dither_step(model) -> bool:
+    """True for this package's denoiser (and anything wrapping it that declares the keyword, e.g. respace._WrappedModel's
+    **kwargs pass-through around a DvdDenoiser); False for a callable with the reference's keyword surface."""
+    import inspect
+    inner = getattr(model, "model", model)            # _WrappedModel keeps the wrapped module in .model
+    fwd = getattr(inner, "forward", inner)
+    try:
+        params = inspect.signature(fwd).parameters
+    except (TypeError, ValueError):
+        return False
+    return "dither_step" in params
+
+
 class ModelMeanType(enum.Enum):
     PREVIOUS_X = enum.auto()
     START_X = enum.auto()
@@ -171,11 +184,15 @@ class GaussianDiffusion:
             raise ValueError("the timestep must be identical across the batch (the denoiser's override rule is batch-global)")
         return i
 
-    def _single_call_kwargs(self, model_kwargs, i):
+    def _single_call_kwargs(self, model, model_kwargs, i):
         """model_kwargs of a single-step call at timestep index i: the weight-dithering phase is the one the sampling
-        loop uses at that index (sampler.sample: k = S-1-i), so chaining ddim_sample by hand gives the loop's bits."""
+        loop uses at that index (sampler.sample: k = S-1-i), so chaining ddim_sample by hand gives the loop's bits.
+        `dither_step` is an extension of THIS package's denoiser; the reference calls model(x, t, **model_kwargs) with the
+        caller's keywords only (idf/gaussian_diffusion.py:327), so a callable with the reference's keyword surface - a wrapper,
+        a lambda, a test double - gets exactly those and nothing else."""
         kw = dict(model_kwargs or {})
-        kw.setdefault("dither_step", self.num_timesteps - 1 - i)
+        if "dither_step" not in kw and _accepts_dither_step(model):
+            kw["dither_step"] = self.num_timesteps - 1 - i
         return kw
 
     def p_mean_variance(self, model, x, t, clip_denoised=True, denoised_fn=None, model_kwargs=None):
@@ -186,7 +203,7 @@ class GaussianDiffusion:
             raise NotImplementedError("clip_denoised / denoised_fn are off on the DvD path")
         i = self._step_index(t)
         t_model = th.full((x.shape[0],), self.tables.model_time(i), device=x.device)
-        x0, feat = model(x, t_model, **self._single_call_kwargs(model_kwargs, i))
+        x0, feat = model(x, t_model, **self._single_call_kwargs(model, model_kwargs, i))
         c = self.tables.ddpm_coef(i)
         c.sigma = 0.0                                                  # mean only
         mean = ops.sched_step(c, x.float().contiguous(), x0)
@@ -204,7 +221,7 @@ class GaussianDiffusion:
             raise NotImplementedError("clip_denoised / denoised_fn are off on the DvD path")
         i = self._step_index(t)
         t_model = th.full((x.shape[0],), self.tables.model_time(i), device=x.device)
-        x0, feat = model(x, t_model, **self._single_call_kwargs(model_kwargs, i))
+        x0, feat = model(x, t_model, **self._single_call_kwargs(model, model_kwargs, i))
         coef = self.tables.ddim_coef(i, eta)
         noise = th.randn_like(x0) if coef.sigma != 0.0 else None
         return {"sample": ops.sched_step(coef, x.float().contiguous(), x0, noise), "pred_xstart": x0, "feat_dict": feat}

@@ -11,6 +11,7 @@ builder; the library executes the list (gather + exact-f32 MFMA GEMM per conv). 
 from __future__ import annotations
 
 import ctypes as C
+import logging
 from collections import OrderedDict
 
 import numpy as np
@@ -19,6 +20,8 @@ from torch import nn
 
 from . import lib, synth
 from .lib import ptr, stream_ptr
+
+_log = logging.getLogger(__name__)
 
 CONV, POOL, RESIZE, ADD, SIGMOID = range(5)
 BN_EPS = 1e-5
@@ -342,6 +345,8 @@ class _RefNet(nn.Module):
     def bind_blob(self, view_u8: torch.Tensor):
         self._blob, self._blob_version = view_u8.view(torch.float32), self._version
 
+    MAX_EXECUTORS_PER_SHAPE = 2
+
     def _net(self, h, w, batch=1) -> ConvNet:
         """The executor for (batch, h, w): one per batch size - its activation slots hold all the images of a batch, so the
         net's ~500 ops are enqueued once per BATCH of documents, not once per document."""
@@ -351,12 +356,19 @@ class _RefNet(nn.Module):
         key = (batch, h, w, dev.index)
         net = self._nets.get(key)
         if net is None:
-            # ONE executor (and one workspace) per image size and device: a different batch size - the ragged last batch
-            # of a run - replaces the previous executor instead of keeping a second full set of activation slots alive
-            for old in [k for k in self._nets if k[1:] == key[1:]]:
+            # At most TWO executors (and workspaces) per image size and device, least recently used out: the ragged last
+            # batch of a run or a service that alternates single documents with batches keeps both of its executors
+            # (one per batch size evicted the other on every call - a silent rebuild + weight re-bind each time), while a
+            # sweep over many batch sizes still cannot pile up full sets of activation slots.
+            same = [k for k in self._nets if k[1:] == key[1:]]
+            for old in same[:max(0, len(same) - (self.MAX_EXECUTORS_PER_SHAPE - 1))]:
                 del self._nets[old]
-            net = self._nets[key] = ConvNet(self._program, self._outputs, (h, w), device=dev, batch=batch)
+                _log.debug("prestage: evicted the executor for batch %d at %dx%d", old[0], h, w)
+            net = ConvNet(self._program, self._outputs, (h, w), device=dev, batch=batch)
             net._bound = -1
+        else:
+            del self._nets[key]                      # re-inserted below: dict order = recency
+        self._nets[key] = net
         if net._bound != self._version:
             if self._blob is None or self._blob_version != self._version:
                 from . import dist_util

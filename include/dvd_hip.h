@@ -127,11 +127,15 @@ typedef struct {
   const float* gate; int ldgate; int gate_rows; long strideGate;
   const float* res; int ldres; long strideRes;
   int small_tiles;                           /* f16 only: 1 = 128x128 tiles for every shape.  The caller's statement about
-                                                its PROBLEM FAMILY (the engine sets it from the grid, never from the batch):
-                                                at a few thousand rows the 256x256 persistent kernels put < 50 workgroups on
-                                                256 CUs and run one workgroup's K loop latency-bound.  2 = the same family
-                                                with many rows: N % 256 == 0 shapes take the 256x256 kernel in the two-sweep
-                                                form whose accumulation sequence IS the 128x128 kernel's (same bits) */
+                                                its PROBLEM FAMILY (the engine derives 1 from the grid alone): at a few
+                                                thousand rows the 256x256 persistent kernels put < 50 workgroups on 256 CUs
+                                                and run one workgroup's K loop latency-bound.  2 = the same family with MANY
+                                                rows (the engine: >= 16 384 token rows, i.e. the choice between 1 and 2 DOES
+                                                depend on the batch): N % 256 == 0 shapes take the 256x256 kernel in the
+                                                two-sweep form whose accumulation sequence IS the 128x128 kernel's - the
+                                                same bits, which is what keeps 'alone == in a batch' true
+                                                (tests/test_gpu_gemm.py::test_gemm_small_family_engine_shapes_same_bits,
+                                                tests/test_gpu_engine.py::test_large_batch_of_small_grids_matches_single) */
 } dvd_gemm_desc;
 
 int dvd_gemm_nt(const dvd_gemm_desc* desc, void* stream);

@@ -401,6 +401,32 @@ def test_gemm_small_family_many_rows_same_bits(ops, side):
     assert ((got if side == "B" else got.t()) - want).abs().max().item() < 2e-5
 
 
+@pytest.mark.parametrize("M", [16384, 2000])
+@pytest.mark.parametrize("N,K,epi", [(768, 384, "bias"), (1536, 384, "gelu"), (3072, 1536, "plain"), (1536, 1536, "res"),
+                                     (2048, 1536, "relu"), (1536, 2048, "relu_res")])
+def test_gemm_small_family_engine_shapes_same_bits(ops, M, N, K, epi):
+    """from 16 384 token rows on, the small-grid engine sends its N % 256 == 0 GEMMs to the 256 x 256
+    kernel (small_tiles = 2, two sweeps) while a single document runs 128 x 128 tiles (small_tiles = 1) - 'a document gives the
+    same bits alone and in a batch' then rests on the two kernels accumulating identically.  Every (N, K) of the engine's
+    small family with the epilogue it carries there (engine.hip:enqueue_step), at a batch-sized M and at a ragged one."""
+    a = rnd(f"se/a{K}", (M, K)).half().cuda()
+    w = rnd(f"se/w{N}{K}", (N, K)) * 0.05
+    hi, lo = w.half().cuda(), (w - w.half().float()).half().cuda()
+    bias, res = rnd("se/bias", (N,)).cuda(), rnd(f"se/res{N}", (M, N)).cuda()
+    outs = []
+    for st in (1, 2):
+        kw = dict(b_lo=lo, lo_scale=1.0, small_tiles=st)
+        if epi in ("res", "relu_res"):
+            o = res.clone()
+            ops.gemm_nt(a, hi, out32=o, res=o, **(dict(bias=bias, act=2) if epi == "relu_res" else {}), **kw)
+        else:
+            o = torch.zeros(M, N, dtype=torch.float16, device="cuda")
+            extra = {"bias": dict(bias=bias), "gelu": dict(bias=bias, act=1), "relu": dict(bias=bias, act=2), "plain": {}}[epi]
+            ops.gemm_nt(a, hi, out16=o, **extra, **kw)
+        outs.append(o.cpu())
+    assert torch.equal(outs[0], outs[1]), (N, K, epi, M)
+
+
 @pytest.mark.parametrize("M,N,K", [(1536, 1536, 1536), (1100, 512, 256), (2304, 3072, 1536), (777, 256, 384), (4000, 2048, 1536),
                                    (1152, 1536, 2048), (384, 256, 256), (5, 768, 384)])
 def test_gemm_t384_kernel(ops, lab, monkeypatch, M, N, K):

@@ -157,3 +157,20 @@ def test_batched_conditioning_equals_per_document(models):
         one = prestage.conditioning(dewarp, seg, line, src[i:i + 1].contiguous(), 16)
         for k in ("mask_cat", "mask_y512", "line_msk"):
             assert torch.equal(both[k][i:i + 1], one[k]), (i, k)
+
+
+def test_executor_cache_keeps_two_batch_sizes_per_shape(models):
+    """a caller that alternates batch sizes (a single document, then a batch, then a single one again ...) must
+    not rebuild the executor - workspace re-allocation and weight re-bind - on every call: two executors per (h, w, device)
+    stay alive, the least recently used one goes when a third batch size arrives."""
+    dewarp, seg, line, sds = models
+    net = line
+    img = torch.from_numpy(synth.smooth_image("lru/src", 64, 64, 5))[None].cuda()
+    n1 = net._net(64, 64, 1)
+    n3 = net._net(64, 64, 3)
+    assert net._net(64, 64, 1) is n1 and net._net(64, 64, 3) is n3          # both alive, nothing rebuilt
+    n2 = net._net(64, 64, 2)                                                 # third size: the LRU one (batch 1) goes
+    assert net._net(64, 64, 3) is n3 and net._net(64, 64, 2) is n2
+    assert len([k for k in net._nets if k[1:3] == (64, 64)]) == net.MAX_EXECUTORS_PER_SHAPE
+    assert net._net(64, 64, 1) is not n1
+    assert torch.equal(net(img)[0], net(img.repeat(2, 1, 1, 1))[0][:1])      # and the results do not care

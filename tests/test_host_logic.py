@@ -248,3 +248,33 @@ def test_library_path_is_not_taken_from_the_environment(monkeypatch):
     finally:
         monkeypatch.delenv("DVD_HIP_LIB")
         importlib.reload(lib)
+
+
+def test_single_step_calls_keep_the_reference_keyword_surface():
+    """p_mean_variance / ddim_sample call model(x, t, **model_kwargs) like the reference
+    (idf/gaussian_diffusion.py:327); the package's own `dither_step` keyword is injected only for a model that declares it -
+    a lambda, a wrapper or a test double with the reference's keywords must not see it."""
+    from dvd_amd import gaussian_diffusion as gd
+    from dvd_amd.script_util import create_gaussian_diffusion
+
+    diff = create_gaussian_diffusion(steps=10, noise_schedule="cosine", timestep_respacing="", predict_xstart=True)
+    seen = {}
+
+    def ref_like(x, t, init_flow=None, y512=None, **kw):       # the reference's surface: unknown keywords are the caller's
+        seen.update(kw)
+        return x, None
+
+    class Own:
+        def forward(self, x, t, init_flow=None, dither_step=None):
+            return x, None
+
+        __call__ = forward
+
+    assert not gd._accepts_dither_step(lambda x, t, init_flow=None: (x, None))
+    assert gd._accepts_dither_step(Own())
+    assert diff._single_call_kwargs(lambda x, t, init_flow=None: (x, None), {"init_flow": 1}, 3) == {"init_flow": 1}
+    assert diff._single_call_kwargs(Own(), {"init_flow": 1}, 3) == {"init_flow": 1, "dither_step": 6}
+    assert diff._single_call_kwargs(Own(), {"dither_step": 2}, 3) == {"dither_step": 2}      # the caller's value wins
+    assert "dither_step" not in diff._single_call_kwargs(ref_like, None, 0)
+    from dvd_amd.cross_model import DvdDenoiser
+    assert "dither_step" in __import__("inspect").signature(DvdDenoiser.forward).parameters

@@ -210,3 +210,24 @@ def test_prestage_oracle_vs_reference():
     np.testing.assert_allclose(out["mask_y512"][0].numpy(), g["mask_y512"], rtol=0, atol=2e-5)
     np.testing.assert_allclose(out["line_map"][0, ::8, ::16, ::16].numpy(), g["line_map_sub"], rtol=0, atol=2e-5)
     np.testing.assert_allclose(out["line_msk"][0].numpy(), g["line_msk"], rtol=0, atol=2e-5)
+
+
+@pytest.mark.parametrize("shape", [(16, 97, 131), (32, 240, 172), (64, 301, 415)])
+def test_aten_order_restatement(shape):
+    """oracle/aten_order.py - the arithmetic ORDER the HIP warps implement (FMA contractions of the torch-CPU kernels included)
+    - against the torch build of THIS box, bit for bit: grid, f32 image and truncated bytes of the whole tail, and the golden
+    G5 vectors of the real reference."""
+    from oracle import aten_order as A
+    g, H, W = shape
+    rng = np.random.RandomState(g)
+    flow = (rng.randn(1, 2, g, g) * 0.06).astype(np.float32)
+    src = (rng.rand(1, 3, H, W) * 255).astype(np.float32)
+    grid, out, u8 = O.unwarp_tail(torch.from_numpy(flow), torch.from_numpy(src))
+    grid2, out2, u82 = A.unwarp_tail(flow, src)
+    assert np.array_equal(grid.numpy(), grid2) and np.array_equal(out.numpy(), out2) and np.array_equal(u8, u82)
+    gold = load("unwarp.npz")
+    for tag in ("a", "b", "c"):
+        s8 = gold[f"{tag}/src_u8"]
+        g3, o3, u3 = A.unwarp_tail(gold[f"{tag}/flow"], s8.transpose(2, 0, 1)[None].astype(np.float32))
+        assert np.array_equal(g3.reshape(gold[f"{tag}/grid"].shape), gold[f"{tag}/grid"])
+        assert np.array_equal(o3, gold[f"{tag}/out_f32"]) and np.array_equal(u3, gold[f"{tag}/out_u8"])
