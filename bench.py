@@ -28,6 +28,9 @@ import os
 import sys
 import time
 
+_T_PROCESS_START = time.perf_counter()
+CFG3_FULL_DEADLINE_S = 900        # other_configs: configs[3] runs its stated 32 documents if the process is younger than this
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
@@ -432,8 +435,10 @@ def other_configs(dev, blob288, H, FH, FW, want_cpu=True, legs=("cfg4", "cfg3", 
     """Bounded legs for the BASELINE.json configurations the headline is NOT quoted on, each with its own time, value and
     parity figure (the headline fields of the line are untouched):
       configs[4]  16 documents, 50-step DDIM, G = 288, + 3508x2480 unwarp: ONE whole batch;
-      configs[3]  250-step DDPM ancestral sampling at G = 288, run at 4 documents instead of 32 (stated): the loop is
-                  strictly per-document work, so documents/s at 4 per batch is a lower bound of the rate at 32;
+      configs[3]  250-step DDPM ancestral sampling at G = 288 at its STATED 32 documents (x H hypotheses = 64 samples, one
+                  engine batch, ~5.5 minutes; round 5) - unless the process has already run longer than CFG3_FULL_DEADLINE_S,
+                  in which case 4 documents are run and the leg says so (the loop is strictly per-document work, so
+                  documents/s at 4 per batch is a lower bound of the rate at 32);
       native      the reference's own operating point (admin/local.py:28-35,82: G = 64, 3 DDIM steps, 2 hypotheses, one
                   document at a time) from a decoded IMAGE: ingest + the three pre-stage nets + sampling + unwarp."""
     import statistics
@@ -481,7 +486,7 @@ def other_configs(dev, blob288, H, FH, FW, want_cpu=True, legs=("cfg4", "cfg3", 
             d = np.abs(got8 - ref8.astype(np.int32))
             par = {"what": "document 0: fused u8 unwarp (3508x2480) vs the CPU oracle's upsample + grid_sample + uint8 on the "
                            "same flow", "pixels_equal": float((d == 0).mean()), "max_abs_u8": int(d.max()),
-                   "ok": bool((d <= 1).mean() > 0.9999)}
+                   "ok": bool((d == 0).all())}       # round 5: the tail follows ATen's arithmetic order - the same bytes
         out["configs[4]"] = {"workload": f"BASELINE configs[4]: batch={B} documents x {H} hypotheses, 50-step DDIM, 288x288 grid, "
                                          f"+ {FH}x{FW} u8 unwarp", "batches_timed": 1, "ms_per_batch": round(dt * 1e3, 1),
                              "value": round(B / dt, 5), "unit": "documents/s", "parity": par}
@@ -489,8 +494,8 @@ def other_configs(dev, blob288, H, FH, FW, want_cpu=True, legs=("cfg4", "cfg3", 
         torch.cuda.empty_cache()
 
     if "cfg3" in legs:
-        # ---- configs[3]: 250-step DDPM at 4 documents ------------------------------------------------------------------
-        B = 4
+        # ---- configs[3]: 250-step DDPM at the stated 32 documents (4 if the run is already long) ------------------------
+        B = 32 if time.perf_counter() - _T_PROCESS_START < CFG3_FULL_DEADLINE_S else 4
         eng = Engine(G, B, H, device=dev)
         eng.bind_blob(blob288)
         cond = docs(B, G)
@@ -520,8 +525,10 @@ def other_configs(dev, blob288, H, FH, FW, want_cpu=True, legs=("cfg4", "cfg3", 
             err = float((got - ref).abs().max())
             par = {"what": "fused DDPM step (t = 125, FIXED_LARGE) on this run's tensors vs the oracle's p_mean_variance + "
                            "noise line", "max_abs": err, "ok": bool(err < 1e-5)}
-        out["configs[3]"] = {"workload": f"BASELINE configs[3] at batch={B} instead of 32 documents (x {H} hypotheses): 250-step "
-                                         "DDPM ancestral sampling, 288x288 grid (no unwarp in this configuration)",
+        out["configs[3]"] = {"workload": (f"BASELINE configs[3]: batch={B} documents x {H} hypotheses" if B == 32 else
+                                          f"BASELINE configs[3] at batch={B} instead of 32 documents (x {H} hypotheses; the run "
+                                          f"was past {CFG3_FULL_DEADLINE_S} s when this leg started)") +
+                                         ": 250-step DDPM ancestral sampling, 288x288 grid (no unwarp in this configuration)",
                              "batches_timed": 1, "ms_per_batch": round(dt * 1e3, 1), "value": round(B / dt, 5),
                              "unit": "documents/s", "finite": bool(torch.isfinite(flow).all()), "parity": par}
         del eng, cond, x_T, flow, last

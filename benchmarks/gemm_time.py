@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Time the decoder's GEMMs at the bench's shapes (M = 331 776 rows): plain f16 weights (what the dithered engine runs;
 product = the 32x32x16 kernel, `--lab` with DVD_GEMM_M16=1 = the rejected 16x16x32 variant) and, with `split`, the (hi, lo) pairs.
-usage: python benchmarks/gemm_time.py [reps=5] [plain|split]"""
+usage: python benchmarks/gemm_time.py [reps=5] [plain|split|res|f32]"""
 import os, sys
 sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__))); import _lab; LIBSEL = _lab.which()   # --lab selects the lab build
@@ -17,8 +17,11 @@ for name, N, K in (("qk  N=3072 K=1536", 3072, 1536), ("c1  N=2048 K=1536", 2048
     a = torch.randn(M, K, device="cuda").half()
     w = torch.randn(N, K, device="cuda") * 0.05
     hi = w.half(); lo = (w - hi.float()).half()
-    out = torch.empty(M, N, dtype=torch.float16, device="cuda")
+    out = torch.empty(M, N, dtype=torch.float32 if MODE in ("res", "f32") else torch.float16, device="cuda")
+    if MODE == "res": out.zero_()
     f = (lambda: ops.gemm_nt(a, hi, out16=out, b_lo=lo, lo_scale=1.0)) if MODE == "split" else (lambda: ops.gemm_nt(a, hi, out16=out))
+    if MODE == "res": f = lambda: ops.gemm_nt(a, hi, out32=out, res=out)        # the decoder's fc / conv2 form: f32 residual stream, in place
+    if MODE == "f32": f = lambda: ops.gemm_nt(a, hi, out32=out)
     for _ in range(2): f()
     torch.cuda.synchronize()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]

@@ -17,6 +17,9 @@
 #include <stdlib.h>
 #include <type_traits>
 
+#ifndef T384_STAGGER
+#define T384_STAGGER 0      // start-up delay quantum of gemm_nt_t384_kernel (x 1024 cycles x 0..15 per workgroup); see the kernel
+#endif
 #ifndef DVD_GEMM_SPREAD_FIRST
 #define DVD_GEMM_SPREAD_FIRST 0
 #endif
@@ -1633,8 +1636,10 @@ extern "C" int dvd_gemm_nt(const dvd_gemm_desc* d, void* stream) {
     // round 5: 384 x 256 tiles, 4-slot half-slab ring, generated K loop; bit-identical to gemm_nt_big_kernel
     p.ntm = cdiv(d->M, 384); p.ntn = d->N / 256;
     int tdbg = 0;
+    p.stagger = T384_STAGGER;
 #ifdef DVD_LAB
     if (const char* e = getenv("DVD_GEMM_T384_DBG")) tdbg = atoi(e);
+    if (const char* e = getenv("DVD_GEMM_T384_STAGGER")) p.stagger = atoi(e);
 #endif
     return launch_gemm_t384(p, d->batch, tdbg, stream);
   }

@@ -149,6 +149,9 @@ __device__ __forceinline__ void epilogue(const GemmArgs& p, float* stage, const 
 // row segments (MI355X_MICROARCH.md: "two 128-B segments in two rows: full rate"), the residual is read the same way.  The
 // residual of tile t + 1 is requested before tile t's stores are issued (vmcnt counts stores and retires in order).
 // Arithmetic per element as in epilogue_readback: ((acc + bias) + 0), ReLU, + residual.
+#ifndef T384_RES_DEPTH
+#define T384_RES_DEPTH 3      // half tiles between a residual load and its use (direct_f32)
+#endif
 typedef __attribute__((address_space(1))) float gfloat;
 typedef __attribute__((address_space(1))) char gchar;
 
@@ -161,52 +164,61 @@ __device__ __forceinline__ void direct_f32(const GemmArgs& p, const floatx16 (&a
 #pragma unroll
     for (int n = 0; n < 4; ++n) bv[n] = bias[col_w + 32 * n + r];
   }
-  const bool relu = p.act == 2, hb = bias != nullptr;
-  // every address = wave-uniform base of the half tile (SGPR pair) + one of 8 per-lane 32-bit offsets (rows 4 h + {0..3, 8..11},
-  // column r) that are the same for all 24 half tiles: global_load/store_dword v, v_off, s[base]
-  unsigned oc[8], orr[8];
-#pragma unroll
-  for (int k = 0; k < 8; ++k) {
-    const int ro = 4 * h + (k & 3) + 8 * (k >> 2);
-    oc[k] = (unsigned)(ro * p.ldc + r) * 4u;
-    orr[k] = (unsigned)(ro * p.ldres + r) * 4u;
-  }
+  const bool relu = p.act == 2;
+  // every address = wave-uniform base of the half tile and row (SGPR pair) + ONE per-lane 32-bit offset (row 4 h, column r):
+  // global_load/store_dword v, v_off, s[base]
+  const unsigned oc = (unsigned)((4 * h) * p.ldc + r) * 4u, orr = (unsigned)((4 * h) * p.ldres + r) * 4u;
   const gchar* cb = (const gchar*)uniform_ptr((const char*)(C32 + (size_t)row_w * p.ldc + col_w));
   const gchar* rb = RES ? (const gchar*)uniform_ptr((const char*)(res + (size_t)row_w * p.ldres + col_w)) : nullptr;
   const int rows_left = p.M - row_w - 4 * h;          // rows of this lane half that exist (ragged last row tile)
-  // half tiles (registers 8 u .. 8 u + 7 of accumulator t): 24 steps; the residual of step s + 2 is requested before step s stores
-  // (waiting for a load also waits for every OLDER store: two steps of slack for their acknowledgements)
-  float rv[3][8];
+  // half tiles (registers 8 u .. 8 u + 7 of accumulator t): 24 steps; the residual of a step is requested `ahead(s)` steps
+  // before it is used, always before the stores of the step that issues it.  Waiting for a load also waits for every OLDER
+  // store (vmcnt retires in order and counts stores), and a store's acknowledgement takes ~2.7 k cycles while every CU is
+  // storing: two steps ahead, a step cost 1375 cycles = 33 k per tile (profiles/r5_gemm_t384_epilogue_kind.txt).  The window
+  // is three steps deep (T384_RES_DEPTH): what the 128 VGPRs hold beside the four VGPR-resident accumulators without spill
+  // reloads inside the store stream - deeper windows (4, 5, and 2 -> 5 once those accumulators are stored) were compiled and
+  // all spilled INTO the stream, where every reload is one more wait for a store.  The residual flavour therefore stays
+  // epilogue-bound (30 % of a tile, 810-925 TF/s against 1040-1140 for the f16 flavour: profiles/r5_gemm_t384_res_ab.txt);
+  // it is 2-3 % faster than gemm_nt_big_kernel's, whose staged epilogue pays the same acknowledgements.
+  constexpr int W = T384_RES_DEPTH + 1;
+  float rv[W][8];
   auto load_res = [&](int s, float (&dst)[8]) {
     const int t = s >> 1, u = s & 1, m = t >> 2, n = t & 3;
-    const gchar* sb = rb + ((size_t)(32 * m + 16 * u) * p.ldres + 32 * n) * 4;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const int ro = 32 * m + 16 * u + (k & 3) + 8 * (k >> 2);
-      dst[k] = (FULL || ro < rows_left) ? *(const gfloat*)(sb + (size_t)orr[k]) : 0.f;
+      const gchar* sb = rb + ((size_t)ro * p.ldres + 32 * n) * 4;               // wave-uniform
+      dst[k] = (FULL || ro < rows_left) ? *(const gfloat*)(sb + (size_t)orr) : 0.f;
     }
   };
-  if constexpr (RES) { load_res(0, rv[0]); load_res(1, rv[1]); }
+  auto ahead = [](int) { return T384_RES_DEPTH; };
+  int nxt = 0;                                                                   // compile-time after unrolling
+  if constexpr (RES) {
+#pragma unroll
+    for (; nxt < ahead(0); ++nxt) load_res(nxt, rv[nxt % W]);
+  }
 #pragma unroll
   for (int s = 0; s < 24; ++s) {
     const int t = s >> 1, u = s & 1, m = t >> 2, n = t & 3;
     __builtin_amdgcn_sched_barrier(0);     // one half tile at a time: the scheduler must not pull all the read-outs forward
     if constexpr (RES) {
-      if (s + 2 < 24) load_res(s + 2, rv[(s + 2) % 3]);
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+        if (nxt <= s + ahead(s) && nxt < 24) { load_res(nxt, rv[nxt % W]); ++nxt; }
     }
     float v[8];
 #pragma unroll
     for (int k = 0; k < 8; ++k) {                 // (no `+ 0.f`: an accumulator that starts at +0 is never -0; bv = 0 without a bias)
       float x = acc[t][8 * u + k] + bv[n];
       x = relu ? fmaxf(x, 0.f) : x;
-      if constexpr (RES) x += rv[s % 3][k];
+      if constexpr (RES) x += rv[s % W][k];
       v[k] = x;
     }
-    gchar* sb = const_cast<gchar*>(cb) + ((size_t)(32 * m + 16 * u) * p.ldc + 32 * n) * 4;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
       const int ro = 32 * m + 16 * u + (k & 3) + 8 * (k >> 2);
-      if (FULL || ro < rows_left) *(gfloat*)(sb + (size_t)oc[k]) = v[k];
+      gchar* sb = const_cast<gchar*>(cb) + ((size_t)ro * p.ldc + 32 * n) * 4;    // wave-uniform
+      if (FULL || ro < rows_left) *(gfloat*)(sb + (size_t)oc) = v[k];
     }
   }
 }
@@ -289,6 +301,14 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_t384_kernel(GemmArgs p) {
   const _Float16* B = (const _Float16*)p.B + z * p.sB;
   const unsigned pda = lds0 + (3 * wave) * 1024, pdb = lds0 + BOFF + (2 * wave) * 1024;
   bool first = true;
+  // De-synchronise the chip: every CU runs the same tiles at the same pace, so all 256 epilogues would store at the same
+  // moment - 50 MB bursts against the HBM write rate (the epilogue of the f16 flavour measured 11.4 k cycles = 5.7 TB/s
+  // chip-wide, while the kernel's AVERAGE write rate is 0.7 TB/s).  A start-up delay of up to 15 quanta spreads the
+  // workgroups of the first round over part of a tile period; without a barrier between tiles (XT) they stay spread.
+  if (p.stagger > 0) {
+    const int slots = (blockIdx.x * 5) & 15;
+    for (int i = 0; i < slots * p.stagger; ++i) __builtin_amdgcn_s_sleep(16);   // 16 x 64 cycles each
+  }
   for (int vid = blockIdx.x; vid < nwg; vid += gridDim.x) {
     int tm, tn;
     tile_coords(vid, p.ntm, p.ntn, tm, tn);
