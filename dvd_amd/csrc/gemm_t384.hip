@@ -191,20 +191,17 @@ __device__ __forceinline__ void direct_f32(const GemmArgs& p, const floatx16 (&a
       dst[k] = (FULL || ro < rows_left) ? *(const gfloat*)(sb + (size_t)orr) : 0.f;
     }
   };
-  auto ahead = [](int) { return T384_RES_DEPTH; };
-  int nxt = 0;                                                                   // compile-time after unrolling
+  constexpr int D = T384_RES_DEPTH;
   if constexpr (RES) {
 #pragma unroll
-    for (; nxt < ahead(0); ++nxt) load_res(nxt, rv[nxt % W]);
+    for (int s = 0; s < D; ++s) load_res(s, rv[s]);
   }
 #pragma unroll
   for (int s = 0; s < 24; ++s) {
     const int t = s >> 1, u = s & 1, m = t >> 2, n = t & 3;
     __builtin_amdgcn_sched_barrier(0);     // one half tile at a time: the scheduler must not pull all the read-outs forward
     if constexpr (RES) {
-#pragma unroll
-      for (int q = 0; q < 3; ++q)
-        if (nxt <= s + ahead(s) && nxt < 24) { load_res(nxt, rv[nxt % W]); ++nxt; }
+      if (s + D < 24) load_res(s + D, rv[(s + D) % W]);
     }
     float v[8];
 #pragma unroll
