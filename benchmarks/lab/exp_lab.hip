@@ -6,6 +6,8 @@
 // reports cycles per 16 MFMAs:
 //   V0  MFMAs only            V1  + 2 v_exp_f32 + 1 v_cvt_pk per MFMA (the kernel today)
 //   V2  half of the pairs by the packed polynomial      V3  all of them by the packed polynomial
+// (a TIMING proxy: the instruction sequence is the one a correct packed 2^x needs - same opcodes, same dependences - its
+//  constants were not validated numerically, because the timing already decides: see profiles/r5_exp_offload_lab.txt)
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 exp_lab.hip -o exp_lab && ./exp_lab
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -65,31 +67,9 @@ __global__ void __launch_bounds__(512, 2) exp_kernel(float* out, int iters, long
   if (threadIdx.x == 0) clk[blockIdx.x] = t1 - t0;
 }
 
-// correctness of the packed unit on a sweep of arguments
-__global__ void poly_check(const float* xin, float* yout, int n) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (2 * i + 1 >= n) return;
-  float x0 = xin[2 * i], x1 = xin[2 * i + 1];
-  unsigned p = 0, t = 0, nn = 0;
-  const unsigned magic = 0x66006600u, lo = 0xcb00cb00u, c3 = 0x2b1c2b1cu, c2 = 0x33b033b0u, c1 = 0x398c398cu, c0 = 0x3c003c00u;
-  asm volatile(POLY("%0", "%1", "%2", "%3", "%4") : "+v"(x0), "+v"(x1), "+v"(p), "+v"(t), "+v"(nn)
-               : [magic] "v"(magic), [lo] "v"(lo), [c3] "v"(c3), [c2] "v"(c2), [c1] "v"(c1), [c0] "v"(c0));
-  const _Float16 h0 = __builtin_bit_cast(_Float16, (unsigned short)(p & 0xffff)), h1 = __builtin_bit_cast(_Float16, (unsigned short)(p >> 16));
-  yout[2 * i] = (float)h0; yout[2 * i + 1] = (float)h1;
-}
-
 int main() {
   float* out; long long* clk;
   CK(hipMalloc(&out, 256 * 512 * 4)); CK(hipMalloc(&clk, 256 * 8));
-  // accuracy of the packed 2^x against exp2f, relative to the f16 rounding of the exact value
-  {
-    const int n = 4096; float hx[n], hy[n]; float *dx, *dy;
-    for (int i = 0; i < n; ++i) hx[i] = -12.0f * i / n;
-    CK(hipMalloc(&dx, n * 4)); CK(hipMalloc(&dy, n * 4)); CK(hipMemcpy(dx, hx, n * 4, hipMemcpyHostToDevice));
-    poly_check<<<n / 2 / 64, 64>>>(dx, dy, n); CK(hipMemcpy(hy, dy, n * 4, hipMemcpyDeviceToHost));
-    double worst = 0; for (int i = 0; i < n; ++i) { const double e = exp2((double)hx[i]); const double r = fabs(hy[i] - e) / e; if (r > worst) worst = r; }
-    printf("packed-f16 2^x on [-12, 0]: max relative error %.2e (f16 rounding alone: 4.9e-4)\n", worst);
-  }
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   const int iters = 20000;
   const char* names[4] = {"MFMAs only", "2 v_exp_f32 + v_cvt_pk per MFMA (today)", "half of the pairs by the packed polynomial", "all pairs by the packed polynomial"};

@@ -50,6 +50,7 @@ struct AttnArgs {
   int nqb;               // query blocks per (b, h)
   float c;               // scale * log2(e)
   unsigned long long* stamps;   // diagnostic builds only
+  int xcd_map;           // lab builds only (DVD_ATTN_XCDMAP, r64x): 0 product map, 1 no remap, 2 two problems interleaved
 };
 
 __device__ __forceinline__ int kappa(int r) {  // swap bits 2 and 3
@@ -1429,8 +1430,18 @@ __global__ void __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(R64X_CO
     const int q = nwg / 8, rr = nwg % 8, xcd = id % 8, k = id / 8;
     id = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + k;
   }
-  const int qb = id % p.nqb;          // 256-row query blocks
-  const int bh = id / p.nqb;
+  int qb = id % p.nqb;                // 256-row query blocks
+  int bh = id / p.nqb;
+#ifdef DVD_LAB
+  // VERDICT r4 item 7 (profiles/r5_attn_xcd_map.txt): the product map above gives an XCD a contiguous range of ids, i.e. the
+  // 81 query blocks of a (sample, head) run on ONE XCD in consecutive residency slots.  1: no remap - consecutive query
+  // blocks land on different XCDs, every XCD streams every problem's K / V.  2: two problems interleaved on an XCD's slots.
+  if (p.xcd_map == 1) { qb = (int)blockIdx.x % p.nqb; bh = (int)blockIdx.x / p.nqb; }
+  if (p.xcd_map == 2) {
+    const int pair = id / (2 * p.nqb), r2 = id % (2 * p.nqb);
+    if (2 * pair + 1 < nwg / p.nqb) { bh = 2 * pair + (r2 & 1); qb = r2 >> 1; }
+  }
+#endif
   const int head = bh % p.heads, b = bh / p.heads;
   const int kvb = b / p.kv_div;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1875,6 +1886,7 @@ extern "C" int dvd_flash_attn(const dvd_attn_desc* d, void* stream) {
   p.nqb = cdiv(d->tq, 128);
   p.c = d->scale * 1.4426950408889634f;
   p.stamps = nullptr;
+  p.xcd_map = 0;
   const long nwg = (long)p.nqb * d->heads * d->batch;
   DVD_REQUIRE(nwg < (1l << 31), "flash_attn: grid too large");
   hipStream_t st = (hipStream_t)stream;
@@ -1896,6 +1908,7 @@ extern "C" int dvd_flash_attn(const dvd_attn_desc* d, void* stream) {
 #ifdef DVD_LAB
   // ---- lab build: every experiment and diagnostic variant behind its environment switch ----
   p.stamps = g_attn_stamps;
+  if (const char* xm = getenv("DVD_ATTN_XCDMAP")) p.xcd_map = atoi(xm);
   const bool dbg = getenv("DVD_ATTN_DEBUG"), bulk = getenv("DVD_ATTN_BULK");
   if (getenv("DVD_ATTN_V1")) fast = false;
   if (getenv("DVD_ATTN_R64") || getenv("DVD_ATTN_R64P") || getenv("DVD_ATTN_R64M") || getenv("DVD_ATTN_R64M_ABL") || getenv("DVD_ATTN_R64X_ABL") ||
