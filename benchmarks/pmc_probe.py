@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Runs one launch-heavy op a few times so rocprofv3 --pmc can attribute counters to it.
-usage: pmc_probe.py gemm|attn256|attn64|unwarp"""
+usage: pmc_probe.py gemm|gemm_res|gemm_split|attn256|attn64|gridsample8|unwarp"""
 import os
 import sys
 
@@ -21,6 +21,13 @@ if which == "gemm":
     out = torch.empty(M, N, dtype=torch.float16, device="cuda")
     for _ in range(3):
         ops.gemm_nt(a, b, out16=out)
+elif which == "gemm_res":                # the decoder's fc / conv2 form: f32 residual stream updated in place
+    M, N, K = 331776, 1536, 1536
+    a = torch.randn(M, K, device="cuda").half()
+    b = (torch.randn(N, K, device="cuda") * 0.02).half()
+    out = torch.zeros(M, N, dtype=torch.float32, device="cuda")
+    for _ in range(3):
+        ops.gemm_nt(a, b, out32=out, res=out)
 elif which == "gemm_split":
     M, N, K = 331776, 3072, 1536
     a = torch.randn(M, K, device="cuda").half()

@@ -10,7 +10,7 @@ cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
 out=gpurun_out/pmc_$round
 rm -rf $out; mkdir -p $out
 export PROBE_B=16
-for op in attn256 attn64 gemm gemm_split gridsample8; do
+for op in attn256 attn64 gemm gemm_res gemm_split gridsample8; do
   for c in FETCH_SIZE WRITE_SIZE; do
     timeout 300 rocprofv3 --pmc $c --output-format csv -d $out/traffic_${op}_$c -- python3 benchmarks/pmc_probe.py $op > $out/traffic_${op}_$c.log 2>&1
   done

@@ -235,7 +235,7 @@ __device__ __forceinline__ void packed_f16(const GemmArgs& p, const floatx16 (&a
     for (int n = 0; n < 4; ++n) bv[n] = bias[col_w + 32 * n + r];
   }
   const int act = p.act;
-  const bool hb = bias != nullptr;
+  const unsigned sel = odd ? 0x03020706u : 0x05040100u;      // v_perm_b32 (S0 = neighbour's word, S1 = own): see the pack below
   // per-lane byte offsets of the 8 packed registers of a tile (register pair (2 j, 2 j + 1) = rows a, a + 1): the same for all tiles
   unsigned oc[8];
 #pragma unroll
@@ -261,13 +261,14 @@ __device__ __forceinline__ void packed_f16(const GemmArgs& p, const floatx16 (&a
     gchar* sb = const_cast<gchar*>(cb) + ((size_t)(32 * m) * p.ldc16 + 32 * n) * 2;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-      // an odd lane takes its left neighbour's value of the odd row, an even lane its right neighbour's of the even row
-      // (quad permutes (0,0,2,2) / (1,1,3,3): the compiler folds each into the v_cndmask that selects by lane parity)
-      const float from_left = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v[2 * j + 1]), 0xA0, 0xF, 0xF, true));
-      const float from_right = __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v[2 * j]), 0xF5, 0xF, 0xF, true));
-      const half2v pk = {(_Float16)(odd ? from_left : v[2 * j]), (_Float16)(odd ? v[2 * j + 1] : from_right)};
+      // pack the lane's two rows of its column, trade the packed word with the neighbour lane (one DPP quad permute), and
+      // pick by a per-lane byte selector: even lane = (row a: own column | neighbour's), odd lane = (row a + 1: neighbour's | own)
+      const half2v own = {(_Float16)v[2 * j], (_Float16)v[2 * j + 1]};
+      const unsigned pw = __builtin_bit_cast(unsigned, own);
+      const unsigned qw = (unsigned)__builtin_amdgcn_mov_dpp((int)pw, 0xB1, 0xF, 0xF, true);
+      const unsigned pk = __builtin_amdgcn_perm(qw, pw, sel);
       const int ro = 32 * m + cd_row(2 * j, h) + (odd ? 1 : 0);
-      if (FULL || ro < rows_left) *(__attribute__((address_space(1))) unsigned*)(sb + (size_t)oc[j]) = __builtin_bit_cast(unsigned, pk);
+      if (FULL || ro < rows_left) *(__attribute__((address_space(1))) unsigned*)(sb + (size_t)oc[j]) = pk;
     }
   }
 }
