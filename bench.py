@@ -322,7 +322,7 @@ def main(argv=None):
             # the gather pattern is set by the flow: the sampler's output under RANDOM synthetic weights is white-noise-
             # like (every pixel samples a random place), which no dewarping flow is; the roofline leg therefore uses a
             # document-like field - bicubic-upsampled 6x6 control points of amplitude 0.05 (up to ~35 degrees of local
-            # shear), the field of profiles/r1_warp_summary.txt and benchmarks/op_bench.py
+            # shear), the field of profiles/archive/r1_warp_summary.txt and benchmarks/op_bench.py
             ctrl = (torch.rand(B, 2, 6, 6, device=dev, generator=gen) - 0.5) * 0.1
             flow_doc = torch.nn.functional.interpolate(ctrl, size=(G, G), mode="bicubic", align_corners=True).contiguous()
             grid_full = torch.cat([ops.unwarp_grid(flow_doc[d:d + 1].contiguous(), FH, FW) for d in range(B)])   # [B,2,H,W]

@@ -4,7 +4,7 @@
 split (round 2's default), plain f16 - on both synthetic weight families:
   part A  G = 96, 1 document x 1 hypothesis: each against the CPU oracle (un-clamped x0 RMSE per step);
   part B  G = 288 (BASELINE's grid): GPU only, dithered and plain f16 against the SPLIT engine (whose own distance to
-          the oracle over the whole G = 288 loop is profiles/r2_parity_g288.json: 6.2e-4 un-clamped, plain family).
+          the oracle over the whole G = 288 loop is profiles/archive/r2_parity_g288.json: 6.2e-4 un-clamped, plain family).
 usage: python tests/tools/dither_drift.py > profiles/<round>_dither_drift.json"""
 import json
 import os
