@@ -1640,6 +1640,7 @@ extern "C" int dvd_gemm_nt(const dvd_gemm_desc* d, void* stream) {
 #ifdef DVD_LAB
     if (const char* e = getenv("DVD_GEMM_T384_DBG")) tdbg = atoi(e);
     if (const char* e = getenv("DVD_GEMM_T384_STAGGER")) p.stagger = atoi(e);
+    if (getenv("DVD_GEMM_T384_PRIO")) p.debug |= 0x100;
 #endif
     return launch_gemm_t384(p, d->batch, tdbg, stream);
   }

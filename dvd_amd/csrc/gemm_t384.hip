@@ -299,6 +299,11 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_t384_kernel(GemmArgs p) {
   const _Float16* B = (const _Float16*)p.B + z * p.sB;
   const unsigned pda = lds0 + (3 * wave) * 1024, pdb = lds0 + BOFF + (2 * wave) * 1024;
   bool first = true;
+#ifdef DVD_LAB
+  // lab (DVD_GEMM_T384_PRIO): static priority for the second-dispatched half of the workgroup (MI355X_MICROARCH.md, two waves
+  // per SIMD, item 4)
+  if ((p.debug & 0x100) && wave >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
   // De-synchronise the chip: every CU runs the same tiles at the same pace, so all 256 epilogues would store at the same
   // moment - 50 MB bursts against the HBM write rate (the epilogue of the f16 flavour measured 11.4 k cycles = 5.7 TB/s
   // chip-wide, while the kernel's AVERAGE write rate is 0.7 TB/s).  A start-up delay of up to 15 quanta spreads the

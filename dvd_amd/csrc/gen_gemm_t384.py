@@ -46,7 +46,8 @@ S_A, S_B, S_CNT = 80, 82, 84
 SGPR_CLOBBERS = [f"s{i}" for i in range(80, 86)]
 MF = "v_mfma_f32_32x32x16_f16"
 ABL = set()        # timing ablations (lab builds only; garbage results): "dma", "read", "bar"
-PIECES_AFTER = (1, 3, 5, 7, 9)     # phase-2 MFMA gaps that carry an LDS-DMA piece
+# phase-2 MFMA gaps that carry an LDS-DMA piece (T384_PIECES: experiment switch of the generator, not a product option)
+PIECES_AFTER = tuple(int(x) for x in os.environ.get("T384_PIECES", "1,3,5,7,9").split(","))
 
 
 def vq(lo):
