@@ -1641,6 +1641,7 @@ extern "C" int dvd_gemm_nt(const dvd_gemm_desc* d, void* stream) {
     if (const char* e = getenv("DVD_GEMM_T384_DBG")) tdbg = atoi(e);
     if (const char* e = getenv("DVD_GEMM_T384_STAGGER")) p.stagger = atoi(e);
     if (getenv("DVD_GEMM_T384_PRIO")) p.debug |= 0x100;
+    if (getenv("DVD_GEMM_T384_NT")) p.debug |= 0x200;
 #endif
     return launch_gemm_t384(p, d->batch, tdbg, stream);
   }

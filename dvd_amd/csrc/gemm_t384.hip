@@ -215,6 +215,11 @@ __device__ __forceinline__ void direct_f32(const GemmArgs& p, const floatx16 (&a
     for (int k = 0; k < 8; ++k) {
       const int ro = 32 * m + 16 * u + (k & 3) + 8 * (k >> 2);
       gchar* sb = const_cast<gchar*>(cb) + ((size_t)ro * p.ldc + 32 * n) * 4;    // wave-uniform
+#ifdef DVD_LAB
+      if (p.debug & 0x200) {                       // lab (DVD_GEMM_T384_NT): streaming stores - are they acknowledged sooner?
+        if (FULL || ro < rows_left) __builtin_nontemporal_store(v[k], (gfloat*)(sb + (size_t)oc));
+      } else
+#endif
       if (FULL || ro < rows_left) *(gfloat*)(sb + (size_t)oc) = v[k];
     }
   }
