@@ -105,37 +105,53 @@ def broadcast_weights(blob, world, sync=None):
     return (time.perf_counter() - t0) * 1e3
 
 
-def launch_ranks(n, argv):
+LAUNCH_DEADLINE_S = 3 * 3600      # launch_ranks: no run of this bench is longer; a hung rank must not block the parent for ever
+
+
+def launch_ranks(n, argv, deadline_s=None, attempts=3):
     """`python bench.py --gpus N` typed without a launcher: start N fresh rank processes of this same script (one per
     GPU, env:// rendezvous on 127.0.0.1 - the reference's own set-up, idf/dist_util.py:21-41, minus MPI), let them print
-    (only rank 0 does), and return the worst exit code.  The parent has not touched the GPU and never will: nothing is
-    re-exec'd, the ranks are children."""
+    (only rank 0 does), and return the worst exit code (a signal exit -s is reported as 128 + s).  The parent has not
+    touched the GPU and never will: nothing is re-exec'd, the ranks are children.
+    A rank that dies takes the others down after a grace period (terminate, then kill: a rank stuck in a GPU collective may
+    ignore SIGTERM); an overall deadline does the same for a rank that hangs without dying; the free-port probe is racy by
+    nature (the socket is closed before rank 0 binds it), so a run whose ranks ALL fail within seconds is retried on a new port."""
     import socket
     import subprocess
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get(
-                       "HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
-    worst, failed_at = 0, None
-    while any(p.poll() is None for p in procs):
-        for p in procs:
-            rc = p.poll()
-            if rc not in (None, 0) and failed_at is None:
-                failed_at = time.monotonic()            # a rank died: the others would wait in a collective for ever
-        if failed_at is not None and time.monotonic() - failed_at > 20.0:
-            for p in procs:
-                if p.poll() is None:
-                    p.terminate()                        # by handle, never by pattern
-        time.sleep(0.2)
-    for p in procs:
-        rc = p.wait()
-        worst = worst if rc == 0 else (rc if worst == 0 else worst)
+    deadline_s = LAUNCH_DEADLINE_S if deadline_s is None else deadline_s
+    worst = 0
+    for attempt in range(attempts):
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        procs = []
+        for r in range(n):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get(
+                           "HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
+        t_start, failed_at, term_at = time.monotonic(), None, None
+        while any(p.poll() is None for p in procs):
+            now = time.monotonic()
+            if failed_at is None and (any(p.poll() not in (None, 0) for p in procs) or now - t_start > deadline_s):
+                failed_at = now                              # a rank died (the others would wait in a collective for ever) or hangs
+            if failed_at is not None and term_at is None and (now - failed_at > 20.0 or now - t_start > deadline_s):
+                term_at = now
+                for p in procs:
+                    if p.poll() is None:
+                        p.terminate()                        # by handle, never by pattern
+            if term_at is not None and now - term_at > 10.0:
+                for p in procs:
+                    if p.poll() is None:
+                        p.kill()                             # SIGTERM ignored (stuck in a collective): escalate
+            time.sleep(0.2)
+        codes = [p.wait() for p in procs]
+        codes = [128 - rc if rc < 0 else rc for rc in codes]
+        worst = next((rc for rc in codes if rc != 0), 0)
+        hung = time.monotonic() - t_start > deadline_s
+        if worst == 0 or hung or time.monotonic() - t_start > 15.0 or not all(codes):
+            return 124 if hung and worst == 0 else worst     # only an instant failure of EVERY rank (the port) is retried
     return worst
 
 

@@ -4,6 +4,7 @@ import hashlib
 import os
 import socket
 import sys
+import time
 
 import pytest
 import torch
@@ -352,3 +353,27 @@ def test_bench_launcher_propagates_a_rank_failure(tmp_path):
            "--ddim-steps", "3", "--full-res", "32x24", "--no-cpu-baseline", "--backend", "gloo"]
     res = subprocess.run(cmd, env=env, cwd=str(tmp_path), capture_output=True, text=True, timeout=600)
     assert res.returncode != 0
+
+
+def test_bench_launcher_ends_a_hung_rank(tmp_path, monkeypatch):
+    """a rank that hangs without dying - and ignores SIGTERM, like one stuck in a GPU collective - must not block
+    the parent for ever: past the overall deadline the ranks are terminated, then killed, and the launcher returns a positive
+    exit code (signal exits are reported as 128 + signal)."""
+    import importlib.util
+    (tmp_path / "sitecustomize.py").write_text(
+        'import os, signal, time\n'
+        'if os.environ.get("DVD_TEST_HANG") == "1" and "RANK" in os.environ:\n'
+        '    signal.signal(signal.SIGTERM, signal.SIG_IGN)\n'
+        '    time.sleep(600)\n')
+    monkeypatch.setenv("DVD_TEST_HANG", "1")
+    monkeypatch.setenv("PYTHONPATH", os.pathsep.join([str(tmp_path), ROOT, os.environ.get("PYTHONPATH", "")]))
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        monkeypatch.delenv(k, raising=False)
+    spec = importlib.util.spec_from_file_location("bench_launcher", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    t0 = time.monotonic()
+    rc = bench.launch_ranks(2, ["--gpus", "2", "--steps", "1"], deadline_s=3.0)
+    dt = time.monotonic() - t0
+    assert rc > 0 and rc in (124, 128 + 9, 128 + 15), rc
+    assert dt < 60, dt
