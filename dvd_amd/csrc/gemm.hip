@@ -17,6 +17,9 @@
 #include <stdlib.h>
 #include <type_traits>
 
+#ifndef T384_WALK
+#define T384_WALK 0         // tile walk of gemm_nt_t384_kernel for six N tiles: 0 row-major, 1 two groups of three (tile_coords)
+#endif
 #ifndef T384_STAGGER
 #define T384_STAGGER 0      // start-up delay quantum of gemm_nt_t384_kernel (x 1024 cycles x 0..15 per workgroup); see the kernel
 #endif
@@ -1522,11 +1525,12 @@ extern "C" int dvd_gemm_nt(const dvd_gemm_desc* d, void* stream) {
   { const char* dbg = getenv("DVD_GEMM_DEBUG"); p.debug = dbg ? atoi(dbg) : 0; }
   { const char* sg = getenv("DVD_GEMM_STAGGER"); p.stagger = sg ? atoi(sg) : 0; }   // measured: no effect
   p.stamps = g_gemm_stamps;
+  p.walk = 0;
   const bool lab_scalar_epi = getenv("DVD_GEMM_SCALAR_EPILOGUE"), lab_v1 = getenv("DVD_GEMM_V1"),
              lab_twopass = getenv("DVD_GEMM_TWOPASS"), lab_nonpersistent = getenv("DVD_GEMM_NONPERSISTENT"),
              lab_spread = getenv("DVD_GEMM_SPREAD"), lab_no_t384 = getenv("DVD_GEMM_NO_T384") || p.debug;
 #else
-  p.debug = 0; p.stagger = 0; p.stamps = nullptr;
+  p.debug = 0; p.stagger = 0; p.stamps = nullptr; p.walk = 0;
   constexpr bool lab_scalar_epi = false, lab_v1 = false, lab_twopass = false, lab_nonpersistent = false, lab_no_t384 = false;
 #endif
   {
@@ -1637,10 +1641,12 @@ extern "C" int dvd_gemm_nt(const dvd_gemm_desc* d, void* stream) {
     p.ntm = cdiv(d->M, 384); p.ntn = d->N / 256;
     int tdbg = 0;
     p.stagger = T384_STAGGER;
+    p.walk = T384_WALK;
 #ifdef DVD_LAB
     if (const char* e = getenv("DVD_GEMM_T384_DBG")) tdbg = atoi(e);
     if (const char* e = getenv("DVD_GEMM_T384_STAGGER")) p.stagger = atoi(e);
     if (getenv("DVD_GEMM_T384_PRIO")) p.debug |= 0x100;
+    if (const char* e = getenv("DVD_GEMM_T384_WALK")) p.walk = atoi(e);
     if (getenv("DVD_GEMM_T384_NT")) p.debug |= 0x200;
 #endif
     return launch_gemm_t384(p, d->batch, tdbg, stream);

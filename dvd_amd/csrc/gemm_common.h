@@ -25,6 +25,7 @@ struct GemmArgs {
   int act;       // 0 none, 1 GELU(tanh), 2 ReLU
   int bias_row;  // bias indexed by row instead of column
   int ntm, ntn;  // tile counts
+  int walk;          // gemm_nt_t384_kernel: tile walk variant (tile_coords)
   int stagger;       // large-tile kernel: start-up delay quantum (x4096 cycles) of the first round of workgroups
   int vec_epilogue;  // 1: LDS-staged row-contiguous stores (needs N % 8 == 0 and 16-byte aligned rows)
   int debug;     // timing ablations only (DVD_GEMM_DEBUG): 1 = no operand loads in the K loop, 2 = no MFMAs,
@@ -41,9 +42,19 @@ struct GemmArgs {
 //    each at K = 1536) + 4 W panels (1.57 MB each, hi + lo), the minimum of a_bytes * rows + w_bytes * cols at rows * cols
 //    = 32; at N = 3072 the row-major walk streamed all 12 W panels (18.9 MB) through L2 for every 32 tiles.
 // The order changes which workgroup computes a tile, never a tile's arithmetic.
-__device__ __forceinline__ void tile_coords(int vid, int ntm, int ntn, int& tm, int& tn) {
+__device__ __forceinline__ void tile_coords(int vid, int ntm, int ntn, int& tm, int& tn, int walk = 0) {
   const int nwg = ntm * ntn;
   const int q = nwg / 8, rr = nwg % 8, xcd = vid % 8, k = vid / 8;
+  if (walk == 1 && ntn == 6 && (ntm & 7) == 0) {
+    // six N tiles (the N = 1536 GEMMs) in two groups of three: an XCD's 32 concurrent tiles are ~10.7 row panels x 3 W panels
+    // - the three W panels (2.4 MB at K = 1536) stay in its 4 MB L2 while the A panels stream through, each read twice overall;
+    // row-major over all six keeps 4.7 MB of W panels + 6.3 MB of A panels in flight and re-fetches W about every other time
+    const int rows = ntm >> 3, per = rows * 3;
+    const int cg = k / per, rem = k - cg * per;
+    tm = xcd * rows + rem / 3;
+    tn = 3 * cg + rem % 3;
+    return;
+  }
   if (rr == 0 && (ntm & 7) == 0 && (ntn & 3) == 0 && ntn >= 8) {
     const int rows = ntm >> 3;               // row panels per XCD
     const int grp = 8 * ntn;                 // tiles in a group of 8 row panels (a multiple of 32)

@@ -319,7 +319,7 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_t384_kernel(GemmArgs p) {
   }
   for (int vid = blockIdx.x; vid < nwg; vid += gridDim.x) {
     int tm, tn;
-    tile_coords(vid, p.ntm, p.ntn, tm, tn);
+    tile_coords(vid, p.ntm, p.ntn, tm, tn, p.walk);
     tm = __builtin_amdgcn_readfirstlane(tm); tn = __builtin_amdgcn_readfirstlane(tn);
     const int bm0 = tm * 384, bn0 = tn * 256;
 #ifdef DVD_LAB
@@ -374,7 +374,7 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_t384_kernel(GemmArgs p) {
         // the next tile of this workgroup (the last one re-loads its own first half slabs: valid addresses, never read)
         const int vnext = vid + (int)gridDim.x < nwg ? vid + (int)gridDim.x : vid;
         int tm2, tn2;
-        tile_coords(vnext, p.ntm, p.ntn, tm2, tn2);
+        tile_coords(vnext, p.ntm, p.ntn, tm2, tn2, p.walk);
         tm2 = __builtin_amdgcn_readfirstlane(tm2); tn2 = __builtin_amdgcn_readfirstlane(tn2);
         const char* Anext = uniform_ptr((const char*)(A + (size_t)tm2 * 384 * p.lda));
         const char* Bnext = uniform_ptr((const char*)(B + (size_t)tn2 * 256 * p.ldb));
