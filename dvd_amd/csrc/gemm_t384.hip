@@ -225,6 +225,82 @@ __device__ __forceinline__ void direct_f32(const GemmArgs& p, const floatx16 (&a
   }
 }
 
+#ifdef DVD_LAB
+// ---- the residual flavour, PHASED (f32 output = residual + relu(acc + bias), the decoder's fc / conv2): five phases of two or
+// three accumulators.  A phase finishes its tiles from the residual rows requested one phase earlier, then requests the next
+// phase's residual values and only THEN issues its own stores - so the loads a phase waits for are older than the
+// stores issued beside them, and the only stores they are younger than were issued a whole phase (~2.5 k cycles: about one
+// store acknowledgement) earlier.  The interleaved form above waits 24 times per tile, each time on stores three small steps
+// old: 30-37 k cycles per tile; this one waits five times.
+// MEASURED (profiles/r5_gemm_t384_res_phased.txt) and NOT adopted: 37.4 k cycles per tile against 37.6 k for the interleaved form, the
+// same wall time - so the acknowledgement order is not what holds the residual epilogue.  With 6-12 KB of residual in flight per
+// wave the epilogue reads 393 KB per CU at ~16 B/clk: the latency of an HBM read under every CU's mixed read / write burst times
+// the bytes the free registers can keep in flight; a start-up stagger of the workgroups (which would spread the bursts) moves it
+// by 2 % (`r5_gemm_t384_stagger_res.txt`).  LAB ONLY (DVD_GEMM_T384_RES_PHASED).
+template <bool FULL>
+__device__ __forceinline__ void phased_res_f32(const GemmArgs& p, const floatx16 (&acc)[12], int row_w, int col_w, int lane, float* C32,
+                                               const float* bias, const float* res) {
+  const int r = lane & 31, h = lane >> 5;
+  float bv[4] = {0.f, 0.f, 0.f, 0.f};
+  if (bias) {
+#pragma unroll
+    for (int n = 0; n < 4; ++n) bv[n] = bias[col_w + 32 * n + r];
+  }
+  const bool relu = p.act == 2;
+  const unsigned oc = (unsigned)((4 * h) * p.ldc + r) * 4u, orr = (unsigned)((4 * h) * p.ldres + r) * 4u;
+  const gchar* cb = (const gchar*)uniform_ptr((const char*)(C32 + (size_t)row_w * p.ldc + col_w));
+  const gchar* rb = (const gchar*)uniform_ptr((const char*)(res + (size_t)row_w * p.ldres + col_w));
+  const int rows_left = p.M - row_w - 4 * h;
+  float rv[3][16];
+  auto load_tile = [&](int t, float (&dst)[16]) {
+    const int m = t >> 2, n = t & 3;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int ro = 32 * m + (i & 3) + 8 * (i >> 2);
+      const gchar* sb = rb + ((size_t)ro * p.ldres + 32 * n) * 4;               // wave-uniform
+      dst[i] = (FULL || ro < rows_left) ? *(const gfloat*)(sb + (size_t)orr) : 0.f;
+    }
+  };
+  // phases of 2, 2, 3, 3, 2 accumulators: the first two are the VGPR-resident ones, finished in place, and are kept small so
+  // that (accumulators still in VGPRs) + (results waiting for their stores) + (the next phase's residual) stays under ~100
+  constexpr int PH[6] = {0, 2, 4, 7, 10, 12};
+#pragma unroll
+  for (int t = PH[0]; t < PH[1]; ++t) load_tile(t, rv[t - PH[0]]);
+#pragma unroll
+  for (int ph = 0; ph < 5; ++ph) {
+    float out[3][16];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = PH[ph]; t < PH[ph + 1]; ++t) {
+      const int j = t - PH[ph], n = t & 3;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        float x = acc[t][i] + bv[n];
+        x = relu ? fmaxf(x, 0.f) : x;
+        out[j][i] = x + rv[j][i];
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);     // the next phase's residual is requested BEFORE this phase's stores
+    if (ph < 4) {
+#pragma unroll
+      for (int t = PH[ph + 1]; t < PH[ph + 2]; ++t) load_tile(t, rv[t - PH[ph + 1]]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = PH[ph]; t < PH[ph + 1]; ++t) {
+      const int j = t - PH[ph], m = t >> 2, n = t & 3;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int ro = 32 * m + (i & 3) + 8 * (i >> 2);
+        gchar* sb = const_cast<gchar*>(cb) + ((size_t)ro * p.ldc + 32 * n) * 4;    // wave-uniform
+        if (FULL || ro < rows_left) *(gfloat*)(sb + (size_t)oc) = out[j][i];
+      }
+    }
+  }
+}
+
+#endif  // DVD_LAB
+
 // ---- fast epilogue 2: f16 output only (bias, ReLU / GELU), NO LDS either.  Bias, activation and the f16 rounding happen in
 // the accumulator layout (a lane = one column); neighbouring lanes then trade one value per register PAIR through a DPP
 // quad permute, so that an even lane holds (row a: columns r, r + 1) and its odd neighbour (row a + 1: columns r - 1, r) as
@@ -417,7 +493,13 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_t384_kernel(GemmArgs p) {
       const int row_w = bm0 + 96 * wr, col_w = bn0 + 128 * wc;
       if constexpr (FL == 0) packed_f16<FULL>(p, acc, row_w, col_w, lane_e, C16, bias);
       else if constexpr (FL == 1) direct_f32<false, FULL>(p, acc, row_w, col_w, lane_e, C32, bias, res);
-      else if constexpr (FL == 2) direct_f32<true, FULL>(p, acc, row_w, col_w, lane_e, C32, bias, res);
+      else if constexpr (FL == 2) {
+#ifdef DVD_LAB
+        if (p.debug & 0x400) phased_res_f32<FULL>(p, acc, row_w, col_w, lane_e, C32, bias, res);    // lab: the phased form (measured equal)
+        else
+#endif
+          direct_f32<true, FULL>(p, acc, row_w, col_w, lane_e, C32, bias, res);
+      }
       else if constexpr (FL == 3) epilogue<0>(p, stage, acc, row_w, col_w, lane_e, C32, C16, bias, res);
       else epilogue<1>(p, stage, acc, row_w, col_w, lane_e, C32, C16, bias, res);
     }
