@@ -171,10 +171,10 @@ __device__ __forceinline__ void direct_f32(const GemmArgs& p, const floatx16 (&a
   const gchar* cb = (const gchar*)uniform_ptr((const char*)(C32 + (size_t)row_w * p.ldc + col_w));
   const gchar* rb = RES ? (const gchar*)uniform_ptr((const char*)(res + (size_t)row_w * p.ldres + col_w)) : nullptr;
   const int rows_left = p.M - row_w - 4 * h;          // rows of this lane half that exist (ragged last row tile)
-  // half tiles (registers 8 u .. 8 u + 7 of accumulator t): 24 steps; the residual of a step is requested `ahead(s)` steps
-  // before it is used, always before the stores of the step that issues it.  Waiting for a load also waits for every OLDER
-  // store (vmcnt retires in order and counts stores), and a store's acknowledgement takes ~2.7 k cycles while every CU is
-  // storing: two steps ahead, a step cost 1375 cycles = 33 k per tile (profiles/r5_gemm_t384_epilogue_kind.txt).  The window
+  // half tiles (registers 8 u .. 8 u + 7 of accumulator t): 24 steps; the residual of a step is requested T384_RES_DEPTH steps
+  // before it is used, always before the stores of the step that issues it (waiting for a load also waits for every OLDER
+  // store: vmcnt retires in order and counts stores).  Two steps ahead a step cost 1375 cycles = 33 k per tile
+  // (profiles/r5_gemm_t384_epilogue_kind.txt); what bounds it is the bytes in flight, see phased_res_f32 below.  The window
   // is three steps deep (T384_RES_DEPTH): what the 128 VGPRs hold beside the four VGPR-resident accumulators without spill
   // reloads inside the store stream - deeper windows (4, 5, and 2 -> 5 once those accumulators are stored) were compiled and
   // all spilled INTO the stream, where every reload is one more wait for a store.  The residual flavour therefore stays
