@@ -314,7 +314,7 @@ __device__ __forceinline__ void store_f4_nt(float* base, uint32_t byte_off, floa
 }
 
 // every global access below is "wave-uniform 64-bit base (SGPR pair) + 32-bit lane byte offset", 16 bytes per lane
-template <int TW, int LCAP, int NT>
+template <int TW, int LCAP, int NT, int DMA = 0>
 __global__ void __launch_bounds__(256) grid_sample_lds_kernel(
     const float* __restrict__ src, const float* __restrict__ grid, float* __restrict__ out, int c, int hin, int win, int h,
     int w, int src_batch_div, int ntx, int nty, unsigned tiles_total, unsigned tiles_per_xcd) {
@@ -390,6 +390,24 @@ __global__ void __launch_bounds__(256) grid_sample_lds_kernel(
     }
     const float* s0 = s + (size_t)ymin * win + x0a;                           // uniform
     for (int ch0 = 0; ch0 < c; ch0 += LCG) {
+      if constexpr (DMA) {
+        // lab (round 5): the box goes global -> LDS directly (global_load_lds_dwordx4: lane-linear 1-KiB chunks = exactly the
+        // compact [bh][bw4] float4 image): no staging registers, no ds_write.  A lane beyond the box writes its (unused) slot.
+        if (ch0) __syncthreads();                      // the previous channel group's taps have been read
+        typedef __attribute__((address_space(3))) void* lptr_t;
+        const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t)box;
+#pragma unroll
+        for (int j = 0; j < LCG; ++j) {
+          const float* pc = s0 + (size_t)min(ch0 + j, c - 1) * plane;         // uniform
+#pragma unroll
+          for (int it = 0; it < ITER; ++it) {
+            const unsigned dst = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(j * LCAP * 4 + (wv * 64 + 256 * it) * 16));
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %0" ::"s"(pc), "s"(dst), "v"(voff[it]) : "memory");
+          }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+      } else {
       float4 v[LCG][ITER];
 #pragma unroll
       for (int j = 0; j < LCG; ++j) {
@@ -404,6 +422,7 @@ __global__ void __launch_bounds__(256) grid_sample_lds_kernel(
         for (int it = 0; it < ITER; ++it)
           if (vok[it]) *reinterpret_cast<float4*>(&box[j * LCAP + (tid + 256 * it) * 4]) = v[j][it];
       __syncthreads();
+      }
 #pragma unroll
       for (int j = 0; j < LCG; ++j) {
         if (ch0 + j >= c) break;
@@ -752,13 +771,14 @@ extern "C" int dvd_grid_sample_bilinear_zeros_ac(const float* src, const float* 
   // LDS-staged tiles: 16-byte row loads need win % 4 == 0 and a 16-byte aligned source; chosen from the SHAPE only
   if (win >= 4 && win % 4 == 0 && w % 4 == 0 && ((uintptr_t)src % 16) == 0 && ((uintptr_t)grid % 16) == 0 &&
       ((uintptr_t)out % 16) == 0 && planes32 && out32 && warp_variant() == 0) {
-#define LDS_LAUNCH(TW_, CAP_, NT_)                                                                                    \
+#define LDS_LAUNCH(TW_, CAP_, NT_) LDS_LAUNCH_D(TW_, CAP_, NT_, 0)
+#define LDS_LAUNCH_D(TW_, CAP_, NT_, DMA_)                                                                            \
   {                                                                                                                   \
     const int ntx = cdiv(w, TW_), nty = cdiv(h, 1024 / TW_);                                                          \
     const size_t total = (size_t)ntx * nty * n;                                                                       \
     DVD_REQUIRE(total < (1ull << 31) - 8, "grid_sample: too many tiles");                                             \
     const unsigned per_xcd = (unsigned)((total + 7) / 8);                                                             \
-    grid_sample_lds_kernel<TW_, CAP_, NT_><<<per_xcd * 8u, 256, 0, (hipStream_t)stream>>>(                             \
+    grid_sample_lds_kernel<TW_, CAP_, NT_, DMA_><<<per_xcd * 8u, 256, 0, (hipStream_t)stream>>>(                       \
         src, grid, out, c, hin, win, h, w, src_batch_div, ntx, nty, (unsigned)total, per_xcd);                        \
   }
 #ifdef DVD_LAB
@@ -768,11 +788,17 @@ extern "C" int dvd_grid_sample_bilinear_zeros_ac(const float* src, const float* 
       case 3: LDS_LAUNCH(64, 4096, 0) return check_launch("grid_sample(lds 64x16 cap 4096)");
       case 4: LDS_LAUNCH(64, 3072, 0) return check_launch("grid_sample(lds 64x16 cap 3072)");
       case 5: LDS_LAUNCH(128, 4096, 0) return check_launch("grid_sample(lds 128x8 cap 4096)");
+      case 6: LDS_LAUNCH(32, 1536, 0) return check_launch("grid_sample(lds 32x32 cap 1536)");
+      case 7: LDS_LAUNCH(32, 1024, 0) return check_launch("grid_sample(lds 32x32 cap 1024)");
+      case 8: LDS_LAUNCH_D(32, 2048, 0, 1) return check_launch("grid_sample(lds 32x32 cap 2048 dma)");
+      case 9: LDS_LAUNCH_D(32, 1536, 0, 1) return check_launch("grid_sample(lds 32x32 cap 1536 dma)");
+      case 10: LDS_LAUNCH_D(32, 1024, 0, 1) return check_launch("grid_sample(lds 32x32 cap 1024 dma)");
       default: break;
     }
 #endif
     LDS_LAUNCH(LTW, LCAP_P, 0)
 #undef LDS_LAUNCH
+#undef LDS_LAUNCH_D
     return check_launch("grid_sample(lds)");
   }
   if (win >= 2 && planes32 && warp_variant() != 2) {
