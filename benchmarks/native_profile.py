@@ -5,6 +5,7 @@
 import os, statistics, sys, time
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__))); import _lab; LIBSEL = _lab.which()   # --lab selects the lab build
 import numpy as np
 import torch
 from dvd_amd import ops, prestage, sampler, schedule, synth

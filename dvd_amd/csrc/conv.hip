@@ -27,6 +27,26 @@ __global__ void __launch_bounds__(256) im2col3x3_kernel(const float* __restrict_
   out[idx] = v;
 }
 
+// the same matrix from a CHANNELS-LAST source [H, W, C], C % 4 == 0: one thread per (pixel, 4 consecutive columns) - the four
+// columns are four channels of one tap, 16 contiguous bytes on both sides (the element-wise kernel above ran at 1.5 TB/s of
+// stores; this form is bound by HBM)
+__global__ void __launch_bounds__(256) im2col3x3_nhwc4_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                              int ldo, int c, int h, int w, long total4) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total4) return;
+  const int l4 = ldo >> 2;
+  const long pix = idx / l4;
+  const int col = (int)(idx - pix * l4) << 2;
+  floatx4 v = {0.f, 0.f, 0.f, 0.f};
+  if (col < 9 * c) {
+    const int tap = col / c, ch = col - tap * c;
+    const int py = (int)(pix / w), px = (int)(pix - (long)py * w);
+    const int y = py + tap / 3 - 1, x = px + tap % 3 - 1;
+    if (y >= 0 && y < h && x >= 0 && x < w) v = *(const floatx4*)(in + ((size_t)y * w + x) * c + ch);
+  }
+  *(floatx4*)(out + pix * ldo + col) = v;
+}
+
 // channels-last 2x2 / stride 2 max-pool: in [H, W, C] -> out [H/2, W/2, C]
 __global__ void __launch_bounds__(256) maxpool2_nhwc_kernel(const float* __restrict__ in, float* __restrict__ out,
                                                             int c, int h, int w, long total4) {
@@ -92,6 +112,11 @@ extern "C" int dvd_im2col3x3(const float* in, long sc, long sy, long sx, float* 
   DVD_REQUIRE(in && out, "im2col3x3: null pointer");
   DVD_REQUIRE(c > 0 && h > 0 && w > 0 && ldo >= 9 * c, "im2col3x3: bad shape");
   const long total = (long)h * w * ldo;
+  if (sc == 1 && sx == c && sy == (long)w * c && c % 4 == 0 && ldo % 4 == 0 && ((uintptr_t)in % 16) == 0 &&
+      ((uintptr_t)out % 16) == 0) {
+    im2col3x3_nhwc4_kernel<<<cdiv(total / 4, 256), 256, 0, (hipStream_t)stream>>>(in, out, ldo, c, h, w, total / 4);
+    return check_launch("im2col3x3(nhwc)");
+  }
   im2col3x3_kernel<<<cdiv(total, 256), 256, 0, (hipStream_t)stream>>>(in, sc, sy, sx, out, ldo, c, h, w, total);
   return check_launch("im2col3x3");
 }

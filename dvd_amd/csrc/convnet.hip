@@ -111,49 +111,92 @@ __global__ void __launch_bounds__(256) conv_f32_narrow_kernel(const float* __res
 #pragma unroll
   for (int t = 0; t < NT; ++t) wp[t] = wgt + (size_t)min(32 * t + r, cout - 1) * kp + 4 * hh;
   cn_floatx16 acc[NT];
+  float bcol[NT];
 #pragma unroll
-  for (int t = 0; t < NT; ++t)
+  for (int t = 0; t < NT; ++t) {
+    bcol[t] = bias[min(32 * t + r, cout - 1)];
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+  }
   const cn_floatx4 zero4 = {0.f, 0.f, 0.f, 0.f};
-  int k0 = 0;
-  for (int tap = 0; tap < ks * ks; ++tap) {
+  // The K loop runs over 16-channel chunks n = tap * (cc / 16) + c0 / 16 in the order of the materialised matrix.  Operands
+  // of chunk n + PF are requested before chunk n's MFMAs are issued (round 5): on the nets' small maps (36 x 36 and below:
+  // a handful of workgroups on 256 CUs) nothing else hides a load, and without the prefetch every chunk cost one L2 round
+  // trip on top of its 8 MFMAs.  Same chunks, same order, same MFMA sequence: same bits.
+  constexpr int PF = 3, NS = PF + 1;       // chunk n lives in register set n % NS; the refill issued beside chunk n's MFMAs
+                                           // goes to the set chunk n - 1 has just left (never to registers still being read)
+  const int cpt = cc >> 4, nch = ks * ks * cpt;
+  cn_floatx4 A0[NS], A1[NS], B0[NS][NT], B1[NS][NT];
+  bool IN[NS];
+  auto fetch = [&](int n, cn_floatx4& a0, cn_floatx4& a1, cn_floatx4 (&b0)[NT], cn_floatx4 (&b1)[NT], bool& inside) {
+    const int tap = n / cpt, c0 = (n - tap * cpt) << 4;
     const int yy = y + (tap / ks - rad) * dil, xx = x + (tap % ks - rad) * dil;
     const bool ok = yy >= 0 && yy < h && xx >= 0 && xx < w;
-    const long q = ok ? img0 + (long)yy * w + xx : 0;
-    for (int c0 = 0; c0 < cc; c0 += 16, k0 += 16) {
-      // channels c0 + 4 hh .. + 3 and c0 + 8 + 4 hh .. + 3 (ca % 8 == 0: a chunk never straddles the two sources)
-      const int c1 = c0 + 4 * hh, c2 = c0 + 8 + 4 * hh;
-      cn_floatx4 a0 = zero4, a1 = zero4;
-      if (ok) {
-        a0 = c1 < ca ? *(const cn_floatx4*)(a + q * ca + c1) : *(const cn_floatx4*)(b + q * cb + (c1 - ca));
-        a1 = c2 < ca ? *(const cn_floatx4*)(a + q * ca + c2) : *(const cn_floatx4*)(b + q * cb + (c2 - ca));
-      }
-      cn_floatx4 b0[NT], b1[NT];
+    // taps outside the map read the lane's own pixel (always valid) and are zeroed when the chunk is consumed: every
+    // lane issues every load, so the number of loads in flight is known and the waits are counted
+    const long q = ok ? img0 + (long)yy * w + xx : pix;
+    // channels c0 + 4 hh .. + 3 and c0 + 8 + 4 hh .. + 3 (ca % 8 == 0: a chunk never straddles the two sources)
+    const int c1 = c0 + 4 * hh, c2 = c0 + 8 + 4 * hh;
+    const bool s1 = c1 < ca, s2 = c2 < ca;            // selects, not branches: one multiply per address
+    const float* p1 = (s1 ? a : b) + q * (s1 ? ca : cb) + (s1 ? c1 : c1 - ca);
+    const float* p2 = (s2 ? a : b) + q * (s2 ? ca : cb) + (s2 ? c2 : c2 - ca);
+    a0 = *(const cn_floatx4*)p1;
+    a1 = *(const cn_floatx4*)p2;
+    inside = ok;
+    const int k0 = n << 4;
 #pragma unroll
-      for (int t = 0; t < NT; ++t) { b0[t] = *(const cn_floatx4*)(wp[t] + k0); b1[t] = *(const cn_floatx4*)(wp[t] + k0 + 8); }
+    for (int t = 0; t < NT; ++t) { b0[t] = *(const cn_floatx4*)(wp[t] + k0); b1[t] = *(const cn_floatx4*)(wp[t] + k0 + 8); }
+  };
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
-#pragma unroll
-        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], b0[t][e], acc[t], 0, 0, 0);
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-#pragma unroll
-        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], b1[t][e], acc[t], 0, 0, 0);
+  for (int s = 0; s < PF; ++s) fetch(min(s, nch - 1), A0[s], A1[s], B0[s], B1[s], IN[s]);
+#define DVD_CONSUME(s_, nxt_)                                                                                       \
+  {                                                                                                                 \
+    constexpr int f_ = ((s_) + PF) % NS;                                                                            \
+    fetch(min((nxt_), nch - 1), A0[f_], A1[f_], B0[f_], B1[f_], IN[f_]);                                            \
+    __builtin_amdgcn_sched_barrier(0);     /* the refill is issued here, ahead of this chunk's MFMAs */                \
+    const cn_floatx4 a0 = IN[s_] ? A0[s_] : zero4, a1 = IN[s_] ? A1[s_] : zero4;                                    \
+    _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                                   \
+      _Pragma("unroll") for (int t = 0; t < NT; ++t)                                                                \
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], B0[s_][t][e], acc[t], 0, 0, 0);                        \
+    _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                                   \
+      _Pragma("unroll") for (int t = 0; t < NT; ++t)                                                                \
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], B1[s_][t][e], acc[t], 0, 0, 0);                        \
+  }
+  int n0 = 0;
+  for (; n0 + NS <= nch; n0 += NS) {       // whole groups: no branch between the waits
+    DVD_CONSUME(0, n0 + PF)
+    DVD_CONSUME(1, n0 + 1 + PF)
+    DVD_CONSUME(2, n0 + 2 + PF)
+    DVD_CONSUME(3, n0 + 3 + PF)
+    asm volatile("" ::: "memory");         // keeps the last refill on this side of the back edge
+  }
+  if (n0 < nch) {
+    DVD_CONSUME(0, n0 + PF)
+    if (n0 + 1 < nch) {
+      DVD_CONSUME(1, n0 + 1 + PF)
+      if (n0 + 2 < nch) DVD_CONSUME(2, n0 + 2 + PF)
     }
   }
+#undef DVD_CONSUME
+  static_assert(NS == 4, "the chunk loop is unrolled by 4");
+  // epilogue: every value first (one wait for the bias and the trailing prefetches), then the stores back to back - with the
+  // bias add inside the row test the compiler waited for ALL memory operations, i.e. the previous store, before each store
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     const int col = 32 * t + r;
-    if (col >= cout) continue;
-    const float bcol = bias[col];
+    float v[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-      const long row = m0 + (i & 3) + 8 * (i >> 2) + 4 * hh;
-      if (row >= rows) continue;
-      float v = acc[t][i] + bcol;
-      if (act == 2) v = fmaxf(v, 0.f);
-      out[row * cout + col] = v;
+      v[i] = acc[t][i] + bcol[t];
+      v[i] = act == 2 ? fmaxf(v[i], 0.f) : v[i];
+      asm volatile("" : "+v"(v[i]));       // the value exists before the row tests
+    }
+    if (col >= cout) continue;
+    float* op = out + m0 * cout + col;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int lr = (i & 3) + 8 * (i >> 2) + 4 * hh;
+      if (m0 + lr < rows) op[(long)lr * cout] = v[i];
     }
   }
 }
@@ -395,6 +438,22 @@ extern "C" int dvd_convnet_slot_shape(void* handle, int slot, int* h, int* w, in
   DVD_REQUIRE(slot >= 0 && slot < (int)n->slots.size() && n->slots[slot].set, "convnet_slot_shape: slot %d not defined", slot);
   *h = n->slots[slot].h; *w = n->slots[slot].w; *c = n->slots[slot].c;
   return DVD_OK;
+}
+
+extern "C" int dvd_conv3x3_nhwc_narrow(const float* in, int c, const float* wgt, int kp, const float* bias, float* out,
+                                       int cout, int h, int w, int relu, void* stream) {
+  DVD_REQUIRE(in && wgt && bias && out, "conv3x3_nhwc_narrow: null pointer");
+  DVD_REQUIRE(c > 0 && c % 16 == 0 && cout > 0 && cout <= 64 && kp >= 9 * c && kp % 4 == 0 && h > 0 && w > 0,
+              "conv3x3_nhwc_narrow: bad shape (c %d, cout %d, kp %d)", c, cout, kp);
+  DVD_REQUIRE(((uintptr_t)in % 16) == 0 && ((uintptr_t)wgt % 16) == 0, "conv3x3_nhwc_narrow: operands must be 16-byte aligned");
+  const long rows = (long)h * w;
+  const dim3 grd(cdiv(rows, 128));
+  hipStream_t st = (hipStream_t)stream;
+  if (cout <= 32)
+    conv_f32_narrow_kernel<1><<<grd, 256, 0, st>>>(in, c, nullptr, 0, wgt, kp, bias, out, cout, 3, 1, h, w, relu ? 2 : 0, rows);
+  else
+    conv_f32_narrow_kernel<2><<<grd, 256, 0, st>>>(in, c, nullptr, 0, wgt, kp, bias, out, cout, 3, 1, h, w, relu ? 2 : 0, rows);
+  return check_launch("conv3x3_nhwc_narrow");
 }
 
 extern "C" int dvd_convnet_run(void* handle, const float* in_nchw, const float* weights, void* workspace,

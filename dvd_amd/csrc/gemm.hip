@@ -234,7 +234,7 @@ __device__ __forceinline__ void epilogue_readback(const GemmArgs& p, float* stag
     else epilogue_block64<0>(__VA_ARGS__);                                                  \
   }
 
-template <bool F32>
+template <bool F32, int PD>
 __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(GemmArgs p) {
   using T = typename std::conditional<F32, float, _Float16>::type;
   constexpr int BK = F32 ? 16 : 64;                 // elements per K-step
@@ -291,24 +291,27 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(GemmArgs p) {
   const int nlo = (Blo || Alo) ? nkk : 0;
   const int nk = nkk + nlo;
 
-  // Register-staged prefetch, TWO K-tiles deep: tile j waits in register set (j & 1) for two full iterations
-  // before it is written to LDS, so a global load has ~2 x (16 MFMA x 2 waves) of matrix time to land.  With
-  // one-tile-deep staging every iteration stalled on L2/HBM latency (2 workgroups per CU cannot hide it).
-  u32x4 ra0[NLD], rb0[NLD], ra1[NLD], rb1[NLD];
-#define DVD_GLOAD(RA, RB, t_)                                                    \
+  // Register-staged prefetch, PD K-tiles deep: tile j waits in register set (j % PD) for PD full iterations before it is
+  // written to LDS, so a global load has ~PD x (16 MFMA x 2 waves) of matrix time to land.  With one-tile-deep staging every
+  // iteration stalled on L2/HBM latency (2 workgroups per CU cannot hide it).  PD = 2 is the product; PD = 4 (lab build,
+  // DVD_GEMM_PD4) measured +-3 % at the sampler's small row counts (profiles/r5_gemm_small_variants.txt), as did hoisting a
+  // K-tile's 16 fragment reads above its MFMAs (+8 %: slower): at M = 2048 (192 workgroups, one wave per SIMD) an iteration
+  // is a chain of dependent latencies - fragment read, MFMA, LDS store, barrier - that neither change shortens.
+  u32x4 ra[PD][NLD], rb[PD][NLD];
+#define DVD_GLOAD(s_, t_)                                                        \
   {                                                                              \
     const int tt_ = (t_);                                                        \
     const bool lo_ = tt_ < nlo;                                                  \
     const size_t kofs_ = (size_t)(lo_ ? tt_ : tt_ - nlo) * BK;                   \
     _Pragma("unroll") for (int i = 0; i < NLD; ++i) {                            \
-      RA[i] = *(const u32x4*)((lo_ ? gal[i] : ga[i]) + kofs_);                   \
-      RB[i] = *(const u32x4*)((lo_ ? gbl[i] : gb[i]) + kofs_);                   \
+      ra[s_][i] = *(const u32x4*)((lo_ ? gal[i] : ga[i]) + kofs_);               \
+      rb[s_][i] = *(const u32x4*)((lo_ ? gbl[i] : gb[i]) + kofs_);               \
     }                                                                            \
   }
-#define DVD_LSTORE(RA, RB, buf_)                                                 \
+#define DVD_LSTORE(s_, buf_)                                                     \
   _Pragma("unroll") for (int i = 0; i < NLD; ++i) {                              \
-    *(u32x4*)(&smem[buf_][0][lofs[i]]) = RA[i];                                  \
-    *(u32x4*)(&smem[buf_][1][lofs[i]]) = RB[i];                                  \
+    *(u32x4*)(&smem[buf_][0][lofs[i]]) = ra[s_][i];                              \
+    *(u32x4*)(&smem[buf_][1][lofs[i]]) = rb[s_][i];                              \
   }
 #define DVD_COMPUTE(buf_)                                                                          \
   {                                                                                                \
@@ -357,35 +360,44 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(GemmArgs p) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[m][n][i] = 0.f;
 
-  // Loads and LDS stores are issued UNCONDITIONALLY (tile index clamped to the last tile: a couple of
-  // redundant tile loads per workgroup) so that the number of loads in flight is the same on every path and
-  // hipcc can emit the counted vmcnt(8) that lets the younger register set stay in flight across the store.
+  // Loads and LDS stores are issued UNCONDITIONALLY (tile index clamped to the last tile: a few redundant tile loads per
+  // workgroup) so that the number of loads in flight is the same on every path and hipcc can emit the counted vmcnt that
+  // lets the younger register sets stay in flight across the store.
+  // step j: tile j is in LDS[j & 1]; tiles j+1 .. j+PD wait in sets (j+1) % PD .. (j+PD) % PD
   const int last = nk - 1;
-  DVD_GLOAD(ra0, rb0, 0)
-  DVD_GLOAD(ra1, rb1, min(1, last))
-  DVD_LSTORE(ra0, rb0, 0)
+#define DVD_STEP(j_, ph_)                                                        \
+  {                                                                              \
+    DVD_COMPUTE((ph_) & 1)                                                       \
+    DVD_LOSCALE(j_)                                                              \
+    DVD_LSTORE(((ph_) + 1) % PD, ((ph_) + 1) & 1)                                \
+    __syncthreads();                                                             \
+    DVD_GLOAD(((ph_) + 1) % PD, min((j_) + 1 + PD, last))                        \
+  }
+  static_assert(PD == 2 || PD == 4, "the step loop is unrolled by 4");
+  DVD_GLOAD(0, 0)
+  DVD_GLOAD(1, min(1, last))
+  if constexpr (PD == 4) {
+    DVD_GLOAD(2 % PD, min(2, last))
+    DVD_GLOAD(3 % PD, min(3, last))
+  }
+  DVD_LSTORE(0, 0)
   __syncthreads();
-  DVD_GLOAD(ra0, rb0, min(2, last))
-  const int pairs = nk >> 1;
-  for (int pp = 0; pp < pairs; ++pp) {
-    const int kt = 2 * pp;
-    // even step: tile kt is in LDS[0]; tile kt+1 waits in set 1, tile kt+2 in set 0
-    DVD_COMPUTE(0)
-    DVD_LOSCALE(kt)
-    DVD_LSTORE(ra1, rb1, 1)
-    __syncthreads();
-    DVD_GLOAD(ra1, rb1, min(kt + 3, last))
-    // odd step: tile kt+1 is in LDS[1]
-    DVD_COMPUTE(1)
-    DVD_LOSCALE(kt + 1)
-    DVD_LSTORE(ra0, rb0, 0)
-    __syncthreads();
-    DVD_GLOAD(ra0, rb0, min(kt + 4, last))
+  DVD_GLOAD(0, min(PD, last))
+  int kt = 0;
+  for (; kt + 4 <= nk; kt += 4) {
+    DVD_STEP(kt, 0)
+    DVD_STEP(kt + 1, 1)
+    DVD_STEP(kt + 2, 2)
+    DVD_STEP(kt + 3, 3)
   }
-  if (nk & 1) {   // odd tile count (no split weights): the last tile is already in LDS[0]
-    DVD_COMPUTE(0)
-    DVD_LOSCALE(nk - 1)
+  if (kt < nk) {
+    DVD_STEP(kt, 0)
+    if (kt + 1 < nk) {
+      DVD_STEP(kt + 1, 1)
+      if (kt + 2 < nk) DVD_STEP(kt + 2, 2)
+    }
   }
+#undef DVD_STEP
 #undef DVD_GLOAD
 #undef DVD_LSTORE
 #undef DVD_COMPUTE
@@ -442,42 +454,74 @@ __global__ void __launch_bounds__(256) gemm_f32_narrow_kernel(GemmArgs p) {
   for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
-  // K % 16 == 0 (checked by the host): two 8-deep chunks per iteration, the next pair prefetched (clamped at the end)
-  floatx4 a0 = *(const floatx4*)ap, a1 = *(const floatx4*)(ap + 8);
-  floatx4 b0[NT], b1[NT];
-#pragma unroll
-  for (int t = 0; t < NT; ++t) { b0[t] = *(const floatx4*)bp[t]; b1[t] = *(const floatx4*)(bp[t] + 8); }
-  for (int k0 = 0; k0 < p.K; k0 += 16) {
-    const int kn = min(k0 + 16, p.K - 16);
-    const floatx4 na0 = *(const floatx4*)(ap + kn), na1 = *(const floatx4*)(ap + kn + 8);
-    floatx4 nb0[NT], nb1[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) { nb0[t] = *(const floatx4*)(bp[t] + kn); nb1[t] = *(const floatx4*)(bp[t] + kn + 8); }
-#pragma unroll
-    for (int e = 0; e < 4; ++e)
-#pragma unroll
-      for (int t = 0; t < NT; ++t) acc[t] = mfma32_f32(a0[e], b0[t][e], acc[t]);
-#pragma unroll
-    for (int e = 0; e < 4; ++e)
-#pragma unroll
-      for (int t = 0; t < NT; ++t) acc[t] = mfma32_f32(a1[e], b1[t][e], acc[t]);
-    a0 = na0; a1 = na1;
-#pragma unroll
-    for (int t = 0; t < NT; ++t) { b0[t] = nb0[t]; b1[t] = nb1[t]; }
+  // K % 16 == 0 (checked by the host): 16-deep chunks (two 8-deep halves), chunk n in register set n % NS.  The refill
+  // issued beside chunk n's MFMAs is chunk n + PF and goes to the set chunk n - 1 has just left, so PF chunks are in flight
+  // and no load targets registers that are still being read (round 5; rounds 2-4 prefetched one chunk through a register
+  // copy, which the compiler had to wait for: every chunk cost a memory round trip on the nets' small maps).
+  constexpr int PF = 3, NS = PF + 1;
+  const int nch = p.K >> 4;
+  floatx4 A0[NS], A1[NS], B0[NS][NT], B1[NS][NT];
+#define DVD_FETCH(s_, n_)                                                                            \
+  {                                                                                                  \
+    const int kk_ = min((n_), nch - 1) << 4;                                                         \
+    A0[s_] = *(const floatx4*)(ap + kk_);                                                            \
+    A1[s_] = *(const floatx4*)(ap + kk_ + 8);                                                        \
+    _Pragma("unroll") for (int t = 0; t < NT; ++t) {                                                 \
+      B0[s_][t] = *(const floatx4*)(bp[t] + kk_);                                                    \
+      B1[s_][t] = *(const floatx4*)(bp[t] + kk_ + 8);                                                \
+    }                                                                                                \
   }
+#define DVD_CONSUME(s_, n_)                                                                          \
+  {                                                                                                  \
+    DVD_FETCH(((s_) + PF) % NS, (n_) + PF)                                                           \
+    __builtin_amdgcn_sched_barrier(0);   /* the refill is issued HERE, not clustered with later ones */ \
+    _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                    \
+      _Pragma("unroll") for (int t = 0; t < NT; ++t) acc[t] = mfma32_f32(A0[s_][e], B0[s_][t][e], acc[t]); \
+    _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                    \
+      _Pragma("unroll") for (int t = 0; t < NT; ++t) acc[t] = mfma32_f32(A1[s_][e], B1[s_][t][e], acc[t]); \
+    __builtin_amdgcn_sched_barrier(0);                                                               \
+  }
+  DVD_FETCH(0, 0)
+  DVD_FETCH(1, 1)
+  DVD_FETCH(2, 2)
+  int n0 = 0;
+  for (; n0 + NS <= nch; n0 += NS) {
+    DVD_CONSUME(0, n0)
+    DVD_CONSUME(1, n0 + 1)
+    DVD_CONSUME(2, n0 + 2)
+    DVD_CONSUME(3, n0 + 3)
+    asm volatile("" ::: "memory");         // keeps the last refill on this side of the back edge
+  }
+  if (n0 < nch) {
+    DVD_CONSUME(0, n0)
+    if (n0 + 1 < nch) {
+      DVD_CONSUME(1, n0 + 1)
+      if (n0 + 2 < nch) DVD_CONSUME(2, n0 + 2)
+    }
+  }
+#undef DVD_CONSUME
+#undef DVD_FETCH
+  static_assert(NS == 4, "the chunk loop is unrolled by 4");
+  // epilogue: every value first (one wait for the bias and the trailing prefetches), then the stores back to back - with the
+  // bias add inside the row test the compiler waited for all memory operations, i.e. the previous store, before each store
   float* C = p.C32 + z * p.sC32;
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     const int col = 32 * t + r;
-    if (col >= p.N) continue;
-    const float bcol = p.bias ? (p.bias + z * p.sBias)[col] : 0.f;
+    const float bcol = p.bias ? (p.bias + z * p.sBias)[min(col, p.N - 1)] : 0.f;
+    float v[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-      const int row = m0 + (i & 3) + 8 * (i >> 2) + 4 * h;
-      if (row >= p.M) continue;
-      float v = acc[t][i] + bcol;
-      if (p.act == 2) v = fmaxf(v, 0.f);
-      C[(size_t)row * p.ldc + col] = v;
+      v[i] = acc[t][i] + bcol;
+      v[i] = p.act == 2 ? fmaxf(v[i], 0.f) : v[i];
+      asm volatile("" : "+v"(v[i]));       // the value exists before the row tests
+    }
+    if (col >= p.N) continue;
+    float* cp = C + (size_t)m0 * p.ldc + col;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int lr = (i & 3) + 8 * (i >> 2) + 4 * h;
+      if (m0 + lr < p.M) cp[(size_t)lr * p.ldc] = v[i];
     }
   }
 }
@@ -1694,9 +1738,16 @@ extern "C" int dvd_gemm_nt(const dvd_gemm_desc* d, void* stream) {
   }
   p.ntm = cdiv(d->M, 128); p.ntn = cdiv(d->N, 128);
   dim3 grid(p.ntm * p.ntn, d->batch);
+#ifdef DVD_LAB
+  if (getenv("DVD_GEMM_PD4")) {       // lab: register prefetch four tiles deep (measured: no gain, see gemm_nt_kernel)
+    if (d->dtype == 1) gemm_nt_kernel<true, 4><<<grid, 256, 0, (hipStream_t)stream>>>(p);
+    else gemm_nt_kernel<false, 4><<<grid, 256, 0, (hipStream_t)stream>>>(p);
+    return check_launch("gemm_nt(pd4, lab)");
+  }
+#endif
   if (d->dtype == 1)
-    gemm_nt_kernel<true><<<grid, 256, 0, (hipStream_t)stream>>>(p);
+    gemm_nt_kernel<true, 2><<<grid, 256, 0, (hipStream_t)stream>>>(p);
   else
-    gemm_nt_kernel<false><<<grid, 256, 0, (hipStream_t)stream>>>(p);
+    gemm_nt_kernel<false, 2><<<grid, 256, 0, (hipStream_t)stream>>>(p);
   return check_launch("gemm_nt");
 }

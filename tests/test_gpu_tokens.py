@@ -151,6 +151,20 @@ def test_build_r_rows(ops, mode):
     assert float(rows[:, 1032:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("cin,cout,h,w", [(64, 64, 40, 24), (16, 32, 9, 13), (32, 48, 17, 5)])
+def test_implicit_conv_has_the_bits_of_im2col_plus_gemm(ops, cin, cout, h, w):
+    """dvd_conv3x3_nhwc_narrow (the pyramid's 64 -> 64 layer since round 5) against the im2col + exact-f32 GEMM pair it replaces:
+    same K order, same chunks, same MFMA sequence - equal bits, on maps whose row count is not a multiple of the wave's 32."""
+    x = rnd(f"pyi/x{cin}", (h * w, cin)).cuda()
+    wt, b = rnd(f"pyi/w{cin}", (cout, cin, 3, 3), -0.3, 0.3), rnd(f"pyi/b{cin}", (cout,), -0.1, 0.1).cuda()
+    wp = wt.permute(0, 2, 3, 1).reshape(cout, -1).contiguous().cuda()
+    a = ops.conv3x3_relu_nhwc(x, wp, b, cin, cout, h, w)
+    i = ops.conv3x3_relu_nhwc_implicit(x, wp, b, cin, cout, h, w)
+    assert torch.equal(a, i)
+    ref = F.relu(F.conv2d(x.cpu().reshape(1, h, w, cin).permute(0, 3, 1, 2), wt, b.cpu(), padding=1))[0].permute(1, 2, 0).reshape(h * w, cout)
+    assert (i.cpu() - ref).abs().max() < 5e-5
+
+
 def test_pyramid_pieces(ops):
     h = w = 16
     cin, cout = 8, 64
