@@ -74,7 +74,7 @@ __device__ __forceinline__ void epilogue_tile(const GemmArgs& p, const floatx16&
 // the wait the compiler places after a conditional load that is skipped at run time - also waits for the previous
 // iteration's global store to be acknowledged (~1300 cycles): the epilogue took 23 000 cycles per 256 x 256 tile, a
 // quarter of the kernel, 16 stores x 1300 (s_memtime stamps, identical to the cycle with and without other CUs storing).
-template <int EPI>
+template <int EPI, int NIT = 8>   // NIT 8-row iterations: 8 = the whole 64 x 64 block, 4 = a 32-row half of it
 __device__ __forceinline__ void epilogue_readback(const GemmArgs& p, float* stage, int row0, int col0, int lane,
                                                   float* C32, _Float16* C16, const float* bias, const float* res,
                                                   const float* gate);
@@ -117,10 +117,11 @@ __device__ __forceinline__ void epilogue_block64_m16(const GemmArgs& p, float* s
   epilogue_readback<EPI>(p, stage, row0, col0, lane, C32, C16, bias, res, gate);
 }
 
-template <int EPI>
+template <int EPI, int NIT>
 __device__ __forceinline__ void epilogue_readback(const GemmArgs& p, float* stage, int row0, int col0, int lane,
                                                   float* C32, _Float16* C16, const float* bias, const float* res,
                                                   const float* gate) {
+  static_assert(NIT == 8 || NIT == 4, "whole block or half block");
   // same-wave LDS accesses execute in order; the compiler inserts the lgkmcnt wait for the reads below.
   // Read back 8 consecutive columns per lane: 8 rows x 256 B (f32, two 16-B stores) / 128 B (f16, one 16-B store)
   // per wave-instruction (guide T21).
@@ -150,15 +151,15 @@ __device__ __forceinline__ void epilogue_readback(const GemmArgs& p, float* stag
   }
   if constexpr (EPI == 3) {
 #pragma unroll
-    for (int it = 0; it < 8; ++it) brow[it] = bias[min(row0 + it * 8 + (lane >> 3), p.M - 1)];
+    for (int it = 0; it < NIT; ++it) brow[it] = bias[min(row0 + it * 8 + (lane >> 3), p.M - 1)];
   }
   const bool relu = p.act == 2;
   // EPI 1 needs compile-time window slots (it & 3): unrolled by 4.  The other flavours are unrolled by 2 only: fully
   // unrolled, the compiler hoists every iteration's addresses out of the persistent tile loop and spills them, and each
   // scratch reload is a vmcnt(0) - i.e. a wait for the previous store again.
-  constexpr int EPI_UNROLL = EPI == 1 ? 4 : (EPI == 3 ? 8 : 2);
+  constexpr int EPI_UNROLL = EPI == 1 ? 4 : (EPI == 3 ? NIT : 2);
 #pragma unroll EPI_UNROLL
-  for (int it = 0; it < 8; ++it) {
+  for (int it = 0; it < NIT; ++it) {
     const int lr = it * 8 + (lane >> 3);
     const int row = row0 + lr;
     const floatx4 s0 = *(const floatx4*)(stage + lr * 64 + c8), s1 = *(const floatx4*)(stage + lr * 64 + c8 + 4);
@@ -166,7 +167,7 @@ __device__ __forceinline__ void epilogue_readback(const GemmArgs& p, float* stag
     if constexpr (EPI == 1) {
       rcur0 = rs0[it & 3];
       rcur1 = rs1[it & 3];
-      if (it + 4 < 8) {
+      if (it + 4 < NIT) {
         rs0[it & 3] = *(const floatx4*)res_row(it + 4);
         rs1[it & 3] = *(const floatx4*)(res_row(it + 4) + 4);
       }
@@ -427,6 +428,162 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(GemmArgs p) {
     }
   }
 }
+
+#ifdef DVD_LAB
+// ================================================================================================
+// LAB (DVD_GEMM_W8=1; measured, not adopted: profiles/r5_gemm_w8.txt).  The 128 x 128 tile of gemm_nt_kernel<false> by EIGHT
+// waves - two per SIMD: each 64 x 64 block of the tile belongs to a pair of waves, 64 x 32 each, so two chains of dependent
+// latencies (fragment read, MFMA, LDS store, barrier) interleave on every SIMD while the tile's global and LDS-store traffic
+// stays that of one tile.  Same operands per output in the same order: the bits of gemm_nt_kernel<false>, tested as such
+// (test_gemm_eight_wave_kernel).  Epilogue: a pair stages its block into one 64 x 64 LDS region; each wave reads back 32 rows
+// of it (epilogue_readback<EPI, 4>).  Result at the sampler's smallest row counts (2048 rows, 192-384 workgroups): 3-4 %
+// faster; nothing from 4096 rows on.  With prefetch depth and fragment-read placement also without effect, what bounds the
+// 128 x 128 tile there is not a latency chain inside the workgroup: the tile moves 32 KiB per 64-deep step for 2 x 128 x 128
+// x 64 FLOP - 64 FLOP per byte - and the kernel draws 8-12 TB/s from L2 at every row count (the guide's L2 streaming peak
+// is 17-19 TB/s with nothing else going on).
+// ================================================================================================
+__global__ void __launch_bounds__(512, 2) gemm_nt_w8_kernel(GemmArgs p) {
+  using T = _Float16;
+  constexpr int BK = 64, LROW = 128 + 16, CH = 8, NLD = 128 * CH / 512, EPC = 8, SLAB = 128 * LROW;
+  __shared__ __attribute__((aligned(16))) char smem[2][2][SLAB];
+
+  const int nwg = p.ntm * p.ntn;
+  int id = blockIdx.x;
+  {
+    const int q = nwg / 8, r = nwg % 8, xcd = id % 8, k = id / 8;
+    id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+  }
+  const int tm = id / p.ntn, tn = id % p.ntn;
+  const int bm0 = tm * 128, bn0 = tn * 128;
+  const int z = blockIdx.y;
+  const T* A = (const T*)p.A + z * p.sA;
+  const T* B = (const T*)p.B + z * p.sB;
+  const T* Blo = p.Blo ? (const T*)p.Blo + z * p.sB : nullptr;
+  const T* Alo = p.Alo ? (const T*)p.Alo + z * p.sA : nullptr;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int wc = wave & 1, wr = (wave >> 1) & 1, wn = wave >> 2;     // block (wr, wc) of the tile, 32-column half wn of it
+
+  const T* ga[NLD];
+  const T* gb[NLD];
+  const T* gbl[NLD];
+  const T* gal[NLD];
+  int lofs[NLD];
+#pragma unroll
+  for (int i = 0; i < NLD; ++i) {
+    const int c = tid + 512 * i;
+    const int row = c / CH, ch = c % CH;
+    const int ra = min(bm0 + row, p.M - 1), rb = min(bn0 + row, p.N - 1);
+    ga[i] = A + (size_t)ra * p.lda + ch * EPC;
+    gb[i] = B + (size_t)rb * p.ldb + ch * EPC;
+    gbl[i] = Blo ? Blo + (size_t)rb * p.ldb + ch * EPC : gb[i];
+    gal[i] = Alo ? Alo + (size_t)ra * p.lda + ch * EPC : ga[i];
+    lofs[i] = row * LROW + ch * 16;
+  }
+  const int nkk = p.K / BK;
+  const int nlo = (Blo || Alo) ? nkk : 0;
+  const int nk = nkk + nlo;
+
+  u32x4 ra[2][NLD], rb[2][NLD];       // register-staged prefetch, two K-tiles deep, as in gemm_nt_kernel
+#define DVD_GLOAD(s_, t_)                                                        \
+  {                                                                              \
+    const int tt_ = (t_);                                                        \
+    const bool lo_ = tt_ < nlo;                                                  \
+    const size_t kofs_ = (size_t)(lo_ ? tt_ : tt_ - nlo) * BK;                   \
+    _Pragma("unroll") for (int i = 0; i < NLD; ++i) {                            \
+      ra[s_][i] = *(const u32x4*)((lo_ ? gal[i] : ga[i]) + kofs_);               \
+      rb[s_][i] = *(const u32x4*)((lo_ ? gbl[i] : gb[i]) + kofs_);               \
+    }                                                                            \
+  }
+#define DVD_LSTORE(s_, buf_)                                                     \
+  _Pragma("unroll") for (int i = 0; i < NLD; ++i) {                              \
+    *(u32x4*)(&smem[buf_][0][lofs[i]]) = ra[s_][i];                              \
+    *(u32x4*)(&smem[buf_][1][lofs[i]]) = rb[s_][i];                              \
+  }
+#define DVD_COMPUTE(buf_)                                                                          \
+  {                                                                                                \
+    const char* sa = &smem[buf_][0][(64 * wr + r) * LROW];                                         \
+    const char* sb = &smem[buf_][1][(64 * wc + 32 * wn + r) * LROW];                               \
+    _Pragma("unroll") for (int s = 0; s < 4; ++s) {                                                \
+      half8 a[2];                                                                                  \
+      _Pragma("unroll") for (int m = 0; m < 2; ++m)                                                \
+        a[m] = *(const half8*)(sa + m * 32 * LROW + (16 * s + 8 * h) * 2);                         \
+      const half8 b = *(const half8*)(sb + (16 * s + 8 * h) * 2);                                  \
+      _Pragma("unroll") for (int m = 0; m < 2; ++m) acc[m] = mfma32_f16(a[m], b, acc[m]);          \
+    }                                                                                              \
+  }
+#define DVD_LOSCALE(kt_)                                                                           \
+  if (nlo && (kt_) == nlo - 1) {                                                                   \
+    _Pragma("unroll") for (int m = 0; m < 2; ++m)                                                  \
+      _Pragma("unroll") for (int i = 0; i < 16; ++i) acc[m][i] *= p.lo_scale;                      \
+  }
+  floatx16 acc[2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[m][i] = 0.f;
+
+  const int last = nk - 1;
+#define DVD_STEP(j_, ph_)                                                        \
+  {                                                                              \
+    DVD_COMPUTE((ph_) & 1)                                                       \
+    DVD_LOSCALE(j_)                                                              \
+    DVD_LSTORE(((ph_) + 1) & 1, ((ph_) + 1) & 1)                                 \
+    __syncthreads();                                                             \
+    DVD_GLOAD(((ph_) + 1) & 1, min((j_) + 3, last))                              \
+  }
+  DVD_GLOAD(0, 0)
+  DVD_GLOAD(1, min(1, last))
+  DVD_LSTORE(0, 0)
+  __syncthreads();
+  DVD_GLOAD(0, min(2, last))
+  int kt = 0;
+  for (; kt + 2 <= nk; kt += 2) {
+    DVD_STEP(kt, 0)
+    DVD_STEP(kt + 1, 1)
+  }
+  if (kt < nk) DVD_STEP(kt, 0)
+#undef DVD_STEP
+#undef DVD_GLOAD
+#undef DVD_LSTORE
+#undef DVD_COMPUTE
+#undef DVD_LOSCALE
+
+  float* C32 = p.C32 ? p.C32 + z * p.sC32 : nullptr;
+  _Float16* C16 = p.C16 ? p.C16 + z * p.sC16 : nullptr;
+  const float* bias = p.bias ? p.bias + z * p.sBias : nullptr;
+  const float* res = p.res ? p.res + z * p.sRes : nullptr;
+  const float* gate = p.gate ? p.gate + z * p.sGate : nullptr;
+  if (p.vec_epilogue) {
+    __syncthreads();                               // every wave is done reading operands
+    float* stage = (float*)(&smem[0][0][0]) + (wave & 3) * (64 * 64);     // the pair's 64 x 64 region (4 x 16 KiB)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int rr = cd_row(i, h);
+      stage[rr * 64 + 32 * wn + r] = acc[0][i];
+      stage[(32 + rr) * 64 + 32 * wn + r] = acc[1][i];
+    }
+    __syncthreads();                               // both halves of the block are staged
+    float* half = stage + wn * (32 * 64);
+    const int row0 = bm0 + 64 * wr + 32 * wn, col0 = bn0 + 64 * wc;
+    const bool brow_ = bias && p.bias_row;
+    if (p.pos || gate || (res && brow_)) epilogue_readback<2, 4>(p, half, row0, col0, lane, C32, C16, bias, res, gate);
+    else if (res) epilogue_readback<1, 4>(p, half, row0, col0, lane, C32, C16, bias, res, gate);
+    else if (brow_) epilogue_readback<3, 4>(p, half, row0, col0, lane, C32, C16, bias, res, gate);
+    else epilogue_readback<0, 4>(p, half, row0, col0, lane, C32, C16, bias, res, gate);
+  } else {
+    const int col = bn0 + 64 * wc + 32 * wn + r;
+    if (col < p.N) {
+      const float bcol = (bias && !p.bias_row) ? bias[col] : 0.f;
+#pragma unroll
+      for (int m = 0; m < 2; ++m) epilogue_tile(p, acc[m], bm0 + 64 * wr + 32 * m, col, h, bcol, C32, C16, bias, res, gate);
+    }
+  }
+}
+
+#endif  // DVD_LAB
 
 // ================================================================================================
 // Exact-f32 GEMM for NARROW outputs (N <= 64): the pre-stage conv nets' shape family - U2NETP's convs have 16 or 64 output
@@ -1739,6 +1896,10 @@ extern "C" int dvd_gemm_nt(const dvd_gemm_desc* d, void* stream) {
   p.ntm = cdiv(d->M, 128); p.ntn = cdiv(d->N, 128);
   dim3 grid(p.ntm * p.ntn, d->batch);
 #ifdef DVD_LAB
+  if (const char* e = getenv("DVD_GEMM_W8"); e && atoi(e) != 0 && d->dtype != 1) {   // lab: two waves per SIMD on each tile
+    gemm_nt_w8_kernel<<<grid, 512, 0, (hipStream_t)stream>>>(p);
+    return check_launch("gemm_nt(w8, lab)");
+  }
   if (getenv("DVD_GEMM_PD4")) {       // lab: register prefetch four tiles deep (measured: no gain, see gemm_nt_kernel)
     if (d->dtype == 1) gemm_nt_kernel<true, 4><<<grid, 256, 0, (hipStream_t)stream>>>(p);
     else gemm_nt_kernel<false, 4><<<grid, 256, 0, (hipStream_t)stream>>>(p);

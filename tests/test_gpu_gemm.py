@@ -490,3 +490,53 @@ def test_gemm_t384_batched_weights_on_a_side(ops, lab, monkeypatch):
     old = torch.zeros_like(out)
     ops.gemm_nt(w, x, out16=old, batch=Bn, N=N, strides={"B": N * K, "C16": M * N})
     assert torch.equal(out.cpu(), old.cpu())
+
+
+@pytest.mark.parametrize("M,N,K", [(2048, 1536, 1536), (2048, 384, 384), (300, 200, 128), (1024, 1088, 64), (77, 130, 192),
+                                   (4096, 640, 1088)])
+def test_gemm_eight_wave_kernel(ops, lab, monkeypatch, M, N, K):
+    """gemm_nt_w8_kernel (round 5: the 128 x 128 tile by two waves per SIMD, taken by f16 problems with few tiles - the sampler at
+    the reference's operating point) on the small family's calls: (hi, lo) weight pairs and single tensors, ragged M and N (scalar
+    epilogue path when N % 8 != 0), one K-tile (K = 64) and odd tile counts, bias / GELU -> f16, residual in place, positional
+    rows + gate, row bias (transposed outputs): against float64, and THE SAME BITS as the 4-wave kernel (lab switch
+    DVD_GEMM_W8=0), which runs the same MFMA sequence per accumulator and the same epilogue arithmetic."""
+    a = rnd(f"w8a{M}{K}", (M, K)).half().cuda()
+    w = rnd(f"w8b{N}{K}", (N, K)) * 0.2
+    hi = w.half()
+    lo = ((w - hi.float()) * 2048.0).half()
+    hi, lo = hi.cuda(), lo.cuda()
+    bias, res = rnd("w8bias", (N,)).cuda(), rnd(f"w8res{M}{N}", (M, N)).cuda()
+    brow = rnd("w8brow", (M,)).cuda()
+    pos, gate = rnd(f"w8pos{N}", (64, N)).cuda(), rnd(f"w8gate{N}", (2, N)).cuda()
+    ref = a.cpu().double() @ (hi.cpu().double() + lo.cpu().double() / 2048.0).t()
+
+    def run_all():
+        kw = dict(b_lo=lo, small_tiles=True)
+        o32 = torch.zeros(M, N, device="cuda")
+        ops.gemm_nt(a, hi, out32=o32, **kw)
+        g16 = torch.zeros(M, N, dtype=torch.float16, device="cuda")
+        ops.gemm_nt(a, hi, out16=g16, bias=bias, act=1, **kw)
+        r32 = res.clone()
+        ops.gemm_nt(a, hi, out32=r32, res=r32, bias=bias, **kw)
+        pg = torch.zeros(M, N, device="cuda")
+        ops.gemm_nt(a, hi, out32=pg, bias=bias, pos=pos, gate=gate, gate_rows=(M + 1) // 2, res=res, **kw)
+        t16 = torch.zeros(M, N, dtype=torch.float16, device="cuda")
+        ops.gemm_nt(a, hi, out16=t16, bias=brow, bias_row=True, small_tiles=True)          # single tensor, row bias
+        torch.cuda.synchronize()
+        return [t.cpu() for t in (o32, g16, r32, pg, t16)]
+
+    monkeypatch.setenv("DVD_GEMM_W8", "1")
+    new = run_all()
+    tol = 2e-4 * K ** 0.5
+    assert (new[0].double() - ref).abs().max().item() < tol
+    assert (new[1].double() - torch.nn.functional.gelu(ref + bias.cpu().double(), approximate="tanh")).abs().max().item() < 4e-2
+    assert (new[2].double() - (ref + bias.cpu().double() + res.cpu().double())).abs().max().item() < tol + 1e-5
+    rows = torch.arange(M)
+    pgref = (ref + bias.cpu().double() + pos.cpu().double()[rows % 64]) * gate.cpu().double()[rows // ((M + 1) // 2)] + res.cpu().double()
+    assert (new[3].double() - pgref).abs().max().item() < 2 * tol + 1e-5
+    ref1 = a.cpu().double() @ hi.cpu().double().t() + brow.cpu().double()[:, None]
+    assert (new[4].double() - ref1).abs().max().item() < 4e-2
+    monkeypatch.setenv("DVD_GEMM_W8", "0")
+    old = run_all()
+    for i, (x, y) in enumerate(zip(new, old)):
+        assert torch.equal(x, y), f"output {i}: the 8-wave and the 4-wave kernel must give the same bits"
