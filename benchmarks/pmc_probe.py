@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Runs one launch-heavy op a few times so rocprofv3 --pmc can attribute counters to it.
-usage: pmc_probe.py gemm|gemm_res|gemm_split|attn256|attn64|gridsample8|unwarp"""
+usage: pmc_probe.py gemm|gemm_res|gemm_split|gemm_small|attn256|attn64|gridsample8|unwarp"""
 import os
 import sys
 
@@ -36,6 +36,14 @@ elif which == "gemm_split":
     out = torch.empty(M, N, dtype=torch.float16, device="cuda")
     for _ in range(3):
         ops.gemm_nt(a, hi, out16=out, b_lo=lo, lo_scale=1.0)
+elif which == "gemm_small":              # the sampler's GEMM at the reference's operating point: 2048 rows, (hi, lo) pair, 128 x 128 tiles
+    M, N, K = 2048 * int(os.environ.get("PROBE_DOCS", "1")), 1536, 1536
+    a = torch.randn(M, K, device="cuda").half()
+    w = torch.randn(N, K, device="cuda") * 0.05
+    hi = w.half(); lo = ((w - hi.float()) * 2048.0).half()
+    out = torch.empty(M, N, dtype=torch.float32, device="cuda")
+    for _ in range(20):
+        ops.gemm_nt(a, hi, out32=out, b_lo=lo, small_tiles=True)
 elif which in ("attn256", "attn64"):  # attn256 at PROBE_B=16 is the bench launch shape (r64 kernel)
     hd = 256 if which == "attn256" else 64
     B, T = (int(os.environ.get("PROBE_B", "2")), 20736) if hd == 256 else (int(os.environ.get("PROBE_B", "8")), 20736)
