@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "common.h"
+#include "gemm_common.h"
 
 namespace dvd {
 
@@ -36,6 +37,17 @@ struct ConvNet {
 };
 
 static inline size_t al256(size_t b) { return (b + 255) & ~(size_t)255; }
+
+// in: [B*H*W, C] -> out: planar [B,C,H,W] (all images of a batch in one launch)
+__global__ void __launch_bounds__(256) nhwc_to_nchw_batched_kernel(const float* __restrict__ in, float* __restrict__ out, int c,
+                                                                   long hw, long total) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const long plane = i / hw, q = i - plane * hw;          // plane = b * c + ch
+  const long b = plane / c;
+  const int ch = (int)(plane - b * c);
+  out[i] = in[(b * hw + q) * c + ch];
+}
 
 // in: planar [B,C,H,W] -> out: [B*H*W, C]
 __global__ void __launch_bounds__(256) nchw_to_nhwc_kernel(const float* __restrict__ in, float* __restrict__ out, int c,
@@ -440,20 +452,21 @@ extern "C" int dvd_convnet_slot_shape(void* handle, int slot, int* h, int* w, in
   return DVD_OK;
 }
 
-extern "C" int dvd_conv3x3_nhwc_narrow(const float* in, int c, const float* wgt, int kp, const float* bias, float* out,
-                                       int cout, int h, int w, int relu, void* stream) {
-  DVD_REQUIRE(in && wgt && bias && out, "conv3x3_nhwc_narrow: null pointer");
-  DVD_REQUIRE(c > 0 && c % 16 == 0 && cout > 0 && cout <= 64 && kp >= 9 * c && kp % 4 == 0 && h > 0 && w > 0,
-              "conv3x3_nhwc_narrow: bad shape (c %d, cout %d, kp %d)", c, cout, kp);
-  DVD_REQUIRE(((uintptr_t)in % 16) == 0 && ((uintptr_t)wgt % 16) == 0, "conv3x3_nhwc_narrow: operands must be 16-byte aligned");
+extern "C" int dvd_conv3x3_nhwc(const float* in, int c, const float* wgt, int kp, const float* bias, float* out, int cout,
+                                int h, int w, int relu, void* stream) {
+  DVD_REQUIRE(in && wgt && bias && out, "conv3x3_nhwc: null pointer");
+  DVD_REQUIRE(c > 0 && c % 16 == 0 && cout > 0 && kp >= 9 * c && kp % 4 == 0 && h > 0 && w > 0,
+              "conv3x3_nhwc: bad shape (c %d, cout %d, kp %d)", c, cout, kp);
+  DVD_REQUIRE(((uintptr_t)in % 16) == 0 && ((uintptr_t)wgt % 16) == 0, "conv3x3_nhwc: operands must be 16-byte aligned");
   const long rows = (long)h * w;
+  if (cout > 64) return launch_gemm_conv_f32(in, c, nullptr, 0, h, w, 3, 1, rows, wgt, kp, bias, out, cout, relu ? 2 : 0, stream);
   const dim3 grd(cdiv(rows, 128));
   hipStream_t st = (hipStream_t)stream;
   if (cout <= 32)
     conv_f32_narrow_kernel<1><<<grd, 256, 0, st>>>(in, c, nullptr, 0, wgt, kp, bias, out, cout, 3, 1, h, w, relu ? 2 : 0, rows);
   else
     conv_f32_narrow_kernel<2><<<grd, 256, 0, st>>>(in, c, nullptr, 0, wgt, kp, bias, out, cout, 3, 1, h, w, relu ? 2 : 0, rows);
-  return check_launch("conv3x3_nhwc_narrow");
+  return check_launch("conv3x3_nhwc");
 }
 
 extern "C" int dvd_convnet_run(void* handle, const float* in_nchw, const float* weights, void* workspace,
@@ -496,6 +509,16 @@ extern "C" int dvd_convnet_run(void* handle, const float* in_nchw, const float* 
             conv_f32_narrow_kernel<2><<<grd, 256, 0, st>>>(P(o.a), a.c, o.b >= 0 ? P(o.b) : nullptr, cb, wgt, kp,
                                                            wgt + (long)o.cout * kp, P(o.dst), o.cout, o.ks, o.dil, a.h, a.w,
                                                            o.act, rows);
+          break;
+        }
+        if (a.c % 16 == 0 && cb % 16 == 0 && kp == o.ks * o.ks * (a.c + cb) && n->ksplit[i] == 1 && rows < (1l << 31) &&
+            !(o.ks == 1 && o.b < 0)) {
+          // wide output over 16-aligned channels (round 5): the 128 x 128 exact-f32 GEMM gathers its A tiles from the map(s)
+          // itself - the im2col matrix (up to 9216 columns per pixel) is never written or read
+          if (int e = launch_gemm_conv_f32(P(o.a), a.c, o.b >= 0 ? P(o.b) : nullptr, cb, a.h, a.w, o.ks, o.dil, rows,
+                                           weights + o.w_off, kp, weights + o.w_off + (long)o.cout * kp, P(o.dst), o.cout, o.act,
+                                           stream))
+            return e;
           break;
         }
         const float* A = P(o.a);
@@ -545,10 +568,8 @@ extern "C" int dvd_convnet_run(void* handle, const float* in_nchw, const float* 
   for (int k = 0; k < n_out; ++k) {
     const int s = out_slots[k];
     DVD_REQUIRE(s >= 0 && s < (int)n->slots.size() && n->slots[s].set && out_nchw[k], "convnet_run: bad output %d", k);
-    const long per = (long)n->slots[s].c * n->slots[s].h * n->slots[s].w;
-    for (long b = 0; b < B; ++b)
-      if (int e = dvd_nhwc_to_nchw(P(s) + b * per, out_nchw[k] + b * per, n->slots[s].c, n->slots[s].h, n->slots[s].w, stream))
-        return e;
+    const long hw = (long)n->slots[s].h * n->slots[s].w, total = B * hw * n->slots[s].c;
+    nhwc_to_nchw_batched_kernel<<<cdiv(total, 256), 256, 0, st>>>(P(s), out_nchw[k], n->slots[s].c, hw, total);
   }
   return check_launch("convnet_run");
 }

@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "common.h"
+#include "gemm_common.h"
 #include "mfma.h"
 
 extern "C" {
@@ -33,7 +34,7 @@ int dvd_small_linear(const float*, int, const float*, const float*, float*, int,
 int dvd_final_tokens(const float*, const float*, const float*, const float*, const float*, int, int, const float*,
                      const float*, const float*, float*, float*, int, int, void*);
 int dvd_im2col3x3(const float*, long, long, long, float*, int, int, int, int, void*);
-int dvd_conv3x3_nhwc_narrow(const float*, int, const float*, int, const float*, float*, int, int, int, int, void*);
+int dvd_conv3x3_nhwc(const float*, int, const float*, int, const float*, float*, int, int, int, int, void*);
 int dvd_maxpool2_nhwc(const float*, float*, int, int, int, void*);
 int dvd_resize_bilinear_nhwc(const float*, float*, int, int, int, int, int, void*);
 int dvd_nhwc_to_nchw(const float*, float*, int, int, int, void*);
@@ -535,10 +536,10 @@ extern "C" int dvd_engine_prepare_docs(void* handle, const float* y512, const fl
       const int cin = PYR_CIN[l.idx], cout = PYR_COUT[l.idx], kp = pyr_kpad(l.idx);
       float* outp = act[wi];
       wi ^= 1;
-      if (sc == 1 && cin % 16 == 0 && cout <= 64) {
-        // level_1's second conv (64 -> 64 on 512 x 512: the largest im2col matrix of the pyramid, 604 MB): implicit GEMM with
-        // the arithmetic - and the bits - of the im2col + narrow-GEMM pair it replaces
-        TRY(dvd_conv3x3_nhwc_narrow(cur, cin, e->F(e->wi.pyr_w[l.idx]), kp, e->F(e->wi.pyr_b[l.idx]), outp, cout, l.hw, l.hw,
+      if (sc == 1 && cin % 16 == 0 && kp == 9 * cin) {
+        // every layer but the first (4 planar input channels): implicit GEMM with the arithmetic - and the bits - of the
+        // im2col + GEMM pair it replaces (level_1's second conv alone wrote and read a 604 MB matrix)
+        TRY(dvd_conv3x3_nhwc(cur, cin, e->F(e->wi.pyr_w[l.idx]), kp, e->F(e->wi.pyr_b[l.idx]), outp, cout, l.hw, l.hw,
                                     1, stream));
       } else {
         TRY(dvd_im2col3x3(cur, sc, sy, sx, col, kp, cin, l.hw, l.hw, stream));

@@ -15,6 +15,7 @@
 // bias, GELU(tanh) / ReLU, positional-embedding add, adaLN gate, residual add, f16/f32 stores.
 #include "gemm_common.h"
 #include <stdlib.h>
+#include <string.h>
 #include <type_traits>
 
 #ifndef T384_WALK
@@ -235,8 +236,9 @@ __device__ __forceinline__ void epilogue_readback(const GemmArgs& p, float* stag
     else epilogue_block64<0>(__VA_ARGS__);                                                  \
   }
 
-template <bool F32, int PD>
+template <bool F32, int PD, bool CONV = false>   // CONV (f32 only): the A operand is an unbuilt im2col matrix (GemmArgs::cv_*)
 __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(GemmArgs p) {
+  static_assert(!CONV || F32, "implicit-GEMM operand: exact-f32 kernel only");
   using T = typename std::conditional<F32, float, _Float16>::type;
   constexpr int BK = F32 ? 16 : 64;                 // elements per K-step
   constexpr int ROWB = BK * (int)sizeof(T);          // payload bytes per LDS row (64 / 128)
@@ -286,6 +288,23 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(GemmArgs p) {
     gal[i] = Alo ? Alo + (size_t)ra * p.lda + ch * EPC : ga[i];
     lofs[i] = row * LROW + ch * 16;
   }
+  // CONV: the slot's pixel (clamped row ra of the im2col matrix = pixel ra of the batch of maps) and its 4-float chunk
+  long cpix[NLD];
+  int cy[NLD], cx[NLD], cch[NLD];
+  bool cok[PD][NLD];
+  if constexpr (CONV) {
+    const long hw = (long)p.cv_h * p.cv_w;
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int c = tid + 256 * i;
+      const int row = c / CH;
+      cch[i] = (c % CH) * EPC;
+      cpix[i] = min(bm0 + row, p.M - 1);
+      const long pl = cpix[i] % hw;
+      cy[i] = (int)(pl / p.cv_w);
+      cx[i] = (int)(pl - (long)cy[i] * p.cv_w);
+    }
+  }
   // Split weights: the low parts are accumulated FIRST, the accumulator is scaled by lo_scale (a power of
   // two: exact), then the high parts are added -> one accumulator, fp32-grade weights at 2x the MFMAs.
   const int nkk = p.K / BK;
@@ -304,14 +323,40 @@ __global__ void __launch_bounds__(256, 2) gemm_nt_kernel(GemmArgs p) {
     const int tt_ = (t_);                                                        \
     const bool lo_ = tt_ < nlo;                                                  \
     const size_t kofs_ = (size_t)(lo_ ? tt_ : tt_ - nlo) * BK;                   \
-    _Pragma("unroll") for (int i = 0; i < NLD; ++i) {                            \
-      ra[s_][i] = *(const u32x4*)((lo_ ? gal[i] : ga[i]) + kofs_);               \
-      rb[s_][i] = *(const u32x4*)((lo_ ? gbl[i] : gb[i]) + kofs_);               \
+    if constexpr (CONV) {                                                        \
+      /* K-tile tt_ = 16 channels of ONE tap of ONE source (ca, cb multiples of 16): wave-uniform tap arithmetic, then a  */ \
+      /* border test per slot.  Taps outside the map load the slot's own pixel (every load is issued: counted waits) and  */ \
+      /* are zeroed when the tile goes to LDS.                                                                            */ \
+      const int cc_ = p.cv_ca + p.cv_cb, cpt_ = cc_ >> 4;                        \
+      const int tap_ = tt_ / cpt_, c0_ = (tt_ - tap_ * cpt_) << 4;               \
+      const int rad_ = p.cv_ks >> 1;                                             \
+      const int dy_ = (tap_ / p.cv_ks - rad_) * p.cv_dil, dx_ = (tap_ % p.cv_ks - rad_) * p.cv_dil; \
+      const bool fst_ = c0_ < p.cv_ca;                                           \
+      const float* sb_ = fst_ ? (const float*)p.A : p.cv_b;                      \
+      const int sc_ = fst_ ? p.cv_ca : p.cv_cb, so_ = fst_ ? c0_ : c0_ - p.cv_ca; \
+      _Pragma("unroll") for (int i = 0; i < NLD; ++i) {                          \
+        const int yy_ = cy[i] + dy_, xx_ = cx[i] + dx_;                          \
+        const bool ok_ = yy_ >= 0 && yy_ < p.cv_h && xx_ >= 0 && xx_ < p.cv_w;    \
+        const long q_ = ok_ ? cpix[i] + (long)dy_ * p.cv_w + dx_ : cpix[i];       \
+        ra[s_][i] = *(const u32x4*)(sb_ + q_ * sc_ + so_ + cch[i]);              \
+        cok[s_][i] = ok_;                                                        \
+        rb[s_][i] = *(const u32x4*)(gb[i] + kofs_);                              \
+      }                                                                          \
+    } else {                                                                     \
+      _Pragma("unroll") for (int i = 0; i < NLD; ++i) {                          \
+        ra[s_][i] = *(const u32x4*)((lo_ ? gal[i] : ga[i]) + kofs_);             \
+        rb[s_][i] = *(const u32x4*)((lo_ ? gbl[i] : gb[i]) + kofs_);             \
+      }                                                                          \
     }                                                                            \
   }
 #define DVD_LSTORE(s_, buf_)                                                     \
   _Pragma("unroll") for (int i = 0; i < NLD; ++i) {                              \
-    *(u32x4*)(&smem[buf_][0][lofs[i]]) = ra[s_][i];                              \
+    if constexpr (CONV) {                                                        \
+      const u32x4 z_ = {0u, 0u, 0u, 0u};                                         \
+      *(u32x4*)(&smem[buf_][0][lofs[i]]) = cok[s_][i] ? ra[s_][i] : z_;          \
+    } else {                                                                     \
+      *(u32x4*)(&smem[buf_][0][lofs[i]]) = ra[s_][i];                            \
+    }                                                                            \
     *(u32x4*)(&smem[buf_][1][lofs[i]]) = rb[s_][i];                              \
   }
 #define DVD_COMPUTE(buf_)                                                                          \
@@ -1719,6 +1764,7 @@ extern "C" int dvd_gemm_nt(const dvd_gemm_desc* d, void* stream) {
   p.ldgate = d->ldgate; p.ldpos = d->ldpos;
   p.gate_rows = d->gate_rows; p.pos_rows = d->pos_rows;
   p.act = d->act; p.bias_row = d->bias_row;
+  p.cv_b = nullptr; p.cv_ca = p.cv_cb = p.cv_h = p.cv_w = p.cv_ks = p.cv_dil = 0;
 
   // The product library has no switches: the kernel is a function of the descriptor alone.  The lab build
   // (-DDVD_LAB, benchmarks/lab/libdvd_hip_lab.so) keeps the A/B switches of the experiments that were measured.
@@ -1911,4 +1957,24 @@ extern "C" int dvd_gemm_nt(const dvd_gemm_desc* d, void* stream) {
   else
     gemm_nt_kernel<false, 2><<<grid, 256, 0, (hipStream_t)stream>>>(p);
   return check_launch("gemm_nt");
+}
+
+int dvd::launch_gemm_conv_f32(const float* a, int ca, const float* b, int cb, int h, int w, int ks, int dil, long rows,
+                              const float* wgt, int kp, const float* bias, float* out, int cout, int act, void* stream) {
+  DVD_REQUIRE(a && wgt && bias && out && (b || cb == 0), "gemm_conv_f32: null pointer");
+  DVD_REQUIRE(ca > 0 && ca % 16 == 0 && cb >= 0 && cb % 16 == 0 && (ks & 1) == 1 && dil > 0 && kp == ks * ks * (ca + cb),
+              "gemm_conv_f32: bad shape (ca %d, cb %d, ks %d, kp %d)", ca, cb, ks, kp);
+  DVD_REQUIRE(h > 0 && w > 0 && rows > 0 && rows % ((long)h * w) == 0 && rows < (1l << 31) && cout > 0,
+              "gemm_conv_f32: bad map (%d x %d, %ld rows)", h, w, rows);
+  DVD_REQUIRE(((uintptr_t)a % 16) == 0 && ((uintptr_t)b % 16) == 0 && ((uintptr_t)wgt % 16) == 0,
+              "gemm_conv_f32: operands must be 16-byte aligned");
+  GemmArgs p;
+  memset(&p, 0, sizeof(p));
+  p.A = a; p.cv_b = b; p.cv_ca = ca; p.cv_cb = cb; p.cv_h = h; p.cv_w = w; p.cv_ks = ks; p.cv_dil = dil;
+  p.B = wgt; p.ldb = kp; p.C32 = out; p.ldc = cout; p.bias = bias; p.act = act; p.lo_scale = 1.f;
+  p.M = (int)rows; p.N = cout; p.K = kp;
+  p.vec_epilogue = (cout % 8 == 0 && ((uintptr_t)out % 16) == 0 && ((uintptr_t)bias % 16) == 0) ? 1 : 0;
+  p.ntm = cdiv(p.M, 128); p.ntn = cdiv(p.N, 128);
+  gemm_nt_kernel<true, 2, true><<<dim3(p.ntm * p.ntn, 1), 256, 0, (hipStream_t)stream>>>(p);
+  return check_launch("gemm_conv_f32");
 }

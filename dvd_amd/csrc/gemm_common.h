@@ -31,7 +31,18 @@ struct GemmArgs {
   int debug;     // timing ablations only (DVD_GEMM_DEBUG): 1 = no operand loads in the K loop, 2 = no MFMAs,
                  // 3 = per-wave s_memtime stamps (start, first tile landed, K loop done, epilogue done) -> stamps
   unsigned long long* stamps;
+  // gemm_nt_kernel<f32, CONV>: A is not a matrix but a channels-last map [M = images * cv_h * cv_w pixels, cv_ca] (plus an
+  // optional second source cv_b [M, cv_cb], the channel concatenation) and column k of row m is tap k / (cv_ca + cv_cb) of
+  // the cv_ks x cv_ks window (dilation cv_dil, zero outside the map), channel k % (cv_ca + cv_cb): the im2col matrix, unbuilt
+  const float* cv_b;
+  int cv_ca, cv_cb, cv_h, cv_w, cv_ks, cv_dil;
 };
+
+// conv (cv_ks x cv_ks, stride 1, 'same' padding) + bias (+ReLU: act 2) of a channels-last f32 map as an implicit GEMM on the
+// exact-f32 128 x 128 kernel: the arithmetic - and the bits - of im2col + dvd_gemm_nt(f32).  ca, cb multiples of 16,
+// kp == ks * ks * (ca + cb).  Returns DVD_OK or an error code (error.hip).
+int launch_gemm_conv_f32(const float* a, int ca, const float* b, int cb, int h, int w, int ks, int dil, long rows,
+                         const float* wgt, int kp, const float* bias, float* out, int cout, int act, void* stream);
 
 // Tile walk of the persistent kernels.  Virtual id `vid` runs on XCD vid % 8 (hardware round-robin) as that XCD's k-th
 // tile, k = vid / 8; an XCD owns a contiguous range of row panels.  At any time an XCD's 32 CUs work on 32 consecutive k.

@@ -107,7 +107,7 @@ SIGNATURES = {
     "dvd_final_tokens": [c_void, c_void, c_void, c_void, c_void, C.c_int, C.c_int, c_void, c_void, c_void, c_void,
                          c_void, C.c_int, C.c_int, c_void],
     "dvd_im2col3x3": [c_void, C.c_long, C.c_long, C.c_long, c_void, C.c_int, C.c_int, C.c_int, C.c_int, c_void],
-    "dvd_conv3x3_nhwc_narrow": [c_void, C.c_int, c_void, C.c_int, c_void, c_void, C.c_int, C.c_int, C.c_int, C.c_int, c_void],
+    "dvd_conv3x3_nhwc": [c_void, C.c_int, c_void, C.c_int, c_void, c_void, C.c_int, C.c_int, C.c_int, C.c_int, c_void],
     "dvd_maxpool2_nhwc": [c_void, c_void, C.c_int, C.c_int, C.c_int, c_void],
     "dvd_resize_bilinear_nhwc": [c_void, c_void, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_void],
     "dvd_nhwc_to_nchw": [c_void, c_void, C.c_int, C.c_int, C.c_int, c_void],

@@ -268,9 +268,9 @@ def conv3x3_relu_nhwc(x_nhwc, w_packed, bias, cin, cout, h, w):
 
 
 def conv3x3_relu_nhwc_implicit(x_nhwc, w_packed, bias, cin, cout, h, w):
-    """The same layer without the im2col matrix (cout <= 64, cin % 16 == 0): what the engine runs for level_1's second conv."""
+    """The same layer without the im2col matrix (cin % 16 == 0): what the engine runs for every pyramid layer but the first."""
     out = torch.empty(h * w, cout, dtype=torch.float32, device=x_nhwc.device)
-    lib.call("dvd_conv3x3_nhwc_narrow", ptr(x_nhwc), cin, ptr(w_packed), w_packed.shape[1], ptr(bias), ptr(out), cout, h, w, 1,
+    lib.call("dvd_conv3x3_nhwc", ptr(x_nhwc), cin, ptr(w_packed), w_packed.shape[1], ptr(bias), ptr(out), cout, h, w, 1,
              stream_ptr())
     return out
 

@@ -221,11 +221,13 @@ int dvd_final_tokens(const float* z, const float* gamma, const float* beta, cons
 
 /* Conv pyramid pieces (idf/cross_model.py:18-95), channels-last f32. */
 int dvd_im2col3x3(const float* in, long sc, long sy, long sx, float* out, int ldo, int c, int h, int w, void* stream);
-/* 3x3 / pad 1 / stride 1 convolution + bias (+ReLU when relu != 0) of a channels-last map in [h, w, c] with at most 64 output
- * channels, c % 16 == 0, as an implicit GEMM: the arithmetic of dvd_im2col3x3 + dvd_gemm_nt (f32) on weights wgt [cout, kp]
- * (kp >= 9 c, K order tap-major) - same chunks, same MFMA sequence, same bits - without the [h w, kp] matrix. */
-int dvd_conv3x3_nhwc_narrow(const float* in, int c, const float* wgt, int kp, const float* bias, float* out, int cout, int h,
-                            int w, int relu, void* stream);
+/* 3x3 / pad 1 / stride 1 convolution + bias (+ReLU when relu != 0) of a channels-last map in [h, w, c], c % 16 == 0, as an
+ * implicit GEMM: the arithmetic of dvd_im2col3x3 + dvd_gemm_nt (f32) on weights wgt [cout, kp] (K order tap-major; kp >= 9 c
+ * for cout <= 64, kp == 9 c above) - same K-tiles, same MFMA sequence, same bits - without the [h w, kp] matrix.  At most 64
+ * output channels: operands straight to registers (conv_f32_narrow_kernel); more: the exact-f32 128 x 128 GEMM gathering its
+ * A tiles from the map (gemm_nt_kernel<f32, CONV>). */
+int dvd_conv3x3_nhwc(const float* in, int c, const float* wgt, int kp, const float* bias, float* out, int cout, int h, int w,
+                     int relu, void* stream);
 int dvd_maxpool2_nhwc(const float* in, float* out, int c, int h, int w, void* stream);
 int dvd_resize_bilinear_nhwc(const float* in, float* out, int c, int hin, int win, int hout, int wout, void* stream);
 int dvd_nhwc_to_nchw(const float* in, float* out, int c, int h, int w, void* stream);
