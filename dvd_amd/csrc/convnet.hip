@@ -213,6 +213,23 @@ __global__ void __launch_bounds__(256) conv_f32_narrow_kernel(const float* __res
   }
 }
 
+// LAB (DVD_CONV_LDS=bytes): dynamic LDS per workgroup of the narrow conv kernels - unused by them, an occupancy cap for
+// the L1-footprint experiment of round 5 (profiles/r5_conv_narrow_occupancy.txt).  0 in the product library.
+static inline unsigned narrow_lds() {
+#ifdef DVD_LAB
+  if (const char* e = getenv("DVD_CONV_LDS")) {
+    static bool once = false;
+    if (!once) {
+      (void)hipFuncSetAttribute((const void*)conv_f32_narrow_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute((const void*)conv_f32_narrow_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      once = true;
+    }
+    return (unsigned)atoi(e);
+  }
+#endif
+  return 0;
+}
+
 // nn.MaxPool2d(2, stride=2, ceil_mode): windows are clipped at the border
 __global__ void __launch_bounds__(256) maxpool2_ceil_kernel(const float* __restrict__ in, float* __restrict__ out, int c,
                                                             int h, int w, int ho, int wo, long total) {
@@ -463,9 +480,9 @@ extern "C" int dvd_conv3x3_nhwc(const float* in, int c, const float* wgt, int kp
   const dim3 grd(cdiv(rows, 128));
   hipStream_t st = (hipStream_t)stream;
   if (cout <= 32)
-    conv_f32_narrow_kernel<1><<<grd, 256, 0, st>>>(in, c, nullptr, 0, wgt, kp, bias, out, cout, 3, 1, h, w, relu ? 2 : 0, rows);
+    conv_f32_narrow_kernel<1><<<grd, 256, narrow_lds(), st>>>(in, c, nullptr, 0, wgt, kp, bias, out, cout, 3, 1, h, w, relu ? 2 : 0, rows);
   else
-    conv_f32_narrow_kernel<2><<<grd, 256, 0, st>>>(in, c, nullptr, 0, wgt, kp, bias, out, cout, 3, 1, h, w, relu ? 2 : 0, rows);
+    conv_f32_narrow_kernel<2><<<grd, 256, narrow_lds(), st>>>(in, c, nullptr, 0, wgt, kp, bias, out, cout, 3, 1, h, w, relu ? 2 : 0, rows);
   return check_launch("conv3x3_nhwc");
 }
 
@@ -502,11 +519,11 @@ extern "C" int dvd_convnet_run(void* handle, const float* in_nchw, const float* 
           const dim3 grd(cdiv(rows, 128));
           const float* wgt = weights + o.w_off;
           if (o.cout <= 32)
-            conv_f32_narrow_kernel<1><<<grd, 256, 0, st>>>(P(o.a), a.c, o.b >= 0 ? P(o.b) : nullptr, cb, wgt, kp,
+            conv_f32_narrow_kernel<1><<<grd, 256, narrow_lds(), st>>>(P(o.a), a.c, o.b >= 0 ? P(o.b) : nullptr, cb, wgt, kp,
                                                            wgt + (long)o.cout * kp, P(o.dst), o.cout, o.ks, o.dil, a.h, a.w,
                                                            o.act, rows);
           else
-            conv_f32_narrow_kernel<2><<<grd, 256, 0, st>>>(P(o.a), a.c, o.b >= 0 ? P(o.b) : nullptr, cb, wgt, kp,
+            conv_f32_narrow_kernel<2><<<grd, 256, narrow_lds(), st>>>(P(o.a), a.c, o.b >= 0 ? P(o.b) : nullptr, cb, wgt, kp,
                                                            wgt + (long)o.cout * kp, P(o.dst), o.cout, o.ks, o.dil, a.h, a.w,
                                                            o.act, rows);
           break;
