@@ -569,12 +569,16 @@ extern "C" int dvd_engine_prepare_docs(void* handle, const float* y512, const fl
   }
   // c / m / l patch embeddings (+pos) and their K / V^T projections (shared cross_attn weights), for GROUPS of documents
   // (round 5): per document these are 1024-row GEMMs at the reference's grid - 24 workgroups on 256 CUs, nine of them per
-  // document, 20 of a 32-document batch's 254 ms.  A group's patch rows and tokens live in the im2col region, which is free
-  // once the pyramid loop is done; the group is as large as that region allows (all 32 documents at G = 64, 3 at G = 288).
+  // document, 20 of a 32-document batch's 254 ms.  A group's patch rows and tokens live in the prepare-time scratch, which is
+  // free once the pyramid loop is done; the group is as large as it allows (all 32 documents at G = 64, 5 at G = 288).
   // Row-stacked GEMMs and a batch dimension for the transposed V projection: per-row arithmetic unchanged, same bits.
   {
+    // the prepare-time scratch from the im2col region to its end (p_col, p_actA, p_actB, p_rows, p_tok32 are laid out in
+    // this order by plan() and none of them is live here); p_rows + p_tok32 alone hold one document at any grid
     const size_t per_doc = (size_t)T * (1536 + HID) * 4;
-    const int gmax = (int)std::max<size_t>(1, std::min<size_t>((size_t)e->docs, e->bufs[e->bi.p_col].bytes / per_doc));
+    const size_t avail = e->bufs[e->bi.p_tok32].off + e->bufs[e->bi.p_tok32].bytes - e->bufs[e->bi.p_col].off;
+    DVD_REQUIRE(avail >= per_doc, "engine_prepare_docs: prepare scratch smaller than one document's rows");
+    const int gmax = (int)std::max<size_t>(1, std::min<size_t>((size_t)e->docs, avail / per_doc));
     const WIdx& wx = e->wi;
     const BIdx& bx = e->bi;
     for (int d0 = 0; d0 < e->docs; d0 += gmax) {
