@@ -94,6 +94,9 @@ __global__ void __launch_bounds__(256) im2col_cat_kernel(const float* __restrict
 }
 
 
+// below this many rows a 33..64-channel narrow convolution runs as two 32-column halves (convnet_run, dvd_conv3x3_nhwc)
+constexpr long NARROW_SPLIT_ROWS = 16384;
+
 typedef float cn_floatx4 __attribute__((ext_vector_type(4)));
 typedef float cn_floatx16 __attribute__((ext_vector_type(16)));
 
@@ -120,13 +123,14 @@ __global__ void __launch_bounds__(256) conv_f32_narrow_kernel(const float* __res
   const int y = (int)(pl / w), x = (int)(pl - (long)y * w);
   const int cc = ca + cb, rad = ks / 2;
   const float* wp[NT];
+  const int col0 = 32 * NT * blockIdx.y;     // blockIdx.y: which group of NT 32-column tiles (small maps split the columns)
 #pragma unroll
-  for (int t = 0; t < NT; ++t) wp[t] = wgt + (size_t)min(32 * t + r, cout - 1) * kp + 4 * hh;
+  for (int t = 0; t < NT; ++t) wp[t] = wgt + (size_t)min(col0 + 32 * t + r, cout - 1) * kp + 4 * hh;
   cn_floatx16 acc[NT];
   float bcol[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
-    bcol[t] = bias[min(32 * t + r, cout - 1)];
+    bcol[t] = bias[min(col0 + 32 * t + r, cout - 1)];
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
   }
@@ -195,7 +199,7 @@ __global__ void __launch_bounds__(256) conv_f32_narrow_kernel(const float* __res
   // bias add inside the row test the compiler waited for ALL memory operations, i.e. the previous store, before each store
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
-    const int col = 32 * t + r;
+    const int col = col0 + 32 * t + r;
     float v[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
@@ -479,8 +483,9 @@ extern "C" int dvd_conv3x3_nhwc(const float* in, int c, const float* wgt, int kp
   if (cout > 64) return launch_gemm_conv_f32(in, c, nullptr, 0, h, w, 3, 1, rows, wgt, kp, bias, out, cout, relu ? 2 : 0, stream);
   const dim3 grd(cdiv(rows, 128));
   hipStream_t st = (hipStream_t)stream;
-  if (cout <= 32)
-    conv_f32_narrow_kernel<1><<<grd, 256, narrow_lds(), st>>>(in, c, nullptr, 0, wgt, kp, bias, out, cout, 3, 1, h, w, relu ? 2 : 0, rows);
+  if (cout <= 32 || rows < NARROW_SPLIT_ROWS)
+    conv_f32_narrow_kernel<1><<<dim3(grd.x, cout <= 32 ? 1 : 2), 256, narrow_lds(), st>>>(in, c, nullptr, 0, wgt, kp, bias, out, cout, 3, 1, h, w,
+                                                                                          relu ? 2 : 0, rows);
   else
     conv_f32_narrow_kernel<2><<<grd, 256, narrow_lds(), st>>>(in, c, nullptr, 0, wgt, kp, bias, out, cout, 3, 1, h, w, relu ? 2 : 0, rows);
   return check_launch("conv3x3_nhwc");
@@ -518,8 +523,10 @@ extern "C" int dvd_convnet_run(void* handle, const float* in_nchw, const float* 
           // narrow output over 16-aligned channels: implicit GEMM, no im2col matrix
           const dim3 grd(cdiv(rows, 128));
           const float* wgt = weights + o.w_off;
-          if (o.cout <= 32)
-            conv_f32_narrow_kernel<1><<<grd, 256, narrow_lds(), st>>>(P(o.a), a.c, o.b >= 0 ? P(o.b) : nullptr, cb, wgt, kp,
+          if (o.cout <= 32 || rows < NARROW_SPLIT_ROWS)
+            // one 32-column tile per wave; a 33..64-channel layer on a small map gets its two tiles from two workgroups
+            // (twice the waves on a chip that is mostly idle there; per output the same chain of MFMAs: same bits)
+            conv_f32_narrow_kernel<1><<<dim3(grd.x, o.cout <= 32 ? 1 : 2), 256, narrow_lds(), st>>>(P(o.a), a.c, o.b >= 0 ? P(o.b) : nullptr, cb, wgt, kp,
                                                            wgt + (long)o.cout * kp, P(o.dst), o.cout, o.ks, o.dil, a.h, a.w,
                                                            o.act, rows);
           else

@@ -152,11 +152,12 @@ def test_build_r_rows(ops, mode):
 
 
 @pytest.mark.parametrize("cin,cout,h,w", [(64, 64, 40, 24), (16, 32, 9, 13), (32, 48, 17, 5), (64, 128, 37, 29), (128, 256, 16, 16),
-                                          (16, 72, 7, 11)])
+                                          (16, 72, 7, 11), (64, 64, 130, 127), (128, 40, 36, 36)])
 def test_implicit_conv_has_the_bits_of_im2col_plus_gemm(ops, cin, cout, h, w):
     """dvd_conv3x3_nhwc (the pyramid's layers since round 5: narrow kernel up to 64 output channels, the 128 x 128 GEMM with an
     implicit A operand above) against the im2col + exact-f32 GEMM pair it replaces: same K order, same K-tiles, same MFMA
-    sequence - equal bits, on maps whose row count is not a multiple of a wave's 32 rows or of a tile's 128, cout ragged."""
+    sequence - equal bits, on maps whose row count is not a multiple of a wave's 32 rows or of a tile's 128, cout ragged, and on
+    both sides of the row count below which a 33..64-channel layer is computed as two 32-column halves."""
     x = rnd(f"pyi/x{cin}", (h * w, cin)).cuda()
     wt, b = rnd(f"pyi/w{cin}", (cout, cin, 3, 3), -0.3, 0.3), rnd(f"pyi/b{cin}", (cout,), -0.1, 0.1).cuda()
     wp = wt.permute(0, 2, 3, 1).reshape(cout, -1).contiguous().cuda()
