@@ -488,6 +488,19 @@ def reload_model(model, path=""):
 # ---------------------------------------------------------------------------------------------------------
 # the glue of evaluation.py:162-216
 # ---------------------------------------------------------------------------------------------------------
+_SIDE_STREAMS = {}
+
+
+def _side_stream(device):
+    """One side HIP stream per device, created once: creating a stream costs several hundred microseconds of host time - it was
+    the largest single gap in the GPU timeline of a document at the reference's operating point (profiles/r5_native_single_trace.txt)."""
+    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    st = _SIDE_STREAMS.get(key)
+    if st is None:
+        st = _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
+    return st
+
+
 def conditioning(dewarp_model, seg_model, line_model, source512: torch.Tensor, grid: int):
     """source512 [N,3,512,512] in 0..1 on the device -> dict(mask_cat [N,1,512,512], mask_y512 [N,384,G,G],
     line_msk [N,64,G,G]) exactly as evaluation.py:162-216 builds them (use_gt_mask False, use_line_mask True)."""
@@ -495,7 +508,7 @@ def conditioning(dewarp_model, seg_model, line_model, source512: torch.Tensor, g
     # The document-mask pass (GeoTr_Seg_Inf.msk) and the Seg pass are independent U2NETP evaluations of the same input,
     # each a chain of several hundred small, latency-bound kernels that fill a few of the 256 CUs: the first runs on a
     # side HIP stream beside the Seg -> line-UNet chain and is joined at the end.
-    side = torch.cuda.Stream(device=source_288.device) if source_288.is_cuda else None
+    side = _side_stream(source_288.device) if source_288.is_cuda else None
     if side is not None:
         cur = torch.cuda.current_stream(source_288.device)
         side.wait_stream(cur)
