@@ -507,21 +507,26 @@ def conditioning(dewarp_model, seg_model, line_model, source512: torch.Tensor, g
     source_288 = resize_bilinear(source512.to(torch.float32).contiguous(), 288, True)                    # :162
     # The document-mask pass (GeoTr_Seg_Inf.msk) and the Seg pass are independent U2NETP evaluations of the same input,
     # each a chain of several hundred small, latency-bound kernels that fill a few of the 256 CUs: the first runs on a
-    # side HIP stream beside the Seg -> line-UNet chain and is joined at the end.
+    # side HIP stream beside the Seg -> line-UNet chain and is joined at the end.  The LONGER chain (Seg, then the line
+    # UNet) is enqueued first: the host needs ~0.6 ms to enqueue a net's launches, and whichever chain is enqueued second
+    # starts that much later - the short one can afford it (round 5; it waits for the resized image only, through an event).
     side = _side_stream(source_288.device) if source_288.is_cuda else None
     if side is not None:
         cur = torch.cuda.current_stream(source_288.device)
-        side.wait_stream(cur)
-        with torch.cuda.stream(side):
-            _, mask_x = dewarp_model(source_288)                                                         # :176
-    else:
-        _, mask_x = dewarp_model(source_288)
+        ready = torch.cuda.Event()
+        ready.record(cur)
     mskx, d0, hx6, hx5d, hx4d, hx3d, hx2d, hx1d = seg_model(source_288)                                   # :198
     seg_map_all = torch.cat([resize_bilinear(t, grid, False) for t in (hx6, hx5d, hx4d, hx3d, hx2d, hx1d)], dim=1)
     textline_map, _ = line_model(mskx)                                                                   # :209
+    line_msk = resize_bilinear(textline_map, grid, False)
     if side is not None:
+        with torch.cuda.stream(side):
+            side.wait_event(ready)
+            _, mask_x = dewarp_model(source_288)                                                         # :176
         cur.wait_stream(side)
         mask_x.record_stream(cur)
         source_288.record_stream(side)
-    return {"mask_cat": mask_x, "mask_y512": seg_map_all, "line_msk": resize_bilinear(textline_map, grid, False),
+    else:
+        _, mask_x = dewarp_model(source_288)
+    return {"mask_cat": mask_x, "mask_y512": seg_map_all, "line_msk": line_msk,
             "mskx": mskx, "d0": d0}
