@@ -21,6 +21,8 @@
 #ifndef T384_WALK
 #define T384_WALK 0         // tile walk of gemm_nt_t384_kernel for six N tiles: 0 row-major, 1 two groups of three (tile_coords)
 #endif
+// gemm_nt_ring128_kernel takes the f16 128 x 128-tile problems with at most this many tiles (profiles/r5_gemm_ring128.txt)
+#define RING128_MAX_TILES 256
 #ifndef T384_STAGGER
 #define T384_STAGGER 0      // start-up delay quantum of gemm_nt_t384_kernel (x 1024 cycles x 0..15 per workgroup); see the kernel
 #endif
@@ -768,6 +770,178 @@ __device__ __forceinline__ void glds_group4(const char* gbase, const unsigned (&
       : "=&s"(keep)
       : "s"(gbase), "s"(lds), "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "v"(voff[3])
       : "memory", "scc");
+}
+
+// ================================================================================================
+// gemm_nt_ring128_kernel (round 5): the 128 x 128 tile of gemm_nt_kernel<f16> for problems with FEW tiles - the sampler at the
+// reference's operating point: 2048 rows, 192-384 workgroups, one per CU, one wave per SIMD.  There the register-staged
+// kernel runs the parts of a K-tile one after the other (PMC: matrix pipe 29 %, parked 28 %, LDS issue 28 %, VALU 12 % of a
+// wave's cycles; profiles/r5_gemm_small_pmc.txt) and nothing overlaps them.  Here, with the means of the large kernels:
+//   * operand tiles go global -> LDS by LDS-DMA (no staging registers, no ds_write, no address VALU per tile): 64-deep slabs
+//     of 2 x 16 KiB, 128-byte rows, chunk ^= (row >> 1) & 7 on the source side and in the fragment reads (gemm_nt_big_kernel);
+//   * a ring of FIVE slabs = all 160 KiB: slab kt + 4 is requested at the top of slab kt and has to have landed by the end
+//     of slab kt + 2 (three slabs of matrix time for an L2 round trip), the wait is counted (vmcnt(16)), never 0;
+//   * the barrier at the end of slab kt publishes slab kt + 2, so slab kt + 1 is complete while slab kt is multiplied:
+//     the last k-step of a slab reads the first fragments of the next one between its MFMAs - no wave starts a slab cold;
+//   * one barrier per slab (16 MFMAs per wave).
+// Same operands per output in the same order (low parts, scale, high parts; k ascending in 16-deep steps) and the same
+// epilogues: the bits of gemm_nt_kernel<f16>, tested as such.  K % 64 == 0, 16-byte aligned operands and rows.
+// Measured (profiles/r5_gemm_ring128.txt): 13-15 % faster than the register-staged kernel up to 256 tiles (one workgroup per
+// CU: 34 vs 39 us at 2048 x 1536 x 1536 with a weight pair), equal from 384 tiles on, where that kernel has two workgroups
+// per CU and this one (160 KiB of LDS) one - hence RING128_MAX_TILES.  Fragment reads one or two k-steps ahead, __syncthreads
+// or a bare s_barrier: no difference - a slab still takes ~1500 cycles for 512 of matrix work.  Each XCD streams the whole
+// weight pair (9.4 MB, twice its L2) through the fabric once per launch; the per-CU rate, 32 KiB per 0.7 us, is what ~96 KiB in
+// flight buy at a ~2 us round trip.
+// ================================================================================================
+__global__ void __launch_bounds__(256, 1) gemm_nt_ring128_kernel(GemmArgs p) {
+  constexpr int BK = 64, TILE = 128 * 128, SLAB = 2 * TILE, NS = 5;     // bytes: one operand tile, one slab (A | B), ring slots
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  const int nwg = p.ntm * p.ntn;
+  int id = blockIdx.x;
+  {
+    const int q = nwg / 8, rr = nwg % 8, xcd = id % 8, k = id / 8;       // XCD-aware tile order, as gemm_nt_kernel
+    id = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + k;
+  }
+  const int tm = id / p.ntn, tn = id % p.ntn;
+  const int bm0 = tm * 128, bn0 = tn * 128;
+  const int z = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const int wr = wave >> 1, wc = wave & 1;
+  const _Float16* A = (const _Float16*)p.A + z * p.sA;
+  const _Float16* B = (const _Float16*)p.B + z * p.sB;
+  const _Float16* Alo = p.Alo ? (const _Float16*)p.Alo + z * p.sA : nullptr;
+  const _Float16* Blo = p.Blo ? (const _Float16*)p.Blo + z * p.sB : nullptr;
+
+  // per-lane source offsets (bytes, relative to the tile's first row at k = 0) of this wave's 4 + 4 one-KiB pieces (8 rows each)
+  unsigned aoff[4], boff[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = 8 * (4 * wave + i) + (lane >> 3), pos = lane & 7;
+    const int logical = pos ^ ((row >> 1) & 7);
+    const int ra = min(bm0 + row, p.M - 1) - bm0, rb = min(bn0 + row, p.N - 1) - bn0;
+    aoff[i] = (unsigned)(ra * (p.lda * 2) + logical * 16);
+    boff[i] = (unsigned)(rb * (p.ldb * 2) + logical * 16);
+  }
+  const char* Atile = (const char*)(A + (size_t)bm0 * p.lda);
+  const char* Btile = (const char*)(B + (size_t)bn0 * p.ldb);
+  const char* Alotile = Alo ? (const char*)(Alo + (size_t)bm0 * p.lda) : Atile;
+  const char* Blotile = Blo ? (const char*)(Blo + (size_t)bn0 * p.ldb) : Btile;
+  const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t)smem;
+
+  int frag[4];
+#pragma unroll
+  for (int s4 = 0; s4 < 4; ++s4) frag[s4] = r * 128 + (((2 * s4 + h) ^ ((r >> 1) & 7)) * 16);
+  const int a_base = wr * 64 * 128;
+  const int b_base = TILE + wc * 64 * 128;
+
+  floatx16 acc[2][2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[m][n][i] = 0.f;
+  const int nkk = p.K / BK;
+  const int nlo = (Blo || Alo) ? nkk : 0;
+  const int nk = nkk + nlo;
+  const int last = nk - 1;
+
+#define RING_ISSUE(t_, slot_)                                                                      \
+  {                                                                                                \
+    const int tt_ = min((t_), last);                                                               \
+    const bool lo_ = tt_ < nlo;                                                                    \
+    const size_t kb_ = (size_t)(lo_ ? tt_ : tt_ - nlo) * (BK * 2);                                 \
+    glds_group4<4>((lo_ ? Alotile : Atile) + kb_, aoff, lds0 + (slot_) * SLAB + (4 * wave) * 1024);        \
+    glds_group4<4>((lo_ ? Blotile : Btile) + kb_, boff, lds0 + (slot_) * SLAB + TILE + (4 * wave) * 1024); \
+  }
+#define SB() __builtin_amdgcn_sched_barrier(0)
+  RING_ISSUE(0, 0)
+  RING_ISSUE(1, 1)
+  RING_ISSUE(2, 2)
+  RING_ISSUE(3, 3)
+  asm volatile("s_waitcnt vmcnt(16)" ::: "memory");   // slabs 0 and 1 (this wave's pieces); 2 and 3 stay in flight
+  __syncthreads();
+  // k-step s4 of every slab multiplies from register set s4; the reads issued between its MFMAs are those of the step TWO
+  // ahead (set (s4 + 2) & 3: this slab's, or the next slab's first two) - 8 MFMAs = 256 cycles between a read and its use,
+  // with one wave per SIMD nothing else covers an LDS round trip
+  half8 fa[4][2], fb[4][2];
+#pragma unroll
+  for (int s4 = 0; s4 < 2; ++s4) {
+#pragma unroll
+    for (int m = 0; m < 2; ++m) fa[s4][m] = *(const half8*)(smem + a_base + m * 32 * 128 + frag[s4]);
+#pragma unroll
+    for (int n = 0; n < 2; ++n) fb[s4][n] = *(const half8*)(smem + b_base + n * 32 * 128 + frag[s4]);
+  }
+  SB();
+  int cur = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    int nxt = cur + 1; if (nxt >= NS) nxt -= NS;
+    int free_slot = cur + 4; if (free_slot >= NS) free_slot -= NS;      // slab kt - 1's slot: everyone left it at the last barrier
+    RING_ISSUE(kt + 4, free_slot)
+    SB();
+    const char* base = smem + cur * SLAB;
+    const char* nbase = smem + nxt * SLAB;
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      const int ns = (s4 + 2) & 3;
+      const char* rb = s4 < 2 ? base : nbase;
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+#pragma unroll
+        for (int n = 0; n < 2; ++n) acc[m][n] = mfma32_f16(fa[s4][m], fb[s4][n], acc[m][n]);
+        SB();
+      }
+      // (after the step's MFMAs have been issued: its own operands are dead, set ns was last read two steps ago)
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        fa[ns][m] = *(const half8*)(rb + a_base + m * 32 * 128 + frag[ns]);
+        fb[ns][m] = *(const half8*)(rb + b_base + m * 32 * 128 + frag[ns]);
+      }
+      SB();
+    }
+    if (nlo && kt == nlo - 1) {
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) acc[m][n][i] *= p.lo_scale;
+    }
+    // slab kt + 2 landed (kt + 3 and kt + 4 stay in flight) ... for everyone; and everyone is past slab kt.  A bare s_barrier:
+    // the fragment reads still in flight here are slab kt + 1's (its slot is not reused before the NEXT barrier), so there is
+    // nothing for an lgkmcnt(0) - which __syncthreads() would add, one exposed LDS round trip per slab - to protect
+    asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
+    cur = nxt;
+  }
+#undef RING_ISSUE
+#undef SB
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the clamped tail requests: nobody may still be writing LDS
+  __syncthreads();
+
+  // ---------------- epilogue: gemm_nt_kernel's ----------------
+  float* C32 = p.C32 ? p.C32 + z * p.sC32 : nullptr;
+  _Float16* C16 = p.C16 ? p.C16 + z * p.sC16 : nullptr;
+  const float* bias = p.bias ? p.bias + z * p.sBias : nullptr;
+  const float* res = p.res ? p.res + z * p.sRes : nullptr;
+  const float* gate = p.gate ? p.gate + z * p.sGate : nullptr;
+  if (p.vec_epilogue) {
+    float* stage = (float*)smem + wave * (64 * 64);
+    DVD_EPILOGUE_BLOCK64(p, stage, acc[0][0], acc[0][1], acc[1][0], acc[1][1], bm0 + 64 * wr, bn0 + 64 * wc, lane, C32,
+                         C16, bias, res, gate)
+  } else {
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+      const int col = bn0 + 64 * wc + 32 * n + r;
+      if (col >= p.N) continue;
+      const float bcol = (bias && !p.bias_row) ? bias[col] : 0.f;
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+        epilogue_tile(p, acc[m][n], bm0 + 64 * wr + 32 * m, col, h, bcol, C32, C16, bias, res, gate);
+    }
+  }
 }
 
 template <int DBG>   // DBG: timing ablations (DVD_GEMM_DEBUG) 1 = no operand loads in the K loop, 2 = no MFMAs, 5 = no fragment
@@ -1941,6 +2115,26 @@ extern "C" int dvd_gemm_nt(const dvd_gemm_desc* d, void* stream) {
   }
   p.ntm = cdiv(d->M, 128); p.ntn = cdiv(d->N, 128);
   dim3 grid(p.ntm * p.ntn, d->batch);
+  {
+    // f16 problems with few 128 x 128 tiles: the LDS-DMA ring kernel (same bits; see gemm_nt_ring128_kernel)
+    auto al16 = [](const void* q) { return ((uintptr_t)q % 16) == 0; };
+    bool ring = d->dtype != 1 && d->K % 64 == 0 && d->K >= 128 && d->lda % 8 == 0 && d->ldb % 8 == 0 && d->strideA % 8 == 0 &&
+                d->strideB % 8 == 0 && al16(d->A) && al16(d->B) && al16(d->A_lo) && al16(d->B_lo) &&
+                (long)p.ntm * p.ntn <= RING128_MAX_TILES && (long)d->M * d->lda < (1l << 30) && (long)d->N * d->ldb < (1l << 30);
+#ifdef DVD_LAB
+    if (const char* e = getenv("DVD_GEMM_RING128")) ring = ring && atoi(e) != 0;
+#endif
+    if (ring) {
+      constexpr int LDS = 5 * 2 * 128 * 128;
+      static DeviceOnce once_r128;
+      if (const auto bit = DeviceOnce::current_bit(); once_r128.need(bit)) {
+        (void)hipFuncSetAttribute((const void*)gemm_nt_ring128_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        once_r128.done(bit);
+      }
+      gemm_nt_ring128_kernel<<<grid, 256, LDS, (hipStream_t)stream>>>(p);
+      return check_launch("gemm_nt(ring128)");
+    }
+  }
 #ifdef DVD_LAB
   if (const char* e = getenv("DVD_GEMM_W8"); e && atoi(e) != 0 && d->dtype != 1) {   // lab: two waves per SIMD on each tile
     gemm_nt_w8_kernel<<<grid, 512, 0, (hipStream_t)stream>>>(p);

@@ -525,6 +525,7 @@ def test_gemm_eight_wave_kernel(ops, lab, monkeypatch, M, N, K):
         torch.cuda.synchronize()
         return [t.cpu() for t in (o32, g16, r32, pg, t16)]
 
+    monkeypatch.setenv("DVD_GEMM_RING128", "0")       # the register-staged 4-wave kernel as the reference of both variants
     monkeypatch.setenv("DVD_GEMM_W8", "1")
     new = run_all()
     tol = 2e-4 * K ** 0.5
@@ -540,3 +541,55 @@ def test_gemm_eight_wave_kernel(ops, lab, monkeypatch, M, N, K):
     old = run_all()
     for i, (x, y) in enumerate(zip(new, old)):
         assert torch.equal(x, y), f"output {i}: the 8-wave and the 4-wave kernel must give the same bits"
+
+
+@pytest.mark.parametrize("M,N,K", [(2048, 1536, 1536), (2048, 384, 384), (300, 200, 128), (1024, 1088, 192), (77, 130, 192),
+                                   (4096, 640, 1088), (2048, 3072, 1536), (128, 128, 128), (2050, 1536, 2048)])
+def test_gemm_ring128_kernel(ops, lab, monkeypatch, M, N, K):
+    """gemm_nt_ring128_kernel (round 5: the 128 x 128 tile fed by LDS-DMA through a five-slab ring, taken by f16 problems with
+    few tiles - the sampler at the reference's operating point) on the small family's calls: (hi, lo) weight pairs and single
+    tensors, ragged M and N (scalar epilogue path when N % 8 != 0), the shortest K (two slabs: prologue and clamped tail only),
+    odd slab counts, bias / GELU -> f16, residual in place, positional rows + gate, row bias: against float64, and THE SAME
+    BITS as the register-staged kernel (lab switch DVD_GEMM_RING128=0), which runs the same MFMA sequence per accumulator
+    and the same epilogue arithmetic."""
+    a = rnd(f"r1a{M}{K}", (M, K)).half().cuda()
+    w = rnd(f"r1b{N}{K}", (N, K)) * 0.2
+    hi = w.half()
+    lo = ((w - hi.float()) * 2048.0).half()
+    hi, lo = hi.cuda(), lo.cuda()
+    bias, res = rnd("r1bias", (N,)).cuda(), rnd(f"r1res{M}{N}", (M, N)).cuda()
+    brow = rnd("r1brow", (M,)).cuda()
+    pos, gate = rnd(f"r1pos{N}", (64, N)).cuda(), rnd(f"r1gate{N}", (2, N)).cuda()
+    ref = a.cpu().double() @ (hi.cpu().double() + lo.cpu().double() / 2048.0).t()
+
+    def run_all():
+        kw = dict(b_lo=lo, small_tiles=True)
+        o32 = torch.zeros(M, N, device="cuda")
+        ops.gemm_nt(a, hi, out32=o32, **kw)
+        g16 = torch.zeros(M, N, dtype=torch.float16, device="cuda")
+        ops.gemm_nt(a, hi, out16=g16, bias=bias, act=1, **kw)
+        r32 = res.clone()
+        ops.gemm_nt(a, hi, out32=r32, res=r32, bias=bias, **kw)
+        pg = torch.zeros(M, N, device="cuda")
+        ops.gemm_nt(a, hi, out32=pg, bias=bias, pos=pos, gate=gate, gate_rows=(M + 1) // 2, res=res, **kw)
+        t16 = torch.zeros(M, N, dtype=torch.float16, device="cuda")
+        ops.gemm_nt(a, hi, out16=t16, bias=brow, bias_row=True, small_tiles=True)          # single tensor, row bias
+        sw = torch.zeros(N, M, device="cuda")
+        ops.gemm_nt(hi, a, out32=sw, a_lo=lo, small_tiles=True)                              # the weight pair on the A side
+        torch.cuda.synchronize()
+        return [t.cpu() for t in (o32, g16, r32, pg, t16, sw)]
+
+    monkeypatch.setenv("DVD_GEMM_RING128", "1")
+    new = run_all()
+    tol = 2e-4 * K ** 0.5
+    assert (new[0].double() - ref).abs().max().item() < tol
+    assert (new[1].double() - torch.nn.functional.gelu(ref + bias.cpu().double(), approximate="tanh")).abs().max().item() < 4e-2
+    assert (new[2].double() - (ref + bias.cpu().double() + res.cpu().double())).abs().max().item() < tol + 1e-5
+    rows = torch.arange(M)
+    pgref = (ref + bias.cpu().double() + pos.cpu().double()[rows % 64]) * gate.cpu().double()[rows // ((M + 1) // 2)] + res.cpu().double()
+    assert (new[3].double() - pgref).abs().max().item() < 2 * tol + 1e-5
+    assert (new[5].double() - ref.t()).abs().max().item() < tol
+    monkeypatch.setenv("DVD_GEMM_RING128", "0")
+    old = run_all()
+    for i, (x, y) in enumerate(zip(new, old)):
+        assert torch.equal(x, y), f"output {i}: the ring kernel and the register-staged kernel must give the same bits"
