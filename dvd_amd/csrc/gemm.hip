@@ -786,12 +786,13 @@ __device__ __forceinline__ void glds_group4(const char* gbase, const unsigned (&
 //   * one barrier per slab (16 MFMAs per wave).
 // Same operands per output in the same order (low parts, scale, high parts; k ascending in 16-deep steps) and the same
 // epilogues: the bits of gemm_nt_kernel<f16>, tested as such.  K % 64 == 0, 16-byte aligned operands and rows.
-// Measured (profiles/r5_gemm_ring128.txt): 13-15 % faster than the register-staged kernel up to 256 tiles (one workgroup per
-// CU: 34 vs 39 us at 2048 x 1536 x 1536 with a weight pair), equal from 384 tiles on, where that kernel has two workgroups
-// per CU and this one (160 KiB of LDS) one - hence RING128_MAX_TILES.  Fragment reads one or two k-steps ahead, __syncthreads
-// or a bare s_barrier: no difference - a slab still takes ~1500 cycles for 512 of matrix work.  Each XCD streams the whole
-// weight pair (9.4 MB, twice its L2) through the fabric once per launch; the per-CU rate, 32 KiB per 0.7 us, is what ~96 KiB in
-// flight buy at a ~2 us round trip.
+// Measured (profiles/r5_gemm_ring128.txt): 23-25 % faster than the register-staged kernel up to 256 tiles (one workgroup per
+// CU: 29.6 vs 38.7 us at 2048 x 1536 x 1536 with a weight pair), equal from 384 tiles on, where that kernel has two workgroups
+// per CU and this one (160 KiB of LDS) one - hence RING128_MAX_TILES.  s_memtime stamps: 855 cycles per slab for 512 of matrix
+// work, the same for ONE tile on an idle chip as for 192 - the bound is inside the workgroup: a wave waits at each of its 8
+// LDS-DMA instructions until the CU's DMA path accepts the piece (~107 cycles per piece and wave = 38 B/clk per CU of the 47
+// the path streams); issued as a burst at the top of the slab those waits cost 1160 cycles per slab, spread between the MFMA
+// pairs 855.  Fragment reads one or two k-steps ahead, __syncthreads or a bare s_barrier: no difference.
 // ================================================================================================
 __global__ void __launch_bounds__(256, 1) gemm_nt_ring128_kernel(GemmArgs p) {
   constexpr int BK = 64, TILE = 128 * 128, SLAB = 2 * TILE, NS = 5;     // bytes: one operand tile, one slab (A | B), ring slots
@@ -858,12 +859,19 @@ __global__ void __launch_bounds__(256, 1) gemm_nt_ring128_kernel(GemmArgs p) {
     glds_group4<4>((lo_ ? Blotile : Btile) + kb_, boff, lds0 + (slot_) * SLAB + TILE + (4 * wave) * 1024); \
   }
 #define SB() __builtin_amdgcn_sched_barrier(0)
+#ifdef DVD_LAB
+  unsigned long long ts0 = 0, ts1 = 0, ts2 = 0;        // lab: s_memtime stamps (benchmarks/gemm_ring128_stamps.py)
+  if (p.stamps) ts0 = __builtin_amdgcn_s_memtime();
+#endif
   RING_ISSUE(0, 0)
   RING_ISSUE(1, 1)
   RING_ISSUE(2, 2)
   RING_ISSUE(3, 3)
   asm volatile("s_waitcnt vmcnt(16)" ::: "memory");   // slabs 0 and 1 (this wave's pieces); 2 and 3 stay in flight
   __syncthreads();
+#ifdef DVD_LAB
+  if (p.stamps) ts1 = __builtin_amdgcn_s_memtime();
+#endif
   // k-step s4 of every slab multiplies from register set s4; the reads issued between its MFMAs are those of the step TWO
   // ahead (set (s4 + 2) & 3: this slab's, or the next slab's first two) - 8 MFMAs = 256 cycles between a read and its use,
   // with one wave per SIMD nothing else covers an LDS round trip
@@ -880,8 +888,16 @@ __global__ void __launch_bounds__(256, 1) gemm_nt_ring128_kernel(GemmArgs p) {
   for (int kt = 0; kt < nk; ++kt) {
     int nxt = cur + 1; if (nxt >= NS) nxt -= NS;
     int free_slot = cur + 4; if (free_slot >= NS) free_slot -= NS;      // slab kt - 1's slot: everyone left it at the last barrier
-    RING_ISSUE(kt + 4, free_slot)
-    SB();
+    // slab kt + 4's eight pieces, ONE after every pair of MFMAs: a piece is accepted every ~90 cycles when the CU's four
+    // waves all feed the LDS-DMA path (47 B/clk per CU), and a wave waits at the instruction until it is - issued as a burst
+    // at the top of the slab they cost 700 cycles in front of its 512 cycles of MFMAs (stamps: 1160 per slab, whatever the
+    // problem size, even for a single tile); spread, the matrix pipe works through the waits
+    const int tt_n = min(kt + 4, last);
+    const bool lo_n = tt_n < nlo;
+    const size_t kb_n = (size_t)(lo_n ? tt_n : tt_n - nlo) * (BK * 2);
+    const char* a_n = (lo_n ? Alotile : Atile) + kb_n;
+    const char* b_n = (lo_n ? Blotile : Btile) + kb_n;
+    const unsigned lds_n = lds0 + free_slot * SLAB + (4 * wave) * 1024;
     const char* base = smem + cur * SLAB;
     const char* nbase = smem + nxt * SLAB;
 #pragma unroll
@@ -892,6 +908,9 @@ __global__ void __launch_bounds__(256, 1) gemm_nt_ring128_kernel(GemmArgs p) {
       for (int m = 0; m < 2; ++m) {
 #pragma unroll
         for (int n = 0; n < 2; ++n) acc[m][n] = mfma32_f16(fa[s4][m], fb[s4][n], acc[m][n]);
+        const int pc = 2 * s4 + m;                   // piece 0..7 of the next slab: A 0-3, B 0-3
+        if (pc < 4) glds_one4(a_n, aoff[pc], lds_n + pc * 1024);
+        else glds_one4(b_n, boff[pc - 4], lds_n + TILE + (pc - 4) * 1024);
         SB();
       }
       // (after the step's MFMAs have been issued: its own operands are dead, set ns was last read two steps ago)
@@ -918,6 +937,9 @@ __global__ void __launch_bounds__(256, 1) gemm_nt_ring128_kernel(GemmArgs p) {
   }
 #undef RING_ISSUE
 #undef SB
+#ifdef DVD_LAB
+  if (p.stamps) ts2 = __builtin_amdgcn_s_memtime();
+#endif
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the clamped tail requests: nobody may still be writing LDS
   __syncthreads();
 
@@ -942,6 +964,13 @@ __global__ void __launch_bounds__(256, 1) gemm_nt_ring128_kernel(GemmArgs p) {
         epilogue_tile(p, acc[m][n], bm0 + 64 * wr + 32 * m, col, h, bcol, C32, C16, bias, res, gate);
     }
   }
+#ifdef DVD_LAB
+  if (p.stamps && lane == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    unsigned long long* o = p.stamps + ((size_t)blockIdx.x * 4 + wave) * 8;
+    o[0] = ts0; o[1] = ts1; o[2] = ts2; o[3] = __builtin_amdgcn_s_memtime();
+  }
+#endif
 }
 
 template <int DBG>   // DBG: timing ablations (DVD_GEMM_DEBUG) 1 = no operand loads in the K loop, 2 = no MFMAs, 5 = no fragment
