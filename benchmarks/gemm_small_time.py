@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """The sampler's per-step GEMMs at the reference's native point (G = 64: 1024 tokens x 2 hypotheses = 2048 rows per document,
 (hi, lo) weight pairs, 128 x 128 tiles): what the library dispatches (product) beside the register-staged 4-wave kernel (w4), the LDS-DMA ring kernel where eligible
-(ring), the 8-wave variant (w8; pd4 = w4 with 4-deep register prefetch) - `--lab` switches DVD_GEMM_RING128 / _W8 / _PD4, interleaved in one process.  usage: python benchmarks/gemm_small_time.py [docs=1] [reps=20] --lab"""
+(ring: 128 x 128 tiles; r256: 128 x 256 tiles, eight waves) - `--lab` switches DVD_GEMM_RING128 / _RING256 (also _W8 / _PD4), interleaved in one process.  usage: python benchmarks/gemm_small_time.py [docs=1] [reps=20] --lab"""
 import os, sys
 sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__))); import _lab; LIBSEL = _lab.which()
@@ -25,7 +25,7 @@ def timed(f):
 
 
 tot = {}
-VARIANTS = ("product", "w4", "ring", "w8")     # product = what the library dispatches; pd4 = lab switch.  (rd0/1/2 in profiles/r5_gemm_small_variants.txt
+VARIANTS = ("product", "w4", "ring", "r256")     # product = what the library dispatches; pd4 = lab switch.  (rd0/1/2 in profiles/r5_gemm_small_variants.txt
 # were fragment-read placements of a lab build that was not kept: all 16 reads of a K-tile first = +8 %, slower.)
 for name, N, K, f32out in (("qk  N=3072 K=1536", 3072, 1536, False), ("c1  N=2048 K=1536", 2048, 1536, False),
                            ("fc  N=1536 K=1536", 1536, 1536, True), ("c2  N=1536 K=2048", 1536, 2048, True),
@@ -46,12 +46,13 @@ for name, N, K, f32out in (("qk  N=3072 K=1536", 3072, 1536, False), ("c1  N=204
         flops = 4.0 * M * N * K
     res = {}
     for tag in VARIANTS * 2:
-        for k in ("DVD_GEMM_PD4", "DVD_GEMM_W8", "DVD_GEMM_RING128"): os.environ.pop(k, None)
+        for k in ("DVD_GEMM_PD4", "DVD_GEMM_W8", "DVD_GEMM_RING128", "DVD_GEMM_RING256"): os.environ.pop(k, None)
+        if tag != "product": os.environ["DVD_GEMM_RING256"] = "2" if tag == "r256" else "0"
         if tag == "pd4": os.environ["DVD_GEMM_PD4"], os.environ["DVD_GEMM_RING128"] = "1", "0"
         if tag in ("w4", "w8"): os.environ["DVD_GEMM_W8"], os.environ["DVD_GEMM_RING128"] = ("1" if tag == "w8" else "0"), "0"
         if tag == "ring": os.environ["DVD_GEMM_RING128"] = "1"
         res.setdefault(tag, []).append(timed(f))
-    for k in ("DVD_GEMM_PD4", "DVD_GEMM_W8", "DVD_GEMM_RING128"): os.environ.pop(k, None)
+    for k in ("DVD_GEMM_PD4", "DVD_GEMM_W8", "DVD_GEMM_RING128", "DVD_GEMM_RING256"): os.environ.pop(k, None)
     best = {t: min(v) for t, v in res.items()}
     for t, v in best.items(): tot[t] = tot.get(t, 0.0) + v
     print(f"{name} rows {a.shape[0]:6d}: " + "  ".join(f"{t} {v:7.1f} us" for t, v in best.items()) +

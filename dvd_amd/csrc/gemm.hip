@@ -23,6 +23,10 @@
 #endif
 // gemm_nt_ring128_kernel takes the f16 128 x 128-tile problems with at most this many tiles (profiles/r5_gemm_ring128.txt)
 #define RING128_MAX_TILES 256
+// ... and gemm_nt_ring256_kernel those with N % 256 == 0 whose 128 x 256 tiles fill most of the chip once (with fewer tiles
+// the 128 x 128 ring kernel on twice as many CUs is faster: profiles/r5_gemm_ring256.txt)
+#define RING256_MAX_TILES 256
+#define RING256_MIN_TILES 160
 #ifndef T384_STAGGER
 #define T384_STAGGER 0      // start-up delay quantum of gemm_nt_t384_kernel (x 1024 cycles x 0..15 per workgroup); see the kernel
 #endif
@@ -971,6 +975,174 @@ __global__ void __launch_bounds__(256, 1) gemm_nt_ring128_kernel(GemmArgs p) {
     o[0] = ts0; o[1] = ts1; o[2] = ts2; o[3] = __builtin_amdgcn_s_memtime();
   }
 #endif
+}
+
+// ================================================================================================
+// gemm_nt_ring256_kernel (round 5): gemm_nt_ring128_kernel's scheme on a 128 x 256 tile with EIGHT waves (2 x 4, 64 x 64 each,
+// two per SIMD), for the same few-tile problems when N % 256 == 0.  ring128 is bound by the rate at which a CU's LDS-DMA
+// path accepts its tile's pieces (32 KiB per 64-deep slab for 512 cycles of matrix work per SIMD); this tile needs 48 KiB for
+// twice the work - 25 % fewer bytes per FLOP - and two waves per SIMD cover each other's waits.  K in 32-deep half slabs
+// (A 8 KiB | B 16 KiB: 24 one-KiB pieces of 16 rows x 64 B, three per wave) through a ring of SIX = 144 KiB: half slab j + 4
+// is requested during half slab j (one piece after each of its first three MFMA pairs) and has to have landed by the end
+// of j + 2 (counted wait: vmcnt(6)); the barrier at the end of j publishes j + 2, so j + 1 is complete while j is
+// multiplied and its first fragments are read under j's last MFMAs.  64-byte LDS rows, chunk ^= (row >> 2) & 3 on the
+// source side and in the fragment reads (gemm_nt_split128_kernel's image).  Same operands per output in the same order
+// (low parts, scale, high parts; k ascending in 16-deep steps) and gemm_nt_kernel's epilogues: its bits, tested as such.
+// ================================================================================================
+__global__ void __launch_bounds__(512, 1) gemm_nt_ring256_kernel(GemmArgs p) {
+  constexpr int BK = 32, TA = 128 * 64, TB = 256 * 64, SLOT = TA + TB, NS = 6;     // bytes
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  const int nwg = p.ntm * p.ntn;
+  int id = blockIdx.x;
+  {
+    const int q = nwg / 8, rr = nwg % 8, xcd = id % 8, k = id / 8;       // XCD-aware tile order, as gemm_nt_kernel
+    id = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + k;
+  }
+  const int tm = id / p.ntn, tn = id % p.ntn;
+  const int bm0 = tm * 128, bn0 = tn * 256;
+  const int z = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const int wr = wave >> 2, wc = wave & 3;
+  const _Float16* A = (const _Float16*)p.A + z * p.sA;
+  const _Float16* B = (const _Float16*)p.B + z * p.sB;
+  const _Float16* Alo = p.Alo ? (const _Float16*)p.Alo + z * p.sA : nullptr;
+  const _Float16* Blo = p.Blo ? (const _Float16*)p.Blo + z * p.sB : nullptr;
+
+  // per-lane source offsets of this wave's pieces (16 rows x 64 B each): A piece `wave`, B pieces 2 wave and 2 wave + 1
+  unsigned aoff, boff[2];
+  {
+    const int row = 16 * wave + (lane >> 2), pos = lane & 3;
+    const int ra = min(bm0 + row, p.M - 1) - bm0;
+    aoff = (unsigned)(ra * (p.lda * 2) + (pos ^ ((row >> 2) & 3)) * 16);
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = 16 * (2 * wave + i) + (lane >> 2), pos = lane & 3;
+    const int rb = min(bn0 + row, p.N - 1) - bn0;
+    boff[i] = (unsigned)(rb * (p.ldb * 2) + (pos ^ ((row >> 2) & 3)) * 16);
+  }
+  const char* Atile = (const char*)(A + (size_t)bm0 * p.lda);
+  const char* Btile = (const char*)(B + (size_t)bn0 * p.ldb);
+  const char* Alotile = Alo ? (const char*)(Alo + (size_t)bm0 * p.lda) : Atile;
+  const char* Blotile = Blo ? (const char*)(Blo + (size_t)bn0 * p.ldb) : Btile;
+  const unsigned lds0 = (unsigned)(uintptr_t)(lptr_t)smem;
+  const unsigned lds_a = lds0 + wave * 1024, lds_b = lds0 + TA + (2 * wave) * 1024;
+
+  int frag[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) frag[ks] = r * 64 + (((2 * ks + h) ^ ((r >> 2) & 3)) * 16);
+  const int a_base = wr * 64 * 64;
+  const int b_base = TA + wc * 64 * 64;
+
+  floatx16 acc[2][2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int n = 0; n < 2; ++n)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[m][n][i] = 0.f;
+  const int nkk = p.K / BK;
+  const int nlo = (Blo || Alo) ? nkk : 0;
+  const int nk = nkk + nlo;
+  const int last = nk - 1;
+
+#define R256_SRC(t_)                                                                               \
+  const int tt_ = min((t_), last);                                                                 \
+  const bool lo_ = tt_ < nlo;                                                                      \
+  const size_t kb_ = (size_t)(lo_ ? tt_ : tt_ - nlo) * (BK * 2);                                   \
+  const char* a_s = (lo_ ? Alotile : Atile) + kb_;                                                 \
+  const char* b_s = (lo_ ? Blotile : Btile) + kb_;
+#define SB() __builtin_amdgcn_sched_barrier(0)
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    R256_SRC(t)
+    glds_one4(a_s, aoff, lds_a + t * SLOT);
+    glds_one4(b_s, boff[0], lds_b + t * SLOT);
+    glds_one4(b_s, boff[1], lds_b + t * SLOT + 1024);
+  }
+  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");    // half slabs 0 and 1 (this wave's pieces); 2 and 3 stay in flight
+  __syncthreads();
+  // k-step ks of every half slab multiplies from register set ks; the reads issued between its MFMAs are the next half
+  // slab's same step (one half slab = 8 MFMAs ahead)
+  half8 fa[2][2], fb[2][2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+    for (int m = 0; m < 2; ++m) fa[ks][m] = *(const half8*)(smem + a_base + m * 32 * 64 + frag[ks]);
+#pragma unroll
+    for (int n = 0; n < 2; ++n) fb[ks][n] = *(const half8*)(smem + b_base + n * 32 * 64 + frag[ks]);
+  }
+  SB();
+  int cur = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    int nxt = cur + 1; if (nxt >= NS) nxt -= NS;
+    int free_slot = cur + 4; if (free_slot >= NS) free_slot -= NS;      // half slab kt - 2's slot
+    R256_SRC(kt + 4)
+    const unsigned la = lds_a + free_slot * SLOT, lb = lds_b + free_slot * SLOT;
+    const char* nbase = smem + nxt * SLOT;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+#pragma unroll
+        for (int n = 0; n < 2; ++n) acc[m][n] = mfma32_f16(fa[ks][m], fb[ks][n], acc[m][n]);
+        const int pc = 2 * ks + m;                   // one piece of half slab kt + 4 after each of the first three MFMA pairs
+        if (pc == 0) glds_one4(a_s, aoff, la);
+        else if (pc == 1) glds_one4(b_s, boff[0], lb);
+        else if (pc == 2) glds_one4(b_s, boff[1], lb + 1024);
+        SB();
+      }
+      // this step's operands are dead: the same step of the NEXT half slab (published at the last barrier) into their set
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        fa[ks][m] = *(const half8*)(nbase + a_base + m * 32 * 64 + frag[ks]);
+        fb[ks][m] = *(const half8*)(nbase + b_base + m * 32 * 64 + frag[ks]);
+      }
+      SB();
+    }
+    if (nlo && kt == nlo - 1) {
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) acc[m][n][i] *= p.lo_scale;
+    }
+    // half slab kt + 2 landed (kt + 3 and kt + 4 stay in flight) ... for everyone; and everyone is past half slab kt.  The
+    // fragment reads in flight here are half slab kt + 1's (its slot is reused after the barrier at the end of kt + 1 at
+    // the earliest, by which time they have been consumed): a bare s_barrier
+    asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
+    cur = nxt;
+  }
+#undef R256_SRC
+#undef SB
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the clamped tail requests: nobody may still be writing LDS
+  __syncthreads();
+
+  // ---------------- epilogue: gemm_nt_kernel's ----------------
+  float* C32 = p.C32 ? p.C32 + z * p.sC32 : nullptr;
+  _Float16* C16 = p.C16 ? p.C16 + z * p.sC16 : nullptr;
+  const float* bias = p.bias ? p.bias + z * p.sBias : nullptr;
+  const float* res = p.res ? p.res + z * p.sRes : nullptr;
+  const float* gate = p.gate ? p.gate + z * p.sGate : nullptr;
+  if (p.vec_epilogue) {
+    float* stage = (float*)smem + wave * (64 * 64);                  // 8 x 16 KiB of the 144 KiB
+    DVD_EPILOGUE_BLOCK64(p, stage, acc[0][0], acc[0][1], acc[1][0], acc[1][1], bm0 + 64 * wr, bn0 + 64 * wc, lane, C32,
+                         C16, bias, res, gate)
+  } else {
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+      const int col = bn0 + 64 * wc + 32 * n + r;
+      if (col >= p.N) continue;
+      const float bcol = (bias && !p.bias_row) ? bias[col] : 0.f;
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+        epilogue_tile(p, acc[m][n], bm0 + 64 * wr + 32 * m, col, h, bcol, C32, C16, bias, res, gate);
+    }
+  }
 }
 
 template <int DBG>   // DBG: timing ablations (DVD_GEMM_DEBUG) 1 = no operand loads in the K loop, 2 = no MFMAs, 5 = no fragment
@@ -2153,6 +2325,30 @@ extern "C" int dvd_gemm_nt(const dvd_gemm_desc* d, void* stream) {
 #ifdef DVD_LAB
     if (const char* e = getenv("DVD_GEMM_RING128")) ring = ring && atoi(e) != 0;
 #endif
+    bool ring256 = d->dtype != 1 && d->N % 256 == 0 && d->K % 32 == 0 && d->K >= 128 && d->lda % 8 == 0 && d->ldb % 8 == 0 &&
+                   d->strideA % 8 == 0 && d->strideB % 8 == 0 && al16(d->A) && al16(d->B) && al16(d->A_lo) && al16(d->B_lo) &&
+                   (long)p.ntm * (d->N / 256) <= RING256_MAX_TILES && (long)p.ntm * (d->N / 256) >= RING256_MIN_TILES &&
+                   (long)d->M * d->lda < (1l << 30) &&
+                   (long)d->N * d->ldb < (1l << 30);
+#ifdef DVD_LAB
+    if (const char* e = getenv("DVD_GEMM_RING256")) {       // 0: off; 2: also below RING256_MIN_TILES (tests, A/B runs)
+      if (atoi(e) == 0) ring256 = false;
+      if (atoi(e) == 2) ring256 = d->dtype != 1 && d->N % 256 == 0 && d->K >= 128 && d->lda % 8 == 0 && d->ldb % 8 == 0 && d->strideA % 8 == 0 &&
+                                  d->strideB % 8 == 0 && al16(d->A) && al16(d->B) && al16(d->A_lo) && al16(d->B_lo) &&
+                                  (long)p.ntm * (d->N / 256) <= RING256_MAX_TILES;
+    }
+#endif
+    if (ring256) {
+      constexpr int LDS = 6 * (128 + 256) * 64;
+      static DeviceOnce once_r256;
+      if (const auto bit = DeviceOnce::current_bit(); once_r256.need(bit)) {
+        (void)hipFuncSetAttribute((const void*)gemm_nt_ring256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        once_r256.done(bit);
+      }
+      p.ntn = d->N / 256;
+      gemm_nt_ring256_kernel<<<dim3(p.ntm * p.ntn, d->batch), 512, LDS, (hipStream_t)stream>>>(p);
+      return check_launch("gemm_nt(ring256)");
+    }
     if (ring) {
       constexpr int LDS = 5 * 2 * 128 * 128;
       static DeviceOnce once_r128;

@@ -526,6 +526,7 @@ def test_gemm_eight_wave_kernel(ops, lab, monkeypatch, M, N, K):
         return [t.cpu() for t in (o32, g16, r32, pg, t16)]
 
     monkeypatch.setenv("DVD_GEMM_RING128", "0")       # the register-staged 4-wave kernel as the reference of both variants
+    monkeypatch.setenv("DVD_GEMM_RING256", "0")
     monkeypatch.setenv("DVD_GEMM_W8", "1")
     new = run_all()
     tol = 2e-4 * K ** 0.5
@@ -544,7 +545,7 @@ def test_gemm_eight_wave_kernel(ops, lab, monkeypatch, M, N, K):
 
 
 @pytest.mark.parametrize("M,N,K", [(2048, 1536, 1536), (2048, 384, 384), (300, 200, 128), (1024, 1088, 192), (77, 130, 192),
-                                   (4096, 640, 1088), (2048, 3072, 1536), (128, 128, 128), (2050, 1536, 2048)])
+                                   (4096, 640, 1088), (2048, 3072, 1536), (128, 128, 128), (2050, 1536, 2048), (256, 512, 128), (1000, 768, 192)])
 def test_gemm_ring128_kernel(ops, lab, monkeypatch, M, N, K):
     """gemm_nt_ring128_kernel (round 5: the 128 x 128 tile fed by LDS-DMA through a five-slab ring, taken by f16 problems with
     few tiles - the sampler at the reference's operating point) on the small family's calls: (hi, lo) weight pairs and single
@@ -579,6 +580,7 @@ def test_gemm_ring128_kernel(ops, lab, monkeypatch, M, N, K):
         torch.cuda.synchronize()
         return [t.cpu() for t in (o32, g16, r32, pg, t16, sw)]
 
+    monkeypatch.setenv("DVD_GEMM_RING256", "0")
     monkeypatch.setenv("DVD_GEMM_RING128", "1")
     new = run_all()
     tol = 2e-4 * K ** 0.5
@@ -593,3 +595,9 @@ def test_gemm_ring128_kernel(ops, lab, monkeypatch, M, N, K):
     old = run_all()
     for i, (x, y) in enumerate(zip(new, old)):
         assert torch.equal(x, y), f"output {i}: the ring kernel and the register-staged kernel must give the same bits"
+    # gemm_nt_ring256_kernel (128 x 256 tiles, eight waves, six half slabs): taken where N % 256 == 0 (for the A-side call:
+    # where the row count M of this test is), the other calls fall through to the kernels above
+    monkeypatch.setenv("DVD_GEMM_RING256", "2")       # 2: also where it has fewer tiles than the dispatch rule asks for
+    wide = run_all()
+    for i, (x, y) in enumerate(zip(wide, old)):
+        assert torch.equal(x, y), f"output {i}: the 128 x 256 ring kernel and the register-staged kernel must give the same bits"
