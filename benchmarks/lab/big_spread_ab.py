@@ -1,5 +1,9 @@
+#!/usr/bin/env python3
+"""Lab A/B (DVD_GEMM_SPREAD): the two-sweep 256 x 256 kernel at 65536 rows with its LDS-DMA pieces as a burst (product) or spread
+over the slab.  usage: python benchmarks/lab/big_spread_ab.py   (result: profiles/r5_gemm_big_spread.txt)"""
 import os, sys
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/benchmarks"); import _lab; _lab.use_lab()
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", ".."))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "benchmarks")); import _lab; _lab.use_lab()
 import torch
 from dvd_amd import ops
 M = 65536
