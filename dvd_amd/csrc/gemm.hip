@@ -786,8 +786,10 @@ __device__ __forceinline__ void glds_group4(const char* gbase, const unsigned (&
 //   * a ring of FIVE slabs = all 160 KiB: slab kt + 4 is requested at the top of slab kt and has to have landed by the end
 //     of slab kt + 2 (three slabs of matrix time for an L2 round trip), the wait is counted (vmcnt(16)), never 0;
 //   * the barrier at the end of slab kt publishes slab kt + 2, so slab kt + 1 is complete while slab kt is multiplied:
-//     the last k-step of a slab reads the first fragments of the next one between its MFMAs - no wave starts a slab cold;
-//   * one barrier per slab (16 MFMAs per wave).
+//     fragments are read TWO k-steps ahead (four register sets), the last two steps of a slab reading the first two of the
+//     next one - no wave starts a slab cold;
+//   * the slab's eight LDS-DMA pieces are issued one after every pair of MFMAs, not as a burst (see 'Measured' below);
+//   * one barrier per slab (16 MFMAs per wave), a bare s_barrier: nothing in flight at it needs an lgkmcnt(0).
 // Same operands per output in the same order (low parts, scale, high parts; k ascending in 16-deep steps) and the same
 // epilogues: the bits of gemm_nt_kernel<f16>, tested as such.  K % 64 == 0, 16-byte aligned operands and rows.
 // Measured (profiles/r5_gemm_ring128.txt): 23-25 % faster than the register-staged kernel up to 256 tiles (one workgroup per
