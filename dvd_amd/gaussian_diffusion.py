@@ -17,17 +17,48 @@ def get_named_beta_schedule(schedule_name, num_diffusion_timesteps):
     return schedule.named_betas(schedule_name, num_diffusion_timesteps)
 
 
+_DITHER_KW_CACHE = None          # WeakKeyDictionary, built on first use (callables that cannot be weakly referenced are not cached)
+
+
 def _accepts_dither_step(model) -> bool:
-    """True for this package's denoiser (and anything wrapping it that declares the keyword, e.g. respace._WrappedModel's
-    **kwargs pass-through around a DvdDenoiser); False for a callable with the reference's keyword surface."""
+    """True for this package's denoiser behind any chain of pass-through wrappers (each hop must forward **kwargs or name
+    the keyword); False for a callable with the reference's keyword surface.  Cached per model object."""
+    global _DITHER_KW_CACHE
     import inspect
-    inner = getattr(model, "model", model)            # _WrappedModel keeps the wrapped module in .model
-    fwd = getattr(inner, "forward", inner)
+    import weakref
+    if _DITHER_KW_CACHE is None:
+        _DITHER_KW_CACHE = weakref.WeakKeyDictionary()
     try:
-        params = inspect.signature(fwd).parameters
-    except (TypeError, ValueError):
-        return False
-    return "dither_step" in params
+        hit = _DITHER_KW_CACHE.get(model)
+    except TypeError:
+        hit = None
+    if hit is not None:
+        return hit
+
+    def takes(obj):
+        fwd = getattr(obj, "forward", obj)
+        try:
+            params = inspect.signature(fwd).parameters
+        except (TypeError, ValueError):
+            return False, False
+        return "dither_step" in params, any(p.kind is inspect.Parameter.VAR_KEYWORD for p in params.values())
+
+    obj, ok = model, False
+    for _ in range(8):
+        named, var_kw = takes(obj)
+        if named:
+            ok = True
+            break
+        nxt = next((getattr(obj, a) for a in ("model", "module", "__wrapped__")
+                    if getattr(obj, a, None) is not None and callable(getattr(obj, a))), None)
+        if not var_kw or nxt is None or nxt is obj:      # a hop that neither names the keyword nor forwards **kwargs
+            break
+        obj = nxt
+    try:
+        _DITHER_KW_CACHE[model] = ok
+    except TypeError:
+        pass
+    return ok
 
 
 class ModelMeanType(enum.Enum):
@@ -195,6 +226,26 @@ class GaussianDiffusion:
             kw["dither_step"] = self.num_timesteps - 1 - i
         return kw
 
+    def _wrap_model(self, model):
+        return model
+
+    def _scale_timesteps(self, t):
+        """idf/gaussian_diffusion.py:1170-1173 (the base class scales by 1000 / num_timesteps itself; SpacedDiffusion leaves
+        it to the wrapped model).  `Tables.model_time` is the same float32 product, tested against both forms."""
+        i = self._step_index(t)
+        return th.full((t.shape[0],), self.tables.model_time(i), device=t.device)
+
+    def _call_model(self, model, x, t, i, model_kwargs):
+        """`model(x, self._scale_timesteps(t), **model_kwargs)` on `self._wrap_model(model)` (idf/gaussian_diffusion.py:327,
+        idf/respace.py:80-85): a model the caller wrapped in respace._WrappedModel is not wrapped twice and receives the
+        step indices."""
+        kw = self._single_call_kwargs(model, model_kwargs, i)
+        from .respace import _WrappedModel
+        wrapped = self._wrap_model(model)
+        if isinstance(wrapped, _WrappedModel):
+            return wrapped(x, t.long(), **kw)
+        return wrapped(x, self._scale_timesteps(t), **kw)
+
     def p_mean_variance(self, model, x, t, clip_denoised=True, denoised_fn=None, model_kwargs=None):
         """idf/gaussian_diffusion.py:294-415 for the live configuration (START_X, FIXED_LARGE/SMALL, no clipping):
         {'mean','variance','log_variance','pred_xstart','feat_dict'}; the denoiser runs on the HIP engine, the posterior
@@ -202,8 +253,7 @@ class GaussianDiffusion:
         if clip_denoised or denoised_fn is not None:
             raise NotImplementedError("clip_denoised / denoised_fn are off on the DvD path")
         i = self._step_index(t)
-        t_model = th.full((x.shape[0],), self.tables.model_time(i), device=x.device)
-        x0, feat = model(x, t_model, **self._single_call_kwargs(model, model_kwargs, i))
+        x0, feat = self._call_model(model, x, t, i, model_kwargs)
         c = self.tables.ddpm_coef(i)
         c.sigma = 0.0                                                  # mean only
         mean = ops.sched_step(c, x.float().contiguous(), x0)
@@ -220,8 +270,7 @@ class GaussianDiffusion:
         if clip_denoised or denoised_fn is not None:
             raise NotImplementedError("clip_denoised / denoised_fn are off on the DvD path")
         i = self._step_index(t)
-        t_model = th.full((x.shape[0],), self.tables.model_time(i), device=x.device)
-        x0, feat = model(x, t_model, **self._single_call_kwargs(model, model_kwargs, i))
+        x0, feat = self._call_model(model, x, t, i, model_kwargs)
         coef = self.tables.ddim_coef(i, eta)
         noise = th.randn_like(x0) if coef.sigma != 0.0 else None
         return {"sample": ops.sched_step(coef, x.float().contiguous(), x0, noise), "pred_xstart": x0, "feat_dict": feat}

@@ -11,7 +11,7 @@ import torch
 import torch.distributed as dist
 
 from . import dist_util, logger, synth
-from .evaluation import image_documents, npz_documents, run_evaluation_docunet, synthetic_documents
+from .evaluation import npz_documents, run_evaluation_docunet, synthetic_documents
 from .script_util import args_to_dict, create_model_and_diffusion, model_and_diffusion_defaults
 
 
@@ -81,17 +81,20 @@ def run(settings):
         files = sorted(glob.glob(os.path.join(env.conditioning_dir, "*.npz")))
         mine = dist_util.shard_documents(len(files))
         documents = npz_documents(settings, mine, files)
-    else:      # a benchmark directory of images, as the reference's Doc_benchmark (val_TDiff.py:96-104)
-        # the reference lists the directory (os.listdir, doc_benchmark.py:60-62) and cv2.imread decodes whatever it finds;
-        # here: every file with an image extension, case-insensitively (.JPG from cameras included), in sorted order
-        exts = (".jpg", ".jpeg", ".png", ".bmp", ".tif", ".tiff", ".webp")
-        files = sorted(os.path.join(env.eval_dataset, f) for f in os.listdir(env.eval_dataset)
-                       if f.lower().endswith(exts))
-        mine = dist_util.shard_documents(len(files))
-        documents = image_documents(settings, mine, files)
+    else:      # a benchmark directory of images: the reference's Doc_benchmark behind a DataLoader (val_TDiff.py:93-104)
+        import datasets
+        from torch.utils.data import DataLoader, Subset
+        from utils_data.image_transforms import ArrayToTensor
+        # the workers only decode (PIL); uint8 CHW crosses PCIe (the reference ships float32: get_float=True), the
+        # resize to 512 x 512 and everything after it runs on the GPU.  Unshuffled: rank r owns files r, r+world, ...
+        test_set = datasets.Doc_benchmark(env.eval_dataset, ArrayToTensor(get_float=False))
+        mine = dist_util.shard_documents(len(test_set))
+        documents = DataLoader(Subset(test_set, list(mine)), batch_size=1, shuffle=False, drop_last=False,
+                               num_workers=int(getattr(env, "num_workers", 0)))
     logger.info(f"rank {dist_util.rank()}/{dist_util.world_size()}: {len(mine)} documents")
     logger.info("Starting sampling")
-    results = run_evaluation_docunet(settings, logger, documents, diffusion, model, dist_util.dev(), pre)
+    dewarp, seg, line = pre if pre is not None else (None, None, None)
+    results = run_evaluation_docunet(settings, logger, documents, diffusion, model, dewarp, line, seg)   # val_TDiff.py:103-104
     if dist.is_initialized():
         dist.barrier()
         if own_group:

@@ -133,12 +133,12 @@ def _run_worker(rank, world, port, q, n_docs, tmp):
     seen = {}
     orig = val_TDiff.run_evaluation_docunet
 
-    def spy(settings, logger, documents, diffusion, model, device, prestage_models=None):
+    def spy(settings, logger, val_loader, diffusion, model, dewarp, line=None, seg=None):
         h = hashlib.sha256(model._blob.cpu().numpy().tobytes())
-        for m in prestage_models:                      # denoiser + pre-stage nets travel in the one flat broadcast
+        for m in (dewarp, seg, line):                  # denoiser + pre-stage nets travel in the one flat broadcast
             h.update((m.msk if hasattr(m, "msk") else m)._blob.cpu().numpy().tobytes())
         seen["digest"] = h.hexdigest()
-        return orig(settings, logger, documents, diffusion, model, device, prestage_models)
+        return orig(settings, logger, val_loader, diffusion, model, dewarp, line, seg)
     val_TDiff.run_evaluation_docunet = spy
     results = val_TDiff.run(s)
     q.put((rank, seen["digest"], [p for p, _ in results], calls.count("dvd_engine_denoise_step"),

@@ -242,7 +242,7 @@ def test_run_sampling_command_line(tmp_path):
     import subprocess
     import sys
     root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
-    for name in ("admin", "train_settings", "dvd_amd"):
+    for name in ("admin", "train_settings", "dvd_amd", "datasets", "utils_flow", "utils_data"):
         os.symlink(os.path.join(root, name), tmp_path / name, target_is_directory=True)
     os.symlink(os.path.join(root, "run_sampling.py"), tmp_path / "run_sampling.py")
     import socket
@@ -337,3 +337,150 @@ def test_ddim_sample_chain_equals_the_loop_bit_for_bit():
     trace2 = []
     sampler.sample(eng, diffusion.tables, x_T, trace=trace2, mean_hyp=False)
     assert all(torch.equal(a, b) for a, b in zip(trace, trace2))
+
+
+# ------------------------------------------------------------------------------------------------
+# Round 6: the remaining call SHAPES of SURVEY 8(b), each invoked exactly as its reference call site does.
+# ------------------------------------------------------------------------------------------------
+def test_register_model2_called_as_the_sampling_loop_calls_it_vs_reference_golden():
+    """idf/gaussian_diffusion.py:218,618-624: `self.reg_model_bilin = register_model2((512,512), 'bilinear')`, then per step
+    `pred_flow_ref = (x0_prev + base)*2 - 1; feat = self.reg_model_bilin([feat.to(dev), pred_flow_ref])` - a LIST of
+    [N,256,G,G] features and an NCHW-2 grid (channel 0 = x) - against golden G6 (the real reference's output), bit for bit;
+    datasets/utils/warping.py:14-23,50-73."""
+    from datasets.utils.warping import SpatialTransformer2, register_model2
+    g = np.load(os.path.join(GOLD, "grid_sample.npz"))
+    reg_model_bilin = register_model2((512, 512), "bilinear")
+    assert isinstance(reg_model_bilin, torch.nn.Module) and isinstance(reg_model_bilin.spatial_trans, SpatialTransformer2)
+    assert not list(reg_model_bilin.parameters()) and not reg_model_bilin.state_dict()
+    feat = torch.from_numpy(synth.uniform("g6/feat", (2, 256, 16, 16), 0.0, 2.0, 1234))
+    x0_prev, base = torch.from_numpy(g["x0"]).cuda(), torch.from_numpy(g["base"]).cuda()
+    pred_flow_ref = (x0_prev + base) * 2 - 1
+    assert np.array_equal(pred_flow_ref.cpu().numpy(), g["grid"])
+    out = reg_model_bilin([feat.to(pred_flow_ref.device), pred_flow_ref])
+    assert tuple(out.shape) == (2, 256, 16, 16) and np.array_equal(out.cpu().numpy(), g["out"])
+    # a permuted (non-contiguous) grid view and the direct SpatialTransformer2 call give the same bits
+    nhwc = pred_flow_ref.permute(0, 2, 3, 1).contiguous()
+    assert torch.equal(reg_model_bilin.spatial_trans(feat.cuda(), nhwc.permute(0, 3, 1, 2)), out)
+    with pytest.raises(Exception, match="device|CPU"):           # no CPU route
+        reg_model_bilin([feat, pred_flow_ref.cpu()])
+    with pytest.raises(ValueError):
+        reg_model_bilin([feat.cuda(), pred_flow_ref[:1]])
+    with pytest.raises(NotImplementedError):
+        register_model2((512, 512), "nearest")
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_visualize_dewarping_called_as_the_reference_calls_it_vs_golden(tag, tmp_path, monkeypatch):
+    """evaluation.py:301-312 + visualization_utils.py:64-78: `sample` = the full-resolution grid [1,2,H,W], `source_vis` the CPU
+    float image [1,3,H,W], `data_path` the loader's list of one file name; the PNG lands where the reference writes it and
+    holds golden G5's bytes (the real reference's tail) exactly - and so does the fused route run_evaluation_docunet takes
+    (coarse flow -> dvd_unwarp_u8 -> warped_u8=)."""
+    from PIL import Image
+    import admin.settings as ws
+    from dvd_amd import ops
+    from utils_flow.visualization_utils import visualize_dewarping
+    monkeypatch.chdir(tmp_path)
+    g = np.load(os.path.join(GOLD, "unwarp.npz"))
+    s = ws.Settings()
+    s.name, s.env.eval_dataset_name = "viz", "docunet"
+    src_u8 = g[f"{tag}/src_u8"]
+    source_vis = torch.from_numpy(src_u8.transpose(2, 0, 1)[None].astype(np.float32))          # cpu, as the loader gives it
+    sample = torch.from_numpy(g[f"{tag}/grid"]).cuda()
+    data_path = [f"/data/docunet/crop/{tag}_1 copy.png"]
+    ret = visualize_dewarping(s, sample, {"path": data_path}, 0, source_vis, data_path, None)
+    png = tmp_path / "vis_hp" / "docunet" / "viz" / "dewarped_pred" / f"warped_{tag}_1 copy.png"
+    assert png.exists() and (tmp_path / "vis_hp" / "docunet" / "viz" / "pred_flow").is_dir()
+    assert np.array_equal(np.asarray(Image.open(png)), g[f"{tag}/out_u8"]) and np.array_equal(ret, g[f"{tag}/out_u8"])
+    fused = ops.unwarp_u8(torch.from_numpy(g[f"{tag}/flow"]).cuda(), torch.from_numpy(src_u8).cuda())
+    visualize_dewarping(s, None, None, 1, None, ["fused.png"], warped_u8=fused)
+    assert np.array_equal(np.asarray(Image.open(png.parent / "warped_fused.png")), g[f"{tag}/out_u8"])
+    # ref_flow branch (:80-92): second image under dewarped_pred_ref, named WITH its extension
+    visualize_dewarping(s, sample, None, 2, source_vis, data_path, sample)
+    ref_png = tmp_path / "vis_hp" / "docunet" / "viz" / "dewarped_pred_ref" / f"warped_{tag}_1 copy.png"
+    assert np.array_equal(np.asarray(Image.open(ref_png)), g[f"{tag}/out_u8"])
+
+
+def test_p_mean_variance_on_a_caller_wrapped_model():
+    """idf/respace.py:80-85,95-104,111-123: SpacedDiffusion wraps the model per call, and `_wrap_model` leaves an already
+    wrapped model alone - so diffusion.p_mean_variance / ddim_sample on `diffusion._wrap_model(model)` (or on a
+    `_WrappedModel` the caller built) must give the bits of the plain call: the wrapper receives the step INDEX and hands
+    the denoiser timestep_map[i] * 1000 / S in float32."""
+    from dvd_amd.respace import _WrappedModel
+    grid = 16
+    s, model, diffusion = build(grid, 10)
+    doc = {k: torch.from_numpy(v)[None].repeat(2, 1, 1, 1).cuda() for k, v in synth.synth_document(0, grid, 1234).items()}
+    kw = {"init_flow": torch.zeros(2, 2, grid, grid, device="cuda"), "y512": doc["y512"], "mask_cat": doc["mask_cat"],
+          "init_feat": torch.zeros(2, 256, grid, grid, device="cuda"), "mask_y512": doc["mask_y512"],
+          "line_msk": doc["line_msk"], "tv": True, "iter": True, "tmode": "stage_1_dit_cross", "mode": None}
+    x = torch.from_numpy(synth.uniform("wm/x", (2, 2, grid, grid), -1, 1, 5)).cuda()
+    seen = []
+
+    class Spy(_WrappedModel):
+        def __call__(self, xx, ts, **k):
+            seen.append(ts.clone())
+            return super().__call__(xx, ts, **k)
+    for i in (9, 6, 4, 0):                       # model times 900 (override 2), 600 (raw), 400 (override 1), 0 (raw)
+        t = torch.tensor([i, i], device="cuda")
+        plain = diffusion.p_mean_variance(model, x, t, clip_denoised=False, model_kwargs=kw)
+        wrapped = diffusion.p_mean_variance(diffusion._wrap_model(model), x, t, clip_denoised=False, model_kwargs=kw)
+        spy = Spy(model, diffusion.timestep_map, diffusion.rescale_timesteps, diffusion.original_num_steps)
+        own = diffusion.ddim_sample(spy, x, t, clip_denoised=False, model_kwargs=kw, eta=0.0)
+        assert seen[-1].dtype == torch.int64 and seen[-1].tolist() == [i, i]
+        for k in ("mean", "log_variance", "pred_xstart", "feat_dict"):
+            assert torch.equal(plain[k], wrapped[k]), (i, k)
+        assert torch.equal(own["pred_xstart"], plain["pred_xstart"]), i
+        assert torch.equal(own["sample"], diffusion.ddim_sample(model, x, t, clip_denoised=False, model_kwargs=kw)["sample"])
+
+
+def test_run_evaluation_docunet_on_a_reference_shaped_loader(tmp_path, monkeypatch):
+    """val_TDiff.py:93-104: `Doc_benchmark(dir, ArrayToTensor)` behind `DataLoader(batch_size=1)`, then
+    `run_evaluation_docunet(settings, logger, test_loader, diffusion, model, dewarp, line, seg)` - positional, the
+    reference's order.  Three page images written as PNG files; the documents it returns and the PNGs it writes equal, byte
+    for byte, those of this package's own document route (decoded arrays handed over as `image_u8`), for float
+    (the reference's transform) and uint8 loaders, and for a loader that supplies `source_image` itself."""
+    from PIL import Image
+    from torch.utils.data import DataLoader
+    import datasets
+    from dvd_amd import logger, ops, val_TDiff
+    from train_settings.dvd.evaluation import run_evaluation_docunet
+    from utils_data.image_transforms import ArrayToTensor
+    monkeypatch.chdir(tmp_path)
+    grid = 16
+    s, model, diffusion = build(grid, 3)
+    s.env.batch_docs, s.env.visualize, s.env.eval_dataset_name = 2, True, "docunet"
+    s.env.synthetic_weights_if_missing = True
+    dewarp, seg, line = val_TDiff.load_prestage_models(s.env)
+    os.makedirs("pages")
+    arrays = []
+    for i in range(3):
+        img = synth.smooth_image(f"doc{i}/image", 96 + 8 * i if i < 2 else 96, 80, seed=1234)      # two sizes in one batch
+        arrays.append(np.ascontiguousarray((img.transpose(1, 2, 0) * 255.0).astype(np.uint8)))
+        Image.fromarray(arrays[-1]).save(f"pages/page_{i}.png")
+    own_docs = [{"image_u8": a, "path": f"pages/page_{i}.png"} for i, a in enumerate(arrays)]
+    s.name = "own"
+    torch.manual_seed(0)
+    want = run_evaluation_docunet(s, logger, own_docs, diffusion, model, dewarp, line, seg)
+    assert [p for p, _ in want] == [f"pages/page_{i}.png" for i in range(3)]
+    for get_float in (True, False):
+        s.name = f"loader_{int(get_float)}"
+        test_loader = DataLoader(datasets.Doc_benchmark("pages", ArrayToTensor(get_float=get_float)), batch_size=1,
+                                 shuffle=False, drop_last=False, num_workers=2 if get_float else 0,
+                                 timeout=120 if get_float else 0)
+        torch.manual_seed(0)
+        got = run_evaluation_docunet(s, logger, test_loader, diffusion, model, dewarp, line, seg)
+        assert len(got) == 3
+        for (pa, a), (pb, b), arr in zip(want, got, arrays):
+            assert pa == pb and a.dtype == torch.uint8 and tuple(a.shape) == arr.shape and torch.equal(a, b), pa
+            png = tmp_path / "vis_hp" / "docunet" / s.name / "dewarped_pred" / f"warped_{os.path.basename(pa)[:-4]}.png"
+            assert np.array_equal(np.asarray(Image.open(png)), b.cpu().numpy())
+    # a loader that carries source_image (the reference's cv2 dataset does): taken as given, no ingest
+    s.name = "given"
+    items = []
+    for a, (p, _) in zip(arrays, want):
+        y = ops.ingest_u8(torch.from_numpy(a).cuda(), swap_rb=False, out_size=512)
+        items.append({"source_image": y[None].cpu(), "source_image_ori": torch.from_numpy(a).permute(2, 0, 1)[None].float(),
+                      "path": [p]})
+    torch.manual_seed(0)
+    got = run_evaluation_docunet(s, logger, items, diffusion, model, dewarp, line, seg)
+    for (pa, a), (pb, b) in zip(want, got):
+        assert pa == pb and torch.equal(a, b), pa

@@ -278,3 +278,165 @@ def test_single_step_calls_keep_the_reference_keyword_surface():
     assert "dither_step" not in diff._single_call_kwargs(ref_like, None, 0)
     from dvd_amd.cross_model import DvdDenoiser
     assert "dither_step" in __import__("inspect").signature(DvdDenoiser.forward).parameters
+
+
+# ------------------------------------------------------------------------------------------------
+# Round 6: the drop-in surface in the reference's call shapes: signatures, the time map of
+# respace._WrappedModel, the loader item shapes, the dataset.  Host logic only - nothing here touches the GPU.
+# ------------------------------------------------------------------------------------------------
+def test_evaluation_entry_points_have_the_reference_positional_signatures():
+    """evaluation.py:80-84 and :142-145 of the reference, name by name and in order: a reference-side caller passes these
+    POSITIONALLY (evaluation.py:247-265, val_TDiff.py:103-104)."""
+    import inspect
+    from train_settings.dvd.evaluation import run_evaluation_docunet, run_sample_lr_dewarping
+    names = lambda f: [(p.name, p.default is not inspect.Parameter.empty)  # noqa: E731
+                       for p in inspect.signature(f).parameters.values() if p.kind is p.POSITIONAL_OR_KEYWORD]
+    assert names(run_sample_lr_dewarping) == [(n, False) for n in (
+        "settings", "logger", "diffusion", "model", "radius", "source", "feature_size", "raw_corr", "init_flow", "c20",
+        "source_64", "pyramid", "doc_mask")] + [("seg_map_all", True), ("textline_map", True), ("init_feat", True)]
+    assert names(run_evaluation_docunet) == [(n, False) for n in (
+        "settings", "logger", "val_loader", "diffusion", "model", "pretrained_dewarp_model")] + \
+        [("pretrained_line_seg_model", True), ("pretrained_seg_model", True)]
+    from utils_flow.visualization_utils import visualize_dewarping
+    assert [n for n, _ in names(visualize_dewarping)] == ["settings", "sample", "data", "i", "source_vis", "data_path", "ref_flow"]
+
+
+def test_run_sample_lr_dewarping_builds_the_reference_kwargs_and_call():
+    """The model_kwargs dict and the ddim_sample_loop call of evaluation.py:106-135, observed on a recording diffusion."""
+    import torch
+    import admin.settings as ws
+    from dvd_amd import evaluation
+    s = ws.Settings()
+    seen = {}
+
+    class Diff:
+        def ddim_sample_loop(self, model, shape, **kw):
+            seen.update(kw, model=model, shape=shape)
+            return torch.full(shape, 3.0), {}
+
+    class Log:
+        def info(self, *a):
+            pass
+    src, flow0, msk = torch.zeros(1, 3, 512, 512), torch.zeros(1, 2, 64, 64), torch.ones(1, 1, 512, 512)
+    seg, line, feat0 = torch.zeros(1, 384, 64, 64), torch.zeros(1, 64, 64, 64), torch.zeros(1, 256, 64, 64)
+    out = evaluation.run_sample_lr_dewarping(s, Log(), Diff(), "MODEL", 4, src, 64, None, flow0, None, None, "PYR", msk,
+                                             seg, line, feat0)
+    assert float(out.max()) == 1.0                                        # th.clamp(sample, -1, 1) (:137)
+    assert seen["model"] == "MODEL" and seen["shape"] == (1, 2, 64, 64) and seen["pyramid"] == "PYR"
+    assert seen["noise"] is None and seen["clip_denoised"] is False and seen["eta"] == 0.0 and seen["n_batch"] == 2
+    assert seen["time_variant"] is True and seen["sampling_kwargs"]["src_img"] is src and "sampler_kind" not in seen
+    kw = seen["model_kwargs"]
+    assert set(kw) == {"init_flow", "src_feat", "src_64", "y512", "tmode", "mask_cat", "init_feat", "iter", "mask_y512", "line_msk"}
+    assert kw["y512"] is src and kw["mask_cat"] is msk and kw["mask_y512"] is seg and kw["line_msk"] is line
+    assert kw["init_flow"] is flow0 and kw["init_feat"] is feat0 and kw["src_feat"] is None and kw["iter"] is True
+
+
+@pytest.mark.parametrize("steps,respacing", [(3, ""), (10, ""), (50, ""), (250, ""), (1000, "ddim50"), (1000, "10,15,25")])
+def test_wrapped_model_time_map_equals_the_tables(steps, respacing):
+    """respace._WrappedModel (idf/respace.py:111-123): index tensor -> timestep_map -> float32 * (1000 / original steps),
+    equal BITWISE to Tables.model_time(i) (what the sampling loop feeds the engine) for every step; the golden G1
+    t_model sequence of S = 10 pins the form against the real reference."""
+    import torch
+    from dvd_amd import respace, script_util
+    d = script_util.create_gaussian_diffusion(steps=steps, noise_schedule="cosine", predict_xstart=True,
+                                              rescale_timesteps=True, timestep_respacing=respacing)
+    assert isinstance(d, respace.SpacedDiffusion)
+    got = []
+    inner = lambda x, ts, **kw: got.append((ts.clone(), kw)) or "OUT"  # noqa: E731
+    w = d._wrap_model(inner)
+    assert isinstance(w, respace._WrappedModel) and d._wrap_model(w) is w and w.model is inner
+    assert w.original_num_steps == steps and w.rescale_timesteps and list(w.timestep_map) == list(d.timestep_map)
+    for i in range(d.num_timesteps):
+        assert w(None, torch.tensor([i, i]), a=1) == "OUT"
+        ts, kw = got[-1]
+        assert ts.dtype == torch.float32 and kw == {"a": 1}
+        assert ts.tolist() == [d.tables.model_time(i)] * 2, (i, ts, d.tables.model_time(i))
+    if (steps, respacing) == (10, ""):           # golden G1 (the real reference's wrapped-model times, index order)
+        sch = np.load(os.path.join(os.path.dirname(__file__), "golden", "schedule.npz"))
+        assert np.array_equal(np.array([float(t[0][0]) for t in got], np.float32), sch["s10/t_model_raw"])
+
+
+def test_dither_keyword_reaches_the_denoiser_through_pass_through_wrappers():
+    """Round-5 ADVICE: the loop's dithering phase must reach a DvdDenoiser behind ANY pass-through wrapper (DDP's .module,
+    a user wrapper forwarding **kwargs, respace._WrappedModel), and a callable with the reference's keyword surface must
+    not be handed an unknown keyword."""
+    from dvd_amd import respace
+    from dvd_amd.gaussian_diffusion import _accepts_dither_step
+
+    class Den:                                   # stands for DvdDenoiser: names the keyword
+        def forward(self, x, t, init_flow=None, dither_step=None):
+            return x
+
+        __call__ = forward
+
+    class DDPLike:
+        def __init__(self, m):
+            self.module = m
+
+        def forward(self, *a, **kw):
+            return self.module(*a, **kw)
+
+        __call__ = forward
+
+    class UserWrap:
+        def __init__(self, m):
+            self.model = m
+
+        def __call__(self, x, t, **kw):
+            return self.model(x, t, **kw)
+
+    class Blocking:                              # forwards a FIXED keyword set: the phase cannot pass
+        def __init__(self, m):
+            self.model = m
+
+        def __call__(self, x, t, init_flow=None):
+            return self.model(x, t, init_flow=init_flow)
+    den = Den()
+    assert _accepts_dither_step(den)
+    assert _accepts_dither_step(DDPLike(den)) and _accepts_dither_step(UserWrap(DDPLike(den)))
+    assert _accepts_dither_step(respace._WrappedModel(den, [0, 1, 2], True, 3))
+    assert not _accepts_dither_step(Blocking(den))
+    assert not _accepts_dither_step(lambda x, t, init_flow=None: x)
+    assert not _accepts_dither_step(lambda x, t, **kw: x)        # forwards to nothing that names it
+    w = UserWrap(den)
+    assert _accepts_dither_step(w) and _accepts_dither_step(w)   # second call: the per-object cache
+
+
+def test_doc_benchmark_dataset_and_loader_item_shapes(tmp_path):
+    """datasets.Doc_benchmark (doc_benchmark.py:49-97) behind the reference's DataLoader(batch_size=1): the reference's
+    keys and layouts, files in sorted order, EXIF-free PNG decode exact; evaluation.documents_of splits both item shapes."""
+    import torch
+    from PIL import Image
+    from torch.utils.data import DataLoader
+    import datasets
+    from dvd_amd import evaluation
+    from utils_data.image_transforms import ArrayToTensor
+    rng = np.random.RandomState(0)
+    imgs = {}
+    for name, hw in (("b_page.png", (40, 30)), ("a_page.PNG", (24, 56)), ("notes.txt", None)):
+        if hw is None:
+            (tmp_path / name).write_text("not an image")
+            continue
+        imgs[name] = rng.randint(0, 256, size=hw + (3,)).astype(np.uint8)
+        Image.fromarray(imgs[name]).save(tmp_path / name, format="PNG")
+    ds = datasets.Doc_benchmark(str(tmp_path), ArrayToTensor(get_float=True))
+    assert len(ds) == 2 and ds.data_paths == ["a_page.PNG", "b_page.png"]
+    items = list(DataLoader(ds, batch_size=1, shuffle=False, num_workers=0))
+    for item, name in zip(items, ds.data_paths):
+        assert set(item) == {"source_image_ori", "path"} and item["path"] == [os.path.join(str(tmp_path), name)]
+        ori = item["source_image_ori"]
+        assert ori.dtype == torch.float32 and tuple(ori.shape) == (1, 3) + imgs[name].shape[:2]
+        assert np.array_equal(ori[0].permute(1, 2, 0).numpy().astype(np.uint8), imgs[name])
+        (d,) = evaluation.documents_of(item)
+        assert d["path"] == item["path"][0] and d["source_vis"].shape == ori.shape[1:] and "y512" not in d
+        u8 = evaluation._source_u8(d, "cpu")
+        assert u8.dtype == torch.uint8 and np.array_equal(u8.numpy(), imgs[name])
+    # a reference loader item (cv2 dataset: source_image present), b = 2; and one of this package's documents
+    item = {"source_image": torch.rand(2, 3, 512, 512), "source_image_ori": torch.zeros(2, 3, 8, 6), "path": ["x/p.jpg", "x/q.jpg"]}
+    docs = evaluation.documents_of(item)
+    assert [d["path"] for d in docs] == ["x/p.jpg", "x/q.jpg"] and torch.equal(docs[1]["y512"], item["source_image"][1])
+    own = {"image_u8": np.zeros((4, 4, 3), np.uint8), "path": "stem"}
+    assert evaluation.documents_of(own) == [own]
+    # a float source that is not a byte image cannot become u8 exactly
+    assert evaluation._source_u8({"source_vis": torch.full((3, 2, 2), 7.5)}, "cpu") is None
+    assert ArrayToTensor(get_float=False)(imgs["b_page.png"]).dtype == torch.uint8

@@ -42,13 +42,25 @@ CASES = {
     # headline loop on the PLAIN family (the golden vectors' family) with the reference's two hypotheses
     "ddpm_g288_s10_tame": (288, 10, 1, "tame", "ddpm", [0, 4, 9]),
     "ddim_g288_s50_plain": (288, 50, 2, "plain", "ddim", [0, 28, 49]),
+    # round 6: a family with PEAKED decoder attention (logits x 12: std ~ 10 instead of ~ 0.9, the largest
+    # probability of a row ~ 0.5 instead of ~ 0.01 - the deferred-rescale branch of the online softmax and f16 P with few
+    # dominant terms), and BASELINE configs[3]'s sampler at its REAL LENGTH (250 ancestral steps) on a grid that runs the
+    # headline kernels (T = 6400 >= 5376: r64x / h64x attention, 384 x 256 GEMMs on dithered weights).  250 steps at G = 288
+    # are ~8 h of oracle on all 8 cores of the build box (114 s per step), G = 160 is ~1.5 h.
+    "ddim_g96_s50_peaked": (96, 50, 1, "peaked", "ddim", [0, 7, 14, 21, 28, 35, 42, 49]),
+    "ddpm_g160_s250_tame": (160, 250, 1, "tame", "ddpm", list(range(0, 250, 25)) + [249]),
 }
+PEAK_LOGIT_GAIN = 12.0
 
 
 def inputs(grid, steps, hyp, family, sampler):
     """Everything a roll-out of a case needs, from seeds (used by this tool AND by the tests)."""
-    gain = synth.tame_gain(steps) if family == "tame" else 1.0
+    gain = synth.tame_gain(steps) if family in ("tame", "peaked") else 1.0
     sd = synth.synth_state_dict(grid, SEED_W, blocks=[11], out_gain=gain)
+    if family == "peaked":       # the tame family with the decoder's q / k projections scaled: logits x PEAK_LOGIT_GAIN
+        for k in list(sd):
+            if k.endswith("attn.linear_q.weight") or k.endswith("attn.linear_k.weight"):
+                sd[k] = (np.asarray(sd[k]) * np.float32(PEAK_LOGIT_GAIN ** 0.5)).astype(np.float32)
     d0 = synth.synth_document(0, grid, SEED_IN)
     doc = {k: torch.from_numpy(d0[k])[None] for k in ("y512", "mask_cat", "mask_y512", "line_msk")}
     xT = torch.from_numpy(synth.synth_noise(0, hyp, grid, SEED_IN))
