@@ -18,6 +18,17 @@ for tx, ty in (("4", "1"), ("4", "2"), ("2", "2"), ("2", "4"), ("2", "8"), ("1",
         os.environ["DVD_DWCONV_TY"], os.environ["DVD_DWCONV_TX"] = ty, tx
         ms = t(f)
         print(f"{tx} x {ty} tokens per thread: {ms:.3f} ms  {gb / ms * 1e3:.0f} GB/s")
+del os.environ["DVD_DWCONV_TY"], os.environ["DVD_DWCONV_TX"]
+for tx in ("2", "3", "4"):
+    for sy in ("144", "72", "48", "36", "24", "16"):
+        for nt in (False, True):
+            os.environ["DVD_DWCONV_STRIP"], os.environ["DVD_DWCONV_SY"] = tx, sy
+            os.environ["DVD_DWCONV_NT"] = "1" if nt else "0"
+            ms = t(f)
+            print(f"strip {tx} columns x {sy:>3} rows{' nt' if nt else '   '}: {ms:.3f} ms  {gb / ms * 1e3:.0f} GB/s")
+for k in ("DVD_DWCONV_STRIP", "DVD_DWCONV_SY", "DVD_DWCONV_NT"): os.environ.pop(k, None)
+ms = t(f)
+print(f"product rule: {ms:.3f} ms  {gb / ms * 1e3:.0f} GB/s")
 os.environ["DVD_DWCONV_V1"] = "1"
 ms = t(f)
 print(f"one token per thread (v1): {ms:.3f} ms  {gb / ms * 1e3:.0f} GB/s")

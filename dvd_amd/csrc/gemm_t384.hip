@@ -556,6 +556,9 @@ int launch_gemm_t384(const GemmArgs& p, int batch, int dbg, void* stream) {
   }
   int nblk = p.ntm * p.ntn;
   if (nblk > 256) nblk = 256;
+#ifdef DVD_LAB
+  if (const char* e = getenv("DVD_GEMM_T384_NBLK")) nblk = atoi(e) < nblk ? atoi(e) : nblk;   // lab: fewer persistent workgroups
+#endif
   const dim3 grid(nblk, batch);
   hipStream_t st = (hipStream_t)stream;
   // the epilogue flavour is a function of the descriptor (never of the data): see gemm_nt_t384_kernel

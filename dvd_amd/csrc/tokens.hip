@@ -394,6 +394,121 @@ __global__ void __launch_bounds__(256) dwconv3x3_tile_kernel(const _Float16* __r
   }
 }
 
+// Round 6: the same op as a SLIDING WINDOW down the image.  One wave = 512 channels (16 bytes per lane) of
+// a strip of TX token columns; it walks SY rows down, holding input rows y - 1, y, y + 1 (TX + 2 columns each) in registers and
+// the row after them in flight: per output row ONE new input row is loaded - (TX + 2) / TX loads per output instead of the
+// tile kernel's 3 - the 72 weights of a lane's 8 channels stay in registers for the whole strip, and every column / row test is
+// wave-uniform (scalar branches, no exec masks).  What the tile kernel left on the table was not instructions but LOCALITY: its
+// 2 x 4 tiles re-read every input token three times through L2, and with workgroup i on XCD i mod 8 the tiles that share a halo
+// sat on eight different L2s (fabric traffic ~3x the input).  Here the units are numbered so that the workgroups resident on
+// one XCD at a time are x-adjacent strips of one band of rows: the two halo columns a strip shares with its neighbours are
+// hits in THAT XCD's L2, the band's y halo is 2 rows in SY.  Per output the taps are summed in the order dy = -1, 0, 1 /
+// dx = -1, 0, 1 from the bias, out-of-range taps skipped, each step one FMA of the f16 input with the f32 weight - the order
+// and the arithmetic of dwconv3x3_kernel: bit-identical (tests/test_gpu_tokens.py).  Needs c % 512 == 0 (the decoder FFN: 2048).
+// One strip: LEFT / RIGHT = the strip touches the image's left / right edge (the halo column there does not exist: its taps are
+// skipped STATICALLY; its loads are clamped onto an existing column so that every load is unconditional and the waits are counted).
+template <int TX, bool NT, bool LEFT, bool RIGHT>
+__device__ __forceinline__ void dwconv_strip(const _Float16* __restrict__ img, _Float16* __restrict__ oimg, const float (&wt)[9][8],
+                                             const float (&bs)[8], int side, int c, int x0, int y0, int y1) {
+  const int ncol = RIGHT ? side - x0 : TX;           // output columns of this strip (the last strip may be narrower)
+  half8 R[4][TX + 2];                                // rows y - 1, y, y + 1 and the one in flight, rotating
+  size_t coff[TX + 2];                               // element offsets of the window's columns (clamped into the image)
+#pragma unroll
+  for (int i = 0; i < TX + 2; ++i) coff[i] = (size_t)min(max(x0 - 1 + i, 0), side - 1) * c;
+  auto load_row = [&](int y, half8 (&dst)[TX + 2]) {
+    const _Float16* rp = img + (size_t)min(max(y, 0), side - 1) * side * c;
+#pragma unroll
+    for (int i = 0; i < TX + 2; ++i) dst[i] = *(const half8*)(rp + coff[i]);
+  };
+  load_row(y0 - 1, R[0]);
+  load_row(y0, R[1]);
+  load_row(y0 + 1, R[2]);
+  for (int yy = y0; yy < y1; yy += 4) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int y = yy + u;
+      if (y < y1) {
+        load_row(y + 2, R[(u + 3) & 3]);             // lands while this row and the next are computed
+        float acc[TX][8];
+#pragma unroll
+        for (int k = 0; k < TX; ++k)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) acc[k][e] = bs[e];
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy) {
+          if (dy == -1 && y == 0) continue;          // wave-uniform: the image's first / last row
+          if (dy == 1 && y == side - 1) continue;
+          const half8 (&row)[TX + 2] = R[(u + 1 + dy) & 3];
+#pragma unroll
+          for (int dx = -1; dx <= 1; ++dx) {
+            const int t = (dy + 1) * 3 + (dx + 1);
+#pragma unroll
+            for (int k = 0; k < TX; ++k) {
+              if (LEFT && k + dx < 0) continue;                    // column x0 - 1 does not exist
+              if (RIGHT && k + dx >= ncol) continue;               // ... nor column x0 + ncol (wave-uniform)
+#pragma unroll
+              for (int e = 0; e < 8; ++e) acc[k][e] = __builtin_fmaf((float)row[k + 1 + dx][e], wt[t][e], acc[k][e]);
+            }
+          }
+        }
+        _Float16* op = oimg + ((size_t)y * side + x0) * c;
+#pragma unroll
+        for (int k = 0; k < TX; ++k) {
+          if (RIGHT && k >= ncol) continue;
+          half8 o;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = (_Float16)fmaxf(acc[k][e], 0.f);
+          if (NT) __builtin_nontemporal_store(o, (half8*)(op + (size_t)k * c));
+          else *(half8*)(op + (size_t)k * c) = o;
+        }
+      }
+    }
+  }
+}
+
+template <int TX, bool NT>
+__global__ void __launch_bounds__(256) dwconv3x3_strip_kernel(const _Float16* __restrict__ in, _Float16* __restrict__ out,
+                                                              const float* __restrict__ w, const float* __restrict__ b, int side,
+                                                              int c, int sy, int xstrips, int ybands, int nwaves) {
+  // XCD-aware numbering: hardware block id -> logical id such that the blocks one XCD runs are consecutive logical ids
+  int id = blockIdx.x;
+  {
+    const int nwg = gridDim.x, q = nwg / 8, rr = nwg % 8, xcd = id % 8, k = id / 8;
+    id = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + k;
+  }
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(id * 4 + (int)(threadIdx.x >> 6));
+  if (wid >= nwaves) return;
+  const int chunks = c >> 9;                         // 512-channel chunks per token
+  const int chunk = wid % chunks;
+  int unit = wid / chunks;
+  const int xs = unit % xstrips;
+  unit /= xstrips;
+  const int yb = unit % ybands;
+  const int n = unit / ybands;
+  const int x0 = xs * TX, y0 = yb * sy, y1 = min(y0 + sy, side);
+  const int ch = chunk * 512 + lane * 8;
+  const _Float16* img = in + (size_t)n * side * side * c + ch;
+  _Float16* oimg = out + (size_t)n * side * side * c + ch;
+  float wt[9][8], bs[8];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const floatx4 w0 = *(const floatx4*)(w + t * c + ch), w1 = *(const floatx4*)(w + t * c + ch + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { wt[t][e] = w0[e]; wt[t][4 + e] = w1[e]; }
+  }
+  {
+    const floatx4 b0 = *(const floatx4*)(b + ch), b1 = *(const floatx4*)(b + ch + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { bs[e] = b0[e]; bs[4 + e] = b1[e]; }
+  }
+  const bool left = x0 == 0, right = x0 + TX >= side;          // wave-uniform
+  if (!left && !right) dwconv_strip<TX, NT, false, false>(img, oimg, wt, bs, side, c, x0, y0, y1);
+  else if (left && !right) dwconv_strip<TX, NT, true, false>(img, oimg, wt, bs, side, c, x0, y0, y1);
+  else if (!left) dwconv_strip<TX, NT, false, true>(img, oimg, wt, bs, side, c, x0, y0, y1);
+  else dwconv_strip<TX, NT, true, true>(img, oimg, wt, bs, side, c, x0, y0, y1);
+}
+
 // ----------------------------------------------------------------------------------------------
 // K12: adaptive 2-D positional encoding (idf/cross_attn.py:143-157)
 // colsum_partial: part[n][chunk][c] = sum over the chunk's tokens of z[n,t,c]   (deterministic 2-stage)
@@ -663,6 +778,35 @@ extern "C" int dvd_dwconv3x3(const void* in16, void* out16, const float* w9c, co
     return check_launch("dwconv3x3(lab v1)");
   }
 #endif
+  // product rule (round 6): the sliding-window kernel - 3 columns x 24 rows per wave, streaming stores: 0.505-0.51 ms at
+  // 16 x 144 x 144 x 2048 (5.3-5.4 TB/s) against the tile kernel's 0.97 (profiles/r6_dwconv_strip.txt) - wherever its waves fill
+  // the chip; small maps keep the tile kernel (more, shorter threads).  All kernels give the same bits, so the rule may look
+  // at the batch.
+  int stx = (c % 512 == 0 && (long)n * side * side >= 16384) ? 3 : 0, ssy = 24;
+  bool snt = true;
+  (void)snt;
+#ifdef DVD_LAB
+  // lab: DVD_DWCONV_STRIP = 0 (tile kernel) | 2 | 3 | 4 columns; DVD_DWCONV_SY the band height; DVD_DWCONV_NT = 0 | 1
+  if (getenv("DVD_DWCONV_TY") || getenv("DVD_DWCONV_TX")) stx = 0;
+  if (const char* e = getenv("DVD_DWCONV_STRIP")) stx = (c % 512 == 0) ? atoi(e) : 0;
+  if (const char* e = getenv("DVD_DWCONV_SY")) ssy = atoi(e);
+  if (const char* e = getenv("DVD_DWCONV_NT")) snt = atoi(e) != 0;
+#endif
+  if (stx >= 2 && stx <= 4 && ssy >= 1) {
+    const int xstrips = cdiv(side, stx), ybands = cdiv(side, ssy);
+    const int nwaves = n * ybands * xstrips * (c / 512);
+    const dim3 g(cdiv(nwaves, 4));
+#define DW_STRIP(TX_, NT_) dwconv3x3_strip_kernel<TX_, NT_><<<g, 256, 0, (hipStream_t)stream>>>((const _Float16*)in16, (_Float16*)out16, w9c, b, side, c, ssy, xstrips, ybands, nwaves)
+#ifdef DVD_LAB
+    if (stx == 2) { if (snt) DW_STRIP(2, true); else DW_STRIP(2, false); }
+    else if (stx == 4) { if (snt) DW_STRIP(4, true); else DW_STRIP(4, false); }
+    else if (!snt) DW_STRIP(3, false);
+    else
+#endif
+    DW_STRIP(3, true);
+#undef DW_STRIP
+    return check_launch("dwconv3x3(strip)");
+  }
   int ty = DW_TY_P, tx = DW_TX_P;
 #ifdef DVD_LAB
   if (const char* e = getenv("DVD_DWCONV_TY")) ty = atoi(e);      // lab: 1 = round 1's row kernel, 2, 4

@@ -102,6 +102,56 @@ def test_dwconv_tile_kernels_equal_v1(ops, lab, monkeypatch, side):
         assert torch.equal(o, out_v1), ty
 
 
+@pytest.mark.parametrize("side", [8, 7, 13, 2, 1, 41])
+def test_dwconv_strip_kernels_equal_v1(ops, lab, monkeypatch, side):
+    """Lab build: the sliding-window strip kernels (round 6: TX columns x SY rows per wave, a 3-row register window, every
+    variant of strip width, band height and streaming stores) against the one-token-per-thread kernel: the taps of an output
+    are summed in the same order with the same FMAs -> bit-identical, incl. sides that leave a narrow last strip, a short last
+    band, one-column / one-row images and bands shorter than the unroll."""
+    n, c = 2, 1024
+    x16 = rnd("dw/x", (n * side * side, c), -1, 2).half().contiguous().cuda()
+    w9c = rnd("dw/w9", (9, c), -0.5, 0.5).cuda()
+    b = rnd("dw/b", (c,), -0.3, 0.3).cuda()
+    monkeypatch.setenv("DVD_DWCONV_V1", "1")
+    out_v1 = ops.dwconv3x3(x16, w9c, b, n, side).cpu()
+    monkeypatch.delenv("DVD_DWCONV_V1")
+    for tx in ("2", "3", "4"):
+        for sy in ("36", "5", "3", "1"):
+            for nt in (False, True):
+                monkeypatch.setenv("DVD_DWCONV_STRIP", tx)
+                monkeypatch.setenv("DVD_DWCONV_SY", sy)
+                monkeypatch.setenv("DVD_DWCONV_NT", "1" if nt else "0")
+                got = ops.dwconv3x3(x16, w9c, b, n, side).cpu()
+                assert torch.equal(got.view(torch.int16), out_v1.view(torch.int16)), (tx, sy, nt)
+
+
+def test_dwconv_product_rule_on_a_large_map(ops):
+    """The PRODUCT library on a map large enough for its sliding-window kernel (n side^2 >= 16384 tokens, c % 512 == 0):
+    against torch's depthwise conv + folded BN + ReLU, on a side (130) that leaves a one-column last strip and a 10-row last
+    band; and on the engine's own shape class (c = 2048)."""
+    for n, side, c in ((1, 130, 512), (2, 96, 2048)):
+        x = rnd("dwl/x", (n, c, side, side), -1, 2)
+        w = rnd("dwl/w", (c, 1, 3, 3), -0.5, 0.5)
+        s, b = rnd("dwl/s", (c,), 0.5, 1.5), rnd("dwl/b", (c,), -0.3, 0.3)
+        ref = F.relu(F.conv2d(x.half().float(), w, None, padding=1, groups=c) * s[None, :, None, None] + b[None, :, None, None])
+        x16 = x.permute(0, 2, 3, 1).reshape(n * side * side, c).half().contiguous()
+        w9c = (w.reshape(c, 9) * s[:, None]).t().contiguous()
+        out = ops.dwconv3x3(x16.cuda(), w9c.cuda(), b.cuda(), n, side).float().cpu()
+        got = out.reshape(n, side, side, c).permute(0, 3, 1, 2)
+        assert (got - ref).abs().max() < 6e-3, (n, side, c)
+
+
+def test_dwconv_product_rule_equals_v1_on_a_large_map(ops, lab, monkeypatch):
+    """... and its bits are the one-token-per-thread kernel's (lab build: the same rule picks the strip kernel there)."""
+    n, side, c = 1, 130, 512
+    x16 = rnd("dwl/x16", (n * side * side, c), -1, 2).half().contiguous().cuda()
+    w9c, b = rnd("dwl/w9", (9, c), -0.5, 0.5).cuda(), rnd("dwl/b2", (c,), -0.3, 0.3).cuda()
+    got = ops.dwconv3x3(x16, w9c, b, n, side).cpu()
+    monkeypatch.setenv("DVD_DWCONV_V1", "1")
+    want = ops.dwconv3x3(x16, w9c, b, n, side).cpu()
+    assert torch.equal(got.view(torch.int16), want.view(torch.int16))
+
+
 def test_adaptive_posenc(ops):
     n, side, c = 2, 4, 1536
     z = rnd("pe/z", (n * side * side, c))
