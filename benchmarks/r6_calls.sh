@@ -16,5 +16,20 @@ timeout 300 python benchmarks/dwconv_bench.py 2>&1 | tail -12 | tee $O/c2_dwconv
 timeout 600 python -m pytest tests/test_gpu_tokens.py -x -q -k dwconv 2>&1 | tail -5 | tee $O/c3_dwconv_pytest.txt
 timeout 600 python benchmarks/dwconv_bench.py 2>&1 | grep -v Warning | tee $O/c3_dwconv_bench.txt
 ;;
+4)   # hd-64 attention with the row sums on the matrix pipe: parity, soak, then A/B at the bench shape
+timeout 900 python -m pytest tests/test_gpu_attention.py tests/test_gpu_tokens.py -x -q -k "h64x or H64X or dwconv" 2>&1 | tail -8 | tee $O/c4_h64l_pytest.txt
+( timeout 600 python benchmarks/attn_ab.py 16 9 64 h64x_r4=DVD_ATTN_H64X_NOLM h64x=
+  for a in 1 3; do echo "== ablation $a (1 no VALU, 3 MFMAs only)"; timeout 300 python benchmarks/attn_ab.py 16 3 64 h64x_r4=DVD_ATTN_H64X_NOLM,DVD_ATTN_H64X_ABL:$a h64x=DVD_ATTN_H64X_ABL:$a; done ) 2>&1 | grep -v Warning | tee $O/c4_h64l_ab.txt
+;;
+5)   # the product library with dwconv strips + h64x row sums on the matrix pipe: attention / tokens / engine suites, a short bench
+timeout 2400 python -m pytest tests/test_gpu_attention.py tests/test_gpu_tokens.py tests/test_gpu_engine.py -x -q 2>&1 | tail -12 | tee $O/c5_pytest.txt
+timeout 900 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-other-configs 2>$O/c5_bench.err | tail -1 > $O/c5_bench.json
+python - <<'PY'
+import json
+d=json.loads(open('gpurun_out/r6/c5_bench.json').read())
+print('bench', d['value'], d['ms_per_step'], 'attn', d['roofline']['achieved'], d['roofline']['frac'])
+print({k:v for k,v in d.items() if k in ('kernel_shares','gemm')})
+PY
+;;
 *) echo "unknown call $1"; exit 2;;
 esac

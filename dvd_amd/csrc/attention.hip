@@ -1717,12 +1717,17 @@ __global__ void __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(H64M_CO
 // waves per SIMD leave 16 registers for the tuples): 32 of 135 VALU instructions per tile gone, 9.11 vs 10.07 ms on one
 // box (profiles/r4_attn_h64x_negm_ab.txt) = 1161 TF/s.
 // ================================================================================================
+// Round 6 (LM = true, gen_attn_h64x.py's second body h64l): the row sums l leave the VALU - V^T gets a fifth dim block of ones,
+// l = ones . P falls out of four more PV MFMAs per tile (a[64:79]) and is the sum of the same f16-rounded P that O^T takes.
+typedef unsigned uintx4 __attribute__((ext_vector_type(4)));
 #include "attn_h64x_body.inc"
+#include "attn_h64l_body.inc"
 #ifdef DVD_LAB
 #include "../../benchmarks/lab/csrc/attn_h64x_abl.inc"
+#include "../../benchmarks/lab/csrc/attn_h64l_abl.inc"
 #endif
 
-template <int DBG>
+template <int DBG, bool LM>
 __global__ void __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(H64X_COMPILER_VGPRS))) flash_attn_h64x_kernel(AttnArgs p) {
   using namespace h64m;                 // LDS geometry: 3 + 3 slots of 4 KiB
   constexpr int D = 64, KB = 32;
@@ -1751,7 +1756,8 @@ __global__ void __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(H64X_CO
     const unsigned rowb = (unsigned)(p.ldq * 2);
     const unsigned q0 = (unsigned)min(qrow, p.tq - 1) * rowb + 16 * g, q1 = (unsigned)min(qrow + 16, p.tq - 1) * rowb + 16 * g;
     const unsigned q2 = (unsigned)min(qrow + 32, p.tq - 1) * rowb + 16 * g, q3 = (unsigned)min(qrow + 48, p.tq - 1) * rowb + 16 * g;
-    h64x_load_q((const _Float16*)uniform_ptr((const char*)Qg), q0, q1, q2, q3, p.c);       // Q * c (fp32 multiply, one f16 rounding)
+    if constexpr (LM) h64l_load_q((const _Float16*)uniform_ptr((const char*)Qg), q0, q1, q2, q3, p.c);
+    else h64x_load_q((const _Float16*)uniform_ptr((const char*)Qg), q0, q1, q2, q3, p.c);  // Q * c (fp32 multiply, one f16 rounding)
   }
   // LDS-DMA sources.  K: this wave's piece = the tile's A-rows 8 w .. 8 w + 7 (row 16 kb2 + i holds the natural key
   // 8 (i >> 2) + 4 kb2 + (i & 3)), 8 chunks each, chunk ^ ((row >> 1) & 7).  V^T: dim rows 16 w .. 16 w + 15, 4 chunks each.
@@ -1768,7 +1774,8 @@ __global__ void __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(H64X_CO
   const unsigned kf1 = lds0 + c16 * 128 + (((4 + g) ^ ((c16 >> 1) & 7)) * 16);
   const unsigned vrel = lds0 + VBASE + c16 * 64 + ((g ^ ((0u - (unsigned)(c16 >> 2)) & 3)) * 16);
 
-  h64x_zero_o();
+  if constexpr (LM) h64l_zero_o();
+  else h64x_zero_o();
   const int nt = p.tk / KB;              // even (tk % 64 == 0)
   const size_t ktile = (size_t)KB * p.ldk * 2;
   const unsigned kdst = lds0 + wave * 1024, vdst = lds0 + VBASE + wave * 1024;
@@ -1780,7 +1787,8 @@ __global__ void __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(H64X_CO
   asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
 
   float a[4];
-  h64x_prologue_s0(kf0, kf1, a[0], a[1], a[2], a[3]);                     // S^T(0) -> buffer A; lane-local maxima
+  if constexpr (LM) h64l_prologue_s0(kf0, kf1, a[0], a[1], a[2], a[3]);
+  else h64x_prologue_s0(kf0, kf1, a[0], a[1], a[2], a[3]);               // S^T(0) -> buffer A; lane-local maxima
   asm volatile("s_barrier" ::: "memory");                                // every wave has read K(0) before K slot 0 is refilled
   float m[4];
 #pragma unroll
@@ -1794,25 +1802,40 @@ __global__ void __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(H64X_CO
   const char* vg = uniform_ptr(Vg + (size_t)min(2, nt - 1) * (KB * 2));
   const int klim = nt - 4, vlim = nt - 3;
   const unsigned kstep = (unsigned)ktile, vstep = KB * 2;
-  h64x_prologue_units(kf0, kf1, m[0], m[1], m[2], m[3]);                 // -m -> v[160:175]; tile 0: scores - m, exp units 0..15
+  if constexpr (LM) h64l_prologue_units(kf0, kf1, m[0], m[1], m[2], m[3]);
+  else h64x_prologue_units(kf0, kf1, m[0], m[1], m[2], m[3]);            // -m -> v[160:175]; tile 0: scores - m, exp units 0..15
   float l[4] = {0.f, 0.f, 0.f, 0.f};
-#define H64X_LOOP_ARGS l[0], l[1], l[2], l[3], kg, vg, nt, kf0, kf1, vrel, koff, voff, kdst, vdst, kstep, vstep, klim, vlim
+#define H64X_TAIL_ARGS kg, vg, nt, kf0, kf1, vrel, koff, voff, kdst, vdst, kstep, vstep, klim, vlim
+  if constexpr (LM) {
+    const uintx4 ones = {0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u};      // the A fragment of the ones block: 16 x 32 f16 1.0
 #ifdef DVD_LAB
-  if constexpr (DBG == 1) h64x_loop_novalu(H64X_LOOP_ARGS);
-  else if constexpr (DBG == 2) h64x_loop_nobar(H64X_LOOP_ARGS);
-  else if constexpr (DBG == 3) h64x_loop_mfmaonly(H64X_LOOP_ARGS);
-  else
+    if constexpr (DBG == 1) h64l_loop_novalu(ones, H64X_TAIL_ARGS);
+    else if constexpr (DBG == 2) h64l_loop_nobar(ones, H64X_TAIL_ARGS);
+    else if constexpr (DBG == 3) h64l_loop_mfmaonly(ones, H64X_TAIL_ARGS);
+    else
 #endif
-    h64x_loop(H64X_LOOP_ARGS);
-#undef H64X_LOOP_ARGS
+      h64l_loop(ones, H64X_TAIL_ARGS);
+    l[0] = h64l_read_l<0>(); l[1] = h64l_read_l<1>(); l[2] = h64l_read_l<2>(); l[3] = h64l_read_l<3>();
+  } else {
+#ifdef DVD_LAB
+    if constexpr (DBG == 1) h64x_loop_novalu(l[0], l[1], l[2], l[3], H64X_TAIL_ARGS);
+    else if constexpr (DBG == 2) h64x_loop_nobar(l[0], l[1], l[2], l[3], H64X_TAIL_ARGS);
+    else if constexpr (DBG == 3) h64x_loop_mfmaonly(l[0], l[1], l[2], l[3], H64X_TAIL_ARGS);
+    else
+#endif
+      h64x_loop(l[0], l[1], l[2], l[3], H64X_TAIL_ARGS);
+  }
+#undef H64X_TAIL_ARGS
 
   const int lane_e = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));     // nothing per-lane kept live across the loop
   const int c16e = lane_e & 15, ge = lane_e >> 4;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     float lt = l[q];
-    lt += __shfl_xor(lt, 16);
-    lt += __shfl_xor(lt, 32);
+    if constexpr (!LM) {               // LM: the l tile already holds the sum over all the keys
+      lt += __shfl_xor(lt, 16);
+      lt += __shfl_xor(lt, 32);
+    }
     const float inv = 1.f / lt;
     const int qglob = qb * 256 + wave * 64 + 16 * q + c16e;
     if (qglob < p.tq) {
@@ -1859,7 +1882,7 @@ extern "C" const char* dvd_flash_attn_kernel_name(int head_dim, int tq, int tk) 
   if (head_dim != 64 && head_dim != 256) return "";
   if (tk % 64 != 0) return head_dim == 256 ? "flash_attn_kernel<256>" : "flash_attn_kernel<64>";
   if (head_dim == 256) return tq >= R64_MIN_TQ ? "flash_attn_r64x_kernel<0>" : "flash_attn_glds_kernel<256, 0>";
-  return tq >= R64_MIN_TQ ? "flash_attn_h64x_kernel<0>" : "flash_attn_glds_kernel<64, 0>";
+  return tq >= R64_MIN_TQ ? "flash_attn_h64x_kernel<0, true>" : "flash_attn_glds_kernel<64, 0>";
 }
 
 template <typename KernelT>
@@ -1901,7 +1924,7 @@ extern "C" int dvd_flash_attn(const dvd_attn_desc* d, void* stream) {
   if (first_on_device) {
     allow_lds(flash_attn_glds_kernel<256, 0>, 2 * (64 * 512 + 256 * 128));
     allow_lds(flash_attn_r64x_kernel<0>, r64p::LDS_BYTES);
-    allow_lds(flash_attn_h64x_kernel<0>, h64m::LDS_BYTES);
+    allow_lds(flash_attn_h64x_kernel<0, true>, h64m::LDS_BYTES);
     allow_lds(flash_attn_kernel<256>, 2 * (64 * (2 * 256 + 16) + 256 * (2 * 64 + 16)));
     attr_done.done(dev_bit);
   }
@@ -2002,14 +2025,24 @@ extern "C" int dvd_flash_attn(const dvd_attn_desc* d, void* stream) {
     }
   } else if (fast) {
     constexpr int LDS = 2 * (64 * 128 + 64 * 128);
-    if (getenv("DVD_ATTN_H64X") || (r64 && getenv("DVD_ATTN_H64X_ABL"))) {   // the production kernel forced at any size; _ABL: ablations
+    if (getenv("DVD_ATTN_H64X") || (r64 && (getenv("DVD_ATTN_H64X_ABL") || getenv("DVD_ATTN_H64X_NOLM")))) {   // the production kernel forced at any size; _ABL: ablations
       p.nqb = cdiv(d->tq, 256);
       const unsigned g = (unsigned)((long)p.nqb * d->heads * d->batch);
-      switch (getenv("DVD_ATTN_H64X_ABL") ? atoi(getenv("DVD_ATTN_H64X_ABL")) : 0) {
-        case 1: flash_attn_h64x_kernel<1><<<g, 256, h64m::LDS_BYTES, st>>>(p); break;
-        case 2: flash_attn_h64x_kernel<2><<<g, 256, h64m::LDS_BYTES, st>>>(p); break;
-        case 3: flash_attn_h64x_kernel<3><<<g, 256, h64m::LDS_BYTES, st>>>(p); break;
-        default: flash_attn_h64x_kernel<0><<<g, 256, h64m::LDS_BYTES, st>>>(p);
+      const int abl = getenv("DVD_ATTN_H64X_ABL") ? atoi(getenv("DVD_ATTN_H64X_ABL")) : 0;
+      if (getenv("DVD_ATTN_H64X_NOLM")) {     // round 4's body: the row sums on the VALU (superseded by the LM body in round 6)
+        switch (abl) {
+          case 1: flash_attn_h64x_kernel<1, false><<<g, 256, h64m::LDS_BYTES, st>>>(p); break;
+          case 2: flash_attn_h64x_kernel<2, false><<<g, 256, h64m::LDS_BYTES, st>>>(p); break;
+          case 3: flash_attn_h64x_kernel<3, false><<<g, 256, h64m::LDS_BYTES, st>>>(p); break;
+          default: flash_attn_h64x_kernel<0, false><<<g, 256, h64m::LDS_BYTES, st>>>(p);
+        }
+        return check_launch("flash_attn(lab h64x, row sums on the VALU)");
+      }
+      switch (abl) {
+        case 1: flash_attn_h64x_kernel<1, true><<<g, 256, h64m::LDS_BYTES, st>>>(p); break;
+        case 2: flash_attn_h64x_kernel<2, true><<<g, 256, h64m::LDS_BYTES, st>>>(p); break;
+        case 3: flash_attn_h64x_kernel<3, true><<<g, 256, h64m::LDS_BYTES, st>>>(p); break;
+        default: flash_attn_h64x_kernel<0, true><<<g, 256, h64m::LDS_BYTES, st>>>(p);
       }
       return check_launch("flash_attn(lab h64x)");
     }
@@ -2044,7 +2077,7 @@ extern "C" int dvd_flash_attn(const dvd_attn_desc* d, void* stream) {
     flash_attn_glds_kernel<256, 0><<<(unsigned)nwg, 256, 2 * (64 * 512 + 256 * 128), st>>>(p);
   } else if (fast && r64) {            // head_dim 64 at production sizes: the generated 16x16x32 loop, 256-row workgroups
     p.nqb = cdiv(d->tq, 256);
-    flash_attn_h64x_kernel<0><<<(unsigned)((long)p.nqb * d->heads * d->batch), 256, h64m::LDS_BYTES, st>>>(p);
+    flash_attn_h64x_kernel<0, true><<<(unsigned)((long)p.nqb * d->heads * d->batch), 256, h64m::LDS_BYTES, st>>>(p);
   } else if (fast) {
     flash_attn_glds_kernel<64, 0><<<(unsigned)nwg, 256, 2 * (64 * 128 + 64 * 128), st>>>(p);
   } else if (d->head_dim == 256) {

@@ -41,6 +41,15 @@ COMPILER_VGPRS = 32
 NEGM0 = 160                       # tuple of query block q at 160 + 4 q: four copies of -m_q (the C operand of a chain's first MFMA)
 
 MF = "v_mfma_f32_16x16x32_f16"
+# LM (round 6): the row sums on the MATRIX pipe.  V^T gets a fifth "dim block" of ones: O^T tile (db = 4, qb) =
+# ones[16 x 32] . P[32 x 16] holds sum_k P[k][q] in every row - the row sum l of the lane's own query, of the SAME f16-rounded P that
+# O^T takes - in a[64 + 4 qb ...]; the constant A fragment is one 4-register operand of the statement (0x3c003c00 x 4) that takes
+# the place of the four l operands.  4 more MFMAs per tile (36 instead of 32), 32 v_add_f32 fewer (of ~100 VALU instructions per
+# tile and wave in a loop whose VALU port is busier than its matrix pipe: 77.6 % vs 60.6 %, profiles/r5_pmc_*); 176 VGPRs + 80 AGPRs
+# = the 256 registers of a wave at two per SIMD.  The rare block scales the l tiles like the O^T tiles; after the loop l is read
+# from a[64 + 4 qb], complete (no cross-lane reduction).  Generated as a second body (prefix h64l) beside the round-4 one.
+LM = False
+PFX = "h64x"
 ABL = set()        # timing ablations (lab builds only; garbage results): "valu", "dma", "read", "wait", "bar"
 
 
@@ -66,6 +75,10 @@ def qreg(qb, ks):
 
 def pfrag(qb):
     return vr(P0 + 4 * qb, 4)
+
+
+def lreg(qb):
+    return f"a[{64 + 4 * qb}:{64 + 4 * qb + 3}]"
 
 
 class Stmt:
@@ -205,9 +218,10 @@ def tile(s, var):
     # ---------------- phase 1 (steps 0..3): S^T(t+1); exp units 16..31 of tile t, the 16 packs of P(t) and their row sums
     seq = []
     for j in range(8):
-        seq += [exp_unit(cur, 16 + 2 * j), exp_unit(cur, 17 + 2 * j), cvt_word(cur, j)] + sum_word(j, cur).split("\\n\\t")
+        seq += [exp_unit(cur, 16 + 2 * j), exp_unit(cur, 17 + 2 * j), cvt_word(cur, j)]
+        seq += [] if LM else sum_word(j, cur).split("\\n\\t")
     for j in range(8, 16):
-        seq += [cvt_word(cur, j)] + sum_word(j, cur).split("\\n\\t")
+        seq += [cvt_word(cur, j)] + ([] if LM else sum_word(j, cur).split("\\n\\t"))
     gaps = spread(seq, 16)
     for f in range(4):
         n, ks, kb2 = f, f >> 1, f & 1
@@ -236,7 +250,7 @@ def tile(s, var):
     for kind, i in order:
         if kind == "e":
             seq.append(exp_unit(nxt, i))
-    gaps = spread(seq, 16)
+    gaps = spread(seq, 20 if LM else 16)
     for g in range(4):
         n = 4 + g
         ring_wait(s, n)
@@ -253,6 +267,10 @@ def tile(s, var):
             if qb == 3 and g == 2:
                 s.add(f"s_add_i32 s{S_TC}, s{S_TC}, 1")
             emit_gap(s, gaps[4 * g + qb])
+    if LM:                                                    # the row sums: O^T's fifth dim block, A = ones (no fragment read)
+        for qb in range(4):
+            s.add(f"{MF} {lreg(qb)}, %[ones], {pfrag(qb)}, {lreg(qb)}")
+            emit_gap(s, gaps[16 + qb])
 
 
 def rare_block(s, par):
@@ -279,12 +297,13 @@ def rare_block(s, par):
             s.add(f"v_sub_f32_e32 v{NEGM0 + 4 * q + i}, v{NEGM0 + 4 * q + i}, {t0}")
         for i in range(8):
             s.add(f"v_sub_f32_e32 v{SBUF[nxt] + 8 * q + i}, v{SBUF[nxt] + 8 * q + i}, {t0}")
-        s.add(f"v_mul_f32_e32 %[l{q}], %[l{q}], {t1}")
+        if not LM:
+            s.add(f"v_mul_f32_e32 %[l{q}], %[l{q}], {t1}")
         s.add(f"v_cvt_pk_f16_f32 {t0}, {t1}, {t1}")
         for j in range(4):
             s.add(f"v_pk_mul_f16 v{P0 + 4 * q + j}, v{P0 + 4 * q + j}, {t0}")
         tmp = ("%[t0]", "%[t2]", "%[t3]", "%[t4]")        # t1 = alpha; t0 (the packed alpha) is free again after the P words
-        for a0 in range(16 * q, 16 * q + 16, 4):
+        for a0 in list(range(16 * q, 16 * q + 16, 4)) + ([64 + 4 * q] if LM else []):     # LM: the l tile is O^T's fifth dim block
             for i in range(4):
                 s.add(f"v_accvgpr_read_b32 {tmp[i]}, a{a0 + i}")
             for i in range(4):
@@ -366,34 +385,45 @@ VARIANTS = [("", ()), ("novalu", ("valu",)), ("nobar", ("bar",)), ("mfmaonly", (
 
 def emit_loop(w, sfx):
     w(f"// ---- the key-tile loop{sfx}: six tile variants, the rare rescale block, the drain")
-    w(f"__device__ __forceinline__ void h64x_loop{sfx}(float& l0, float& l1, float& l2, float& l3, const char* kg, const char* vg, int nt,")
+    if LM:
+        w(f"__device__ __forceinline__ void {PFX}_loop{sfx}(uintx4 ones, const char* kg, const char* vg, int nt,")
+    else:
+        w(f"__device__ __forceinline__ void {PFX}_loop{sfx}(float& l0, float& l1, float& l2, float& l3, const char* kg, const char* vg, int nt,")
     w("    unsigned kf0, unsigned kf1, unsigned vrel, unsigned koff, unsigned voff, unsigned kdst, unsigned vdst,")
     w("    unsigned kstep, unsigned vstep, int klim, int vlim) {")
     w("  float a0, a1, a2, a3, t0, t1, t2, t3, t4;")
     w("  asm volatile(")
     w(loop_stmt().text())
-    w('      : [l0] "+v"(l0), [l1] "+v"(l1), [l2] "+v"(l2), [l3] "+v"(l3), [a0] "=&v"(a0), [a1] "=&v"(a1), [a2] "=&v"(a2), [a3] "=&v"(a3),')
+    ls = "" if LM else '[l0] "+v"(l0), [l1] "+v"(l1), [l2] "+v"(l2), [l3] "+v"(l3), '
+    w(f'      : {ls}[a0] "=&v"(a0), [a1] "=&v"(a1), [a2] "=&v"(a2), [a3] "=&v"(a3),')
     w('        [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3), [t4] "=&v"(t4)')
     w('      : [kg] "s"(kg), [vg] "s"(vg), [nt] "s"(nt), [kf0] "v"(kf0), [kf1] "v"(kf1), [vrel] "v"(vrel), [koff] "v"(koff), [voff] "v"(voff),')
-    w('        [kdst] "s"(kdst), [vdst] "s"(vdst), [kstep] "s"(kstep), [vstep] "s"(vstep), [klim] "s"(klim), [vlim] "s"(vlim)')
+    w('        [kdst] "s"(kdst), [vdst] "s"(vdst), [kstep] "s"(kstep), [vstep] "s"(vstep), [klim] "s"(klim), [vlim] "s"(vlim)'
+      + (', [ones] "v"(ones)' if LM else ""))
     w('      : "memory", "scc", "vcc", ' + ", ".join(f'"{r}"' for r in SGPR_CLOBBERS) + ");")
     w("}")
     w("")
 
 
-def emit():
+def emit(lm=False):
+    global LM, PFX
+    LM, PFX = lm, ("h64l" if lm else "h64x")
+    nacc = 80 if LM else 64
+    U = PFX.upper()
     out, lab = [], []
-    lab.append("// GENERATED by dvd_amd/csrc/gen_attn_h64x.py --lab - do not edit.  TIMING ABLATIONS of the h64x loop (lab builds only:")
+    lab.append(f"// GENERATED by dvd_amd/csrc/gen_attn_h64x.py --lab - do not edit.  TIMING ABLATIONS of the {PFX} loop (lab builds only:")
     lab.append("// they compute garbage).")
     lab.append("// clang-format off")
     w = out.append
     w("// GENERATED by gen_attn_h64x.py - do not edit; see that file for the fragment maps, the register plan and the schedule.")
+    if LM:
+        w("// This is the LM body: the row sums l on the matrix pipe (O^T's fifth dim block, A = ones), a[64:79].")
     w("// clang-format off")
-    w(f"#define H64X_COMPILER_VGPRS {COMPILER_VGPRS}   // the kernel carries __attribute__((amdgpu_num_vgpr(H64X_COMPILER_VGPRS)))")
+    w(f"#define {U}_COMPILER_VGPRS {COMPILER_VGPRS}   // the kernel carries __attribute__((amdgpu_num_vgpr({U}_COMPILER_VGPRS)))")
     w("")
     w("// Q: 4 query blocks x 2 slabs of 32 dims; lane (c, g) holds query 16 qb + c, dims 32 ks + 8 g .. + 7; scaled by c in fp32")
     w("// (one wave-uniform base + a 32-bit byte offset per query block)")
-    w("__device__ __forceinline__ void h64x_load_q(const _Float16* base, unsigned q0, unsigned q1, unsigned q2, unsigned q3, float c) {")
+    w(f"__device__ __forceinline__ void {PFX}_load_q(const _Float16* base, unsigned q0, unsigned q1, unsigned q2, unsigned q3, float c) {{")
     w("  float t0, t1;")
     w("  asm volatile(")
     for qb in range(4):
@@ -406,17 +436,26 @@ def emit():
     w('      "s_nop 0"')
     w('      : [t0] "=&v"(t0), [t1] "=&v"(t1)')
     w('      : [base] "s"(base), [q0] "v"(q0), [q1] "v"(q1), [q2] "v"(q2), [q3] "v"(q3), [c] "s"(c)')
-    w('      : "memory", "v175", "a63");   // the clobbers: 176 VGPRs + 64 AGPRs per wave')
+    w(f'      : "memory", "v175", "a{nacc - 1}");   // the clobbers: 176 VGPRs + {nacc} AGPRs per wave')
     w("}")
     w("")
-    w("__device__ __forceinline__ void h64x_zero_o() {")
+    w(f"__device__ __forceinline__ void {PFX}_zero_o() {{")
     w("  asm volatile(")
-    for i in range(64):
+    for i in range(nacc):
         w(f'      "v_accvgpr_write_b32 a{i}, 0\\n\\t"')
     w('      "s_nop 1" ::: "memory");')
     w("}")
     w("")
-    w("__device__ __forceinline__ void h64x_prologue_s0(unsigned kf0, unsigned kf1, float& a0, float& a1, float& a2, float& a3) {")
+    if LM:
+        w("// the row sum of query block QB after the loop: any register of its l tile (all 16 rows of the tile are equal)")
+        w("template <int QB> __device__ __forceinline__ float h64l_read_l() {")
+        w("  float x;")
+        for q in range(4):
+            w(f'  {"if" if q == 0 else "else if"} constexpr (QB == {q}) asm volatile("v_accvgpr_read_b32 %0, a{64 + 4 * q}" : "=v"(x) : : "memory");')
+        w("  return x;")
+        w("}")
+        w("")
+    w(f"__device__ __forceinline__ void {PFX}_prologue_s0(unsigned kf0, unsigned kf1, float& a0, float& a1, float& a2, float& a3) {{")
     w("  asm volatile(")
     w(prologue_s0().text())
     w('      : [a0] "=&v"(a0), [a1] "=&v"(a1), [a2] "=&v"(a2), [a3] "=&v"(a3)')
@@ -424,7 +463,7 @@ def emit():
     w('      : "memory");')
     w("}")
     w("")
-    w("__device__ __forceinline__ void h64x_prologue_units(unsigned kf0, unsigned kf1, float m0, float m1, float m2, float m3) {")
+    w(f"__device__ __forceinline__ void {PFX}_prologue_units(unsigned kf0, unsigned kf1, float m0, float m1, float m2, float m3) {{")
     w("  asm volatile(")
     w(prologue_units().text())
     w('      :')
@@ -444,12 +483,17 @@ def emit():
 
 if __name__ == "__main__":
     here = os.path.dirname(os.path.abspath(__file__))
-    prod, lab = emit()
-    ppath = os.path.join(here, "attn_h64x_body.inc")
-    lpath = os.path.normpath(os.path.join(here, "..", "..", "benchmarks", "lab", "csrc", "attn_h64x_abl.inc"))
+    labdir = os.path.normpath(os.path.join(here, "..", "..", "benchmarks", "lab", "csrc"))
     arg = sys.argv[1] if len(sys.argv) > 1 else ""
+    ok = True
+    for lm, stem in ((False, "attn_h64x"), (True, "attn_h64l")):
+        prod, lab = emit(lm)
+        ppath, lpath = os.path.join(here, stem + "_body.inc"), os.path.join(labdir, stem + "_abl.inc")
+        if arg == "--check":
+            ok = ok and os.path.exists(ppath) and open(ppath).read() == prod
+            continue
+        path, text = (lpath, lab) if arg == "--lab" else (ppath, prod)
+        open(path, "w").write(text)
+        print(f"wrote {path}: {text.count(chr(10))} lines")
     if arg == "--check":
-        sys.exit(0 if os.path.exists(ppath) and open(ppath).read() == prod else 1)
-    path, text = (lpath, lab) if arg == "--lab" else (ppath, prod)
-    open(path, "w").write(text)
-    print(f"wrote {path}: {text.count(chr(10))} lines")
+        sys.exit(0 if ok else 1)

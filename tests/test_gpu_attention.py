@@ -80,7 +80,8 @@ VARIANTS = {
     "head-dim split, two waves per SIMD (experiment)": {"DVD_ATTN_DSPLIT": "1"},
     "hd64 two row blocks per wave (experiment)": {"DVD_ATTN_64X2": "1"},
     "h64m (head_dim 64 on the decoder kernel's recipe: generated loop, two waves per SIMD)": {"DVD_ATTN_H64M": "1"},
-    "h64x (head_dim 64, generated loop on the 16x16x32 MFMA; the default at production sizes)": {"DVD_ATTN_H64X": "1"},
+    "h64x (head_dim 64, generated loop on the 16x16x32 MFMA, row sums on the matrix pipe; the default at production sizes)": {"DVD_ATTN_H64X": "1"},
+    "h64x of round 4 (the row sums on the VALU; superseded)": {"DVD_ATTN_H64X": "1", "DVD_ATTN_H64X_NOLM": "1"},
 }
 
 
@@ -108,11 +109,14 @@ def test_generated_loops_at_every_exit(ops, lab, monkeypatch, switch, tk):
     assert err < 2e-3 * max(1.0, mag), (switch, tk, err, mag)
 
 
-@pytest.mark.parametrize("switch,hd", [("DVD_ATTN_R64", 256), ("DVD_ATTN_R64M", 256), ("DVD_ATTN_H64M", 64), ("DVD_ATTN_H64X", 64)])
+@pytest.mark.parametrize("switch,hd", [("DVD_ATTN_R64", 256), ("DVD_ATTN_R64M", 256), ("DVD_ATTN_H64M", 64), ("DVD_ATTN_H64X", 64),
+                                       ("DVD_ATTN_H64X_NOLM", 64)])
 def test_generated_loops_soak(ops, lab, monkeypatch, switch, hd):
     """40 seeded cases per generated kernel: up to three dominant keys at random positions (the deferred rescale in every tile
     variant, in first and last tiles, on either row / query block), ragged query counts, 1..13 key-tile pairs, shared K/V."""
     monkeypatch.setenv(switch, "1")
+    if switch == "DVD_ATTN_H64X_NOLM":
+        monkeypatch.setenv("DVD_ATTN_H64X", "1")       # round 4's body of the h64x kernel, forced at any size
     heads = 2
     C = heads * hd
     gen = torch.Generator(device="cpu").manual_seed(1234)

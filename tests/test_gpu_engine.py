@@ -249,6 +249,15 @@ def test_long_loop_vs_oracle_trace(name):
                 assert per[last] < 1e-3, (label, per[last])                            # ... and on the un-clamped last x0
             # relative to the map's std: 5-8e-5 at the end of a roll-out on BOTH families; a single evaluation on dithered
             # weights carries the whole f16 weight rounding (4-6e-4 at the first step), which averages out over the steps
+            if family == "peaked":
+                # round 6: decoder logits x 12 (std ~ 10, a row's largest probability ~ 0.5).  A softmax turns an ABSOLUTE logit
+                # error into a RELATIVE probability error (dP / P = d logit), and the f16 rounding of Q and K costs ~2^-11 of a
+                # logit of magnitude 10-30: one evaluation measured 4.7e-3 of the map's std (the tame family: 4-6e-4), the end of
+                # the roll-out 5.1e-4 (tame: 5-8e-5) - the price of f16 operands under peaked attention, 6.7x inside north_star's
+                # 1e-3 on the returned map (1.5e-4).  The bars are 3x the measured values.
+                assert rel[last] < 1.5e-3 and max(rel.values()) < 1.5e-2, (label, rel)
+                assert float(z["last_x0_saturated"]) < 0.01 and per[last] < 4.5e-4, (label, per[last])
+                continue
             assert rel[last] < 3e-4 and max(rel.values()) < 1.2e-3, (label, rel)
             if family == "tame":
                 assert float(z["last_x0_saturated"]) < 0.01
