@@ -116,7 +116,8 @@ def launch_ranks(n, argv, deadline_s=None, attempts=3):
     touched the GPU and never will: nothing is re-exec'd, the ranks are children.
     A rank that dies takes the others down after a grace period (terminate, then kill: a rank stuck in a GPU collective may
     ignore SIGTERM); an overall deadline does the same for a rank that hangs without dying; the free-port probe is racy by
-    nature (the socket is closed before rank 0 binds it), so a run whose ranks ALL fail within seconds is retried on a new port."""
+    nature (the socket is closed before rank 0 binds it): when rank 0 ALONE is down within seconds of the start the others
+    are taken down after a short grace and the run is retried on a new port; any other failure is reported as it is."""
     import socket
     import subprocess
     deadline_s = LAUNCH_DEADLINE_S if deadline_s is None else deadline_s
@@ -132,12 +133,16 @@ def launch_ranks(n, argv, deadline_s=None, attempts=3):
                        MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get(
                            "HSA_ENABLE_IPC_MODE_LEGACY", "0"))
             procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env))
-        t_start, failed_at, term_at = time.monotonic(), None, None
+        t_start, failed_at, term_at, rank0_first = time.monotonic(), None, None, False
         while any(p.poll() is None for p in procs):
             now = time.monotonic()
             if failed_at is None and (any(p.poll() not in (None, 0) for p in procs) or now - t_start > deadline_s):
                 failed_at = now                              # a rank died (the others would wait in a collective for ever) or hangs
-            if failed_at is not None and term_at is None and (now - failed_at > 20.0 or now - t_start > deadline_s):
+                # the port race: rank 0 alone dies at once (EADDRINUSE on MASTER_PORT) while the others sit in the store's
+                # connect - seen as "rank 0 is down within seconds of the start and some other rank is still up"
+                rank0_first = procs[0].poll() not in (None, 0) and now - t_start < 10.0 and any(p.poll() is None for p in procs[1:])
+            grace = 2.0 if rank0_first else 20.0
+            if failed_at is not None and term_at is None and (now - failed_at > grace or now - t_start > deadline_s):
                 term_at = now
                 for p in procs:
                     if p.poll() is None:
@@ -151,8 +156,10 @@ def launch_ranks(n, argv, deadline_s=None, attempts=3):
         codes = [128 - rc if rc < 0 else rc for rc in codes]
         worst = next((rc for rc in codes if rc != 0), 0)
         hung = time.monotonic() - t_start > deadline_s
-        if worst == 0 or hung or time.monotonic() - t_start > 15.0 or not all(codes):
-            return 124 if hung and worst == 0 else worst     # only an instant failure of EVERY rank (the port) is retried
+        # retried: ONLY the rendezvous race (rank 0 gone at once, the others had to be taken down).  Ranks that all exit by
+        # themselves with an error (a bad argument, an import error) would fail the same way again: reported, not repeated.
+        if worst == 0 or hung or not rank0_first:
+            return 124 if hung and worst == 0 else worst
     return worst
 
 
@@ -183,6 +190,16 @@ def max_over_ranks(elapsed, world, dev):
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def per_rank_seconds(elapsed, world, dev):
+    """Every rank's own wall time of the timed region (one all_gather AFTER it: report only)."""
+    if world == 1:
+        return [elapsed]
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    out = [torch.zeros_like(t) for _ in range(world)]
+    dist.all_gather(out, t)
+    return [float(x.item()) for x in out]
 
 
 def main(argv=None):
@@ -284,7 +301,9 @@ def main(argv=None):
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
-    elapsed = max_over_ranks(time.perf_counter() - t0, world, dev)
+    elapsed_local = time.perf_counter() - t0
+    elapsed = max_over_ranks(elapsed_local, world, dev)
+    rank_seconds = per_rank_seconds(elapsed_local, world, dev)
     launches, attn_ms = eng.profile_read()
     eng.profile(False)
     assert bool(torch.isfinite(flow).all()), "non-finite coordinates"
@@ -438,6 +457,12 @@ def main(argv=None):
                        "parallelism": f"dp{world} (documents sharded, one weight broadcast)"},
             "algorithmic_tflops": round(flops_total / elapsed / 1e12, 1),
             "weight_broadcast_ms": None if bcast_ms is None else round(bcast_ms, 2),
+            "weight_broadcast_bytes": int(blob_bytes),
+            # each rank's own clock over the timed region (the line's value uses the MAX): a scaling run explains itself
+            "per_rank": [{"rank": r, "seconds": round(t, 4), "documents_per_s": round(B * args.steps / t, 5)}
+                         for r, t in enumerate(rank_seconds)],
+            "collectives": {"data_path": 0, "setup": ["all_gather_object (ranks_seen)", "barrier", "broadcast (weights, once)"],
+                            "timing": ["barrier", "barrier", "all_reduce MAX (elapsed)", "all_gather (per-rank seconds)", "barrier"]},
             "ranks_seen": seen,
             "roofline": roof, "roofline_unwarp": roof_unwarp, "cpu_baseline": cpu,
             "other_configs": others,
@@ -448,10 +473,24 @@ def main(argv=None):
         dist.destroy_process_group()
 
 
-def other_configs(dev, blob288, H, FH, FW, want_cpu=True, legs=("cfg4", "cfg3", "native")):
+def _aten_order_matches_host():
+    """oracle/aten_order.py (numpy restatement of the arithmetic order the HIP warps implement) against torch's CPU kernels
+    on THIS host, bit for bit, on a small tail (what tests/test_oracle_golden.py::test_aten_order_restatement pins)."""
+    from oracle import aten_order as A
+    from oracle import dvd_oracle as O
+    rng = np.random.RandomState(16)
+    flow = (rng.randn(1, 2, 16, 16) * 0.06).astype(np.float32)
+    src = (rng.rand(1, 3, 97, 131) * 255).astype(np.float32)
+    grid, out, u8 = O.unwarp_tail(torch.from_numpy(flow), torch.from_numpy(src))
+    grid2, out2, u82 = A.unwarp_tail(flow, src)
+    return bool(np.array_equal(grid.numpy(), grid2) and np.array_equal(out.numpy(), out2) and np.array_equal(u8, u82))
+
+
+def other_configs(dev, blob288, H, FH, FW, want_cpu=True, legs=("cfg4", "ns32", "cfg3", "native")):
     """Bounded legs for the BASELINE.json configurations the headline is NOT quoted on, each with its own time, value and
     parity figure (the headline fields of the line are untouched):
       configs[4]  16 documents, 50-step DDIM, G = 288, + 3508x2480 unwarp: ONE whole batch;
+      ns32        north_star's stated target point: 32 documents, 50-step DDIM, G = 288, + unwarp: ONE whole batch (round 6);
       configs[3]  250-step DDPM ancestral sampling at G = 288 at its STATED 32 documents (x H hypotheses = 64 samples, one
                   engine batch, ~5.5 minutes; round 5) - unless the process has already run longer than CFG3_FULL_DEADLINE_S,
                   in which case 4 documents are run and the leg says so (the loop is strictly per-document work, so
@@ -503,11 +542,49 @@ def other_configs(dev, blob288, H, FH, FW, want_cpu=True, legs=("cfg4", "cfg3", 
             d = np.abs(got8 - ref8.astype(np.int32))
             par = {"what": "document 0: fused u8 unwarp (3508x2480) vs the CPU oracle's upsample + grid_sample + uint8 on the "
                            "same flow", "pixels_equal": float((d == 0).mean()), "max_abs_u8": int(d.max()),
-                   "ok": bool((d == 0).all())}       # round 5: the tail follows ATen's arithmetic order - the same bytes
+                   "ok": bool((d == 0).all()),       # round 5: the tail follows ATen's arithmetic order - the same bytes
+                   # byte equality holds while THIS host's torch contracts its CPU kernels into the FMA order the
+                   # kernels restate (oracle/aten_order.py); on another torch build / CPU ISA the strict flag could go false
+                   # with max_abs_u8 == 1 and nothing changed on the GPU - so the old tolerance and the host check ride along
+                   "ok_within_1": bool(d.max() <= 1), "aten_order_matches_host_torch": _aten_order_matches_host()}
         out["configs[4]"] = {"workload": f"BASELINE configs[4]: batch={B} documents x {H} hypotheses, 50-step DDIM, 288x288 grid, "
                                          f"+ {FH}x{FW} u8 unwarp", "batches_timed": 1, "ms_per_batch": round(dt * 1e3, 1),
                              "value": round(B / dt, 5), "unit": "documents/s", "parity": par}
         del eng, cond, x_T, src_u8, outs, flow
+        torch.cuda.empty_cache()
+
+    if "ns32" in legs:
+        # ---- north_star's stated target point: 50-step DDIM, 288x288 grid, batch = 32 (+ the full-resolution unwarp) ------------
+        # (VERDICT r5 missing 7: configs[1] (8) and configs[4] (16) bracket it from below only.)  Parity of the leg's own product:
+        # document 0 of the batch must have the bits it has when sampled ALONE (one engine of one document, same x_T) - the
+        # kernel choice is a function of the shape, never of the batch, so a 32-document batch changes no document.
+        B = 32
+        eng = Engine(G, B, H, device=dev)
+        eng.bind_blob(blob288)
+        cond = docs(B, G)
+        x_T = torch.randn(B * H, 2, G, G, device=dev, generator=gen)
+        src_u8 = torch.randint(0, 256, (B, FH, FW, 3), device=dev, dtype=torch.uint8, generator=gen)
+        tab = schedule.Tables(schedule.named_betas("cosine", 50))
+
+        def ns32():
+            eng.prepare(*cond)
+            flow = sampler.sample(eng, tab, x_T)
+            return flow, ops.unwarp_u8_batch(flow, src_u8)
+        dt, (flow, outs) = timed(ns32)
+        del eng
+        torch.cuda.empty_cache()
+        eng1 = Engine(G, 1, H, device=dev)
+        eng1.bind_blob(blob288)
+        eng1.prepare(*[c[:1].contiguous() for c in cond])
+        flow1 = sampler.sample(eng1, tab, x_T[:H].contiguous())
+        same = bool(torch.equal(flow1[0], flow[0]))
+        out["north_star_batch32"] = {"workload": f"north_star target point: batch={B} documents x {H} hypotheses, 50-step DDIM, 288x288 "
+                                                 f"grid, + {FH}x{FW} u8 unwarp, 1 GPU", "batches_timed": 1,
+                                     "ms_per_batch": round(dt * 1e3, 1), "value": round(B / dt, 5), "unit": "documents/s",
+                                     "finite": bool(torch.isfinite(flow).all()),
+                                     "parity": {"what": "document 0 of the 32-document batch == the same document sampled alone "
+                                                        "(coordinate map, bit for bit)", "ok": same}}
+        del eng1, cond, x_T, src_u8, outs, flow, flow1
         torch.cuda.empty_cache()
 
     if "cfg3" in legs:
@@ -596,7 +673,8 @@ def other_configs(dev, blob288, H, FH, FW, want_cpu=True, legs=("cfg4", "cfg3", 
         par = {"what": "coordinate map of the 3-step loop (conditioning = the GPU pre-stage's own output) vs the CPU oracle",
                "coord_rmse": rm, "bar": 1e-3, "ok": bool(rm < 1e-3), "cpu_oracle_seconds_sampling_only": round(cpu_s, 2)}
     out["native_point"] = {"workload": f"reference-native: 1 document at a time, G=64, 3-step DDIM, {H} hypotheses, from a "
-                                       "decoded 1024x768 image: ingest + U2NETP x2 + line UNet + sampling + u8 unwarp",
+                                       "decoded 1024x768 image: ingest (parity with a real cv2.resize UNPINNED: no OpenCV offline) + U2NETP x2 + "
+                                       "line UNet + sampling + u8 unwarp",
                            "documents_timed": len(lat), "ms_per_document_median": round(statistics.median(lat), 3),
                            "value": round(1e3 / statistics.median(lat), 2), "unit": "documents/s", "parity": par}
     # ---- the same operating point BATCHED (admin/local.py's per-document settings, `batch_docs` documents per engine
@@ -605,7 +683,7 @@ def other_configs(dev, blob288, H, FH, FW, want_cpu=True, legs=("cfg4", "cfg3", 
     # it gives alone (no cross-document arithmetic), and document 0 is compared with the CPU oracle like the single leg.
     single_flow, single_img = flow.clone(), img_u8
     del eng
-    for Bn in (8, 32):
+    for Bn in (32,):          # (round 6: the 8-document leg made room for north_star_batch32)
         imgs = [torch.roll(img_u8, shifts=(17 * d, 29 * d), dims=(0, 1)).contiguous() for d in range(Bn)]
         engb = Engine(Gn, Bn, H, device=dev)
         engb.load_state_dict(sd)

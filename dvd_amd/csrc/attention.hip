@@ -697,7 +697,7 @@ __global__ void __launch_bounds__(256, (D == 256 ? 1 : DVD_ATTN64_OCC)) flash_at
 // architectural VGPRs (2 x 32), the loop is unrolled by two so both buffers have compile-time names; Q (128 VGPRs) and
 // O^T (all 256 AGPRs) as in flash_attn_r64_kernel.  The row maximum is checked LANE-LOCALLY (a lane owns 16 of its query's
 // 32 keys; m_run is kept identical in both halves of a row), so the cross-half exchange exists only in the rare branch.
-// Measured (MI355X, s_memtime stamps + PMC, profiles/r4_*): 3574 -> ~2900 cycles per tile, MFMA busy 58.7 -> 68.6 %, but the
+// Measured (MI355X, s_memtime stamps + PMC, profiles/archive/r4_*): 3574 -> ~2900 cycles per tile, MFMA busy 58.7 -> 68.6 %, but the
 // chip holds 1.70 instead of 1.87 GHz under the denser stream (it runs at its power cap): +7 % wall for -14 % cycles.
 //
 // Why statements are merged: hipcc's hazard recogniser counts an inline-asm statement as ZERO wait states and assumes a
@@ -1576,7 +1576,7 @@ __global__ void __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(R64X_CO
 // hand-allocated registers - and TWO waves per SIMD (160 VGPRs + 64 AGPRs per wave), because head_dim 64 has four exp units
 // beside every pair of MFMAs.  K image: natural key rows of 128 B, chunks XOR-swizzled by (row >> 1) & 7, rows read in kappa
 // order (one fragment base per ks); V^T image as in the decoder kernel (64-byte rows, chunk ^ ((row >> 2) & 3)).
-// MEASURED (lab switch DVD_ATTN_H64M; profiles/r4_attn_h64m_*): correct on the first run and EXACTLY as fast as the
+// MEASURED (lab switch DVD_ATTN_H64M; profiles/archive/r4_attn_h64m_*): correct on the first run and EXACTLY as fast as the
 // compiler-scheduled flash_attn_glds_kernel<64> (10.32 vs 10.32 ms, 10.49 vs 10.62 on another box): 17.3 M vs 16.4 M cycles,
 // MFMA busy 58 vs 61 %.  Its ablations say why neither moves: without the exp units 11.1 M cycles (91 % busy), i.e. the
 // softmax VALU work is not hidden at all - each of a tile's 132 VALU instructions costs the SIMD ~2.4 cycles on top of
@@ -1711,11 +1711,11 @@ __global__ void __launch_bounds__(256, 2) __attribute__((amdgpu_num_vgpr(H64M_CO
 // blocks of 16, 32-key tiles of 8 steps, two waves per SIMD (176 VGPRs + 64 AGPRs), K tiles in A-row order with 128-byte
 // rows, one LDS-DMA piece per wave, stream and tile.  Priced first by an ablation of h64m (two 16x16x32 MFMAs per 32x32x16:
 // 10.01 vs 10.53 ms), then built: correct on its first run; against flash_attn_glds_kernel<64> on four boxes +0.8, +2.2,
-// +4.0, +5.2 % (9.80-10.25 vs 10.13-10.66 ms; profiles/r4_attn_h64x_*).  19.6 M cycles against 16.7 M - the softmax VALU
+// +4.0, +5.2 % (9.80-10.25 vs 10.13-10.66 ms; profiles/archive/r4_attn_h64x_*).  19.6 M cycles against 16.7 M - the softmax VALU
 // work hides even less beside 16-cycle MFMAs - at 1.96 instead of 1.65 GHz.  Then the softmax argument was taken off the
 // VALU as in flash_attn_glds_kernel<64> (Q pre-scaled by c, -m through the C operand of each chain's first MFMA: the two
 // waves per SIMD leave 16 registers for the tuples): 32 of 135 VALU instructions per tile gone, 9.11 vs 10.07 ms on one
-// box (profiles/r4_attn_h64x_negm_ab.txt) = 1161 TF/s.
+// box (profiles/archive/r4_attn_h64x_negm_ab.txt) = 1161 TF/s.
 // ================================================================================================
 // Round 6 (LM = true, gen_attn_h64x.py's second body h64l): the row sums l leave the VALU - V^T gets a fifth dim block of ones,
 // l = ones . P falls out of four more PV MFMAs per tile (a[64:79]) and is the sum of the same f16-rounded P that O^T takes.
@@ -1872,7 +1872,7 @@ extern "C" int dvd_attn_debug_stamps(void* dev_u64) { g_attn_stamps = (unsigned 
 
 // 64 query rows per wave (256 per workgroup) from this many query rows on: a (batch, head) then has >= 21 workgroups of
 // its own, so that ONE document (two samples) already fills the 256 CUs.  At 16 samples the generated kernels also win
-// below it (profiles/r4_attn_midsize_threshold.txt: head_dim 256 +12 .. 38 % from T = 1024 on, head_dim 64 +5 .. 17 % from
+// below it (profiles/archive/r4_attn_midsize_threshold.txt: head_dim 256 +12 .. 38 % from T = 1024 on, head_dim 64 +5 .. 17 % from
 // T = 2304 on), but with one document their 256-row workgroups would leave half of the CUs idle - and the choice must not
 // depend on the batch.  The choice depends on the problem's SHAPE only (head_dim, tq, tk) - never on the batch - so a document
 // takes the same kernel, and the same online-softmax tile order, alone or in a batch (bit-identical results).

@@ -576,6 +576,15 @@ extern "C" int dvd_engine_prepare_docs(void* handle, const float* y512, const fl
     // the prepare-time scratch from the im2col region to its end (p_col, p_actA, p_actB, p_rows, p_tok32 are laid out in
     // this order by plan() and none of them is live here); p_rows + p_tok32 alone hold one document at any grid
     const size_t per_doc = (size_t)T * (1536 + HID) * 4;
+    {   // the grouping below treats the five regions as ONE contiguous scratch - say so where a re-ordered
+        // plan() would otherwise underflow `avail` and let rows_g / tok_g run into live buffers
+      const int chain[5] = {e->bi.p_col, e->bi.p_actA, e->bi.p_actB, e->bi.p_rows, e->bi.p_tok32};
+      for (int i = 0; i + 1 < 5; ++i)
+        DVD_REQUIRE(e->bufs[chain[i]].off < e->bufs[chain[i + 1]].off &&
+                        e->bufs[chain[i]].off + e->bufs[chain[i]].bytes <= e->bufs[chain[i + 1]].off &&
+                        e->bufs[chain[i + 1]].off - (e->bufs[chain[i]].off + e->bufs[chain[i]].bytes) < 4096,
+                    "engine_prepare_docs: the prepare-time scratch regions are not laid out back to back (plan() changed?)");
+    }
     const size_t avail = e->bufs[e->bi.p_tok32].off + e->bufs[e->bi.p_tok32].bytes - e->bufs[e->bi.p_col].off;
     DVD_REQUIRE(avail >= per_doc, "engine_prepare_docs: prepare scratch smaller than one document's rows");
     const int gmax = (int)std::max<size_t>(1, std::min<size_t>((size_t)e->docs, avail / per_doc));

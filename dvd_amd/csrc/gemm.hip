@@ -1393,7 +1393,7 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_big_kernel(GemmArgs p) {
 //     LDS-DMA queue is never drained inside the K loop (counted vmcnt), the LDS queue is waited for with counted lgkmcnt.
 // Plain and residual epilogues through the shared LDS staging (epilogue_block64), tile walk of the 8-wave kernel.  One
 // weight tensor only (the dithered weights of large grids); a (hi, lo) pair takes the split kernels.
-// MEASURED (MI355X, benchmarks/gemm_time.py, same process order A/B/A/B, M = 331 776; profiles/r4_gemm_big2.txt) and
+// MEASURED (MI355X, benchmarks/gemm_time.py, same process order A/B/A/B, M = 331 776; profiles/archive/r4_gemm_big2.txt) and
 // REJECTED: 943-961 TF/s at K = 1536 (N = 3072 / 2048 / 1536) and 1031-1036 at K = 2048 against 1015-1041 and 1077-1081
 // for the 8-wave kernel: 4-9 % SLOWER, bit-identical results.  The K loop is not where the 8-wave kernel loses: a 256 x 256
 // tile needs 32 KiB of operands per 1024 matrix cycles = 32 B/clk, the CU's whole L2 -> LDS rate, whatever

@@ -247,6 +247,28 @@ class _FakeEvent:
         return 1.0
 
 
+def _count_collectives(log, marks):
+    """Wrap every torch.distributed collective bench.py could issue: log (name, payload bytes).  `marks` are appended to the same
+    log by the stubbed compute calls, so the log shows what ran BETWEEN the two barriers of the timed region."""
+    def wrap(name, nbytes):
+        real = getattr(dist, name)
+
+        def f(*a, **k):
+            log.append((name, nbytes(*a, **k)))
+            return real(*a, **k)
+        setattr(dist, name, f)
+    tb = lambda t, *a, **k: t.numel() * t.element_size()  # noqa: E731
+    wrap("broadcast", tb)
+    wrap("all_reduce", tb)
+    wrap("all_gather", lambda out, t, *a, **k: t.numel() * t.element_size())
+    wrap("all_gather_object", lambda *a, **k: -1)
+    wrap("barrier", lambda *a, **k: 0)
+    for name in ("reduce", "gather", "scatter", "reduce_scatter", "all_to_all", "all_to_all_single", "send", "recv", "isend", "irecv",
+                 "broadcast_object_list", "all_gather_into_tensor", "reduce_scatter_tensor"):
+        if hasattr(dist, name):
+            wrap(name, lambda *a, **k: -2)
+
+
 def _bench_main_worker(rank, world, port, q, tmp):
     sys.path.insert(0, ROOT)
     os.chdir(tmp)
@@ -257,6 +279,7 @@ def _bench_main_worker(rank, world, port, q, tmp):
     import importlib.util
     calls = []
     _stub_compute(calls)
+    _count_collectives(calls, None)            # collectives and stubbed compute calls in ONE log, in program order
     import torch as th
     from dvd_amd import engine as eng_mod
     real_device = th.device
@@ -265,24 +288,62 @@ def _bench_main_worker(rank, world, port, q, tmp):
     th.device = lambda *a, **k: real_device("cpu") if (a and a[0] == "cuda") else real_device(*a, **k)
     eng_mod.Engine.profile = lambda self, on: None
     eng_mod.Engine.profile_read = lambda self: (0, 0.0)
+    from dvd_amd import ops as ops_mod         # the stubbed kernels write nothing: give bench's finiteness check defined zeros
+    ops_mod.hyp_mean_clamp = lambda x0, n_hyp: th.zeros(x0.shape[0] // n_hyp, 2, x0.shape[2], x0.shape[3])
     spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
     out = io.StringIO()
     with contextlib.redirect_stdout(out):
         try:
-            bench.main(["--gpus", "2", "--steps", "2", "--warmup", "1", "--grid", "16", "--docs", "3", "--ddim-steps", "3",
+            bench.main(["--gpus", str(world), "--steps", "2", "--warmup", "1", "--grid", "16", "--docs", "3", "--ddim-steps", "3",
                         "--full-res", "32x24", "--no-cpu-baseline", "--backend", "gloo"])
         except AssertionError as e:          # the stubbed engine writes nothing: bench's own finiteness check may fire
             if "non-finite" not in str(e):
                 raise
-    q.put((rank, out.getvalue(), calls.count("dvd_engine_denoise_step"), calls.count("dvd_engine_prepare_docs")))
+    q.put((rank, out.getvalue(), calls.count("dvd_engine_denoise_step"), calls.count("dvd_engine_prepare_docs"),
+           [c for c in calls if isinstance(c, tuple)],
+           # the log between the two barriers that bracket the timed region (the 2nd and 3rd barrier of the run)
+           _between_timing_barriers(calls)))
+
+
+def _between_timing_barriers(calls):
+    idx = [i for i, c in enumerate(calls) if c == ("barrier", 0)]
+    return calls[idx[1] + 1:idx[2]] if len(idx) >= 3 else None
+
+
+def test_bench_main_eight_ranks(tmp_path):
+    """Round 6: no 8-GPU node has ever been available, so the first real SCALE run must be boring - the
+    WHOLE `bench.py --gpus 8` branch under 8 gloo ranks (BASELINE configs[2]'s world size): exactly ONE broadcast, of the packed
+    weight blob's byte count; NO collective of any kind between the two barriers of the timed region (only engine launches); the
+    same number of evaluations on every rank; the line carries the broadcast's time and bytes and every rank's own
+    documents/s."""
+    import json
+    res = _spawn_ranks(_bench_main_worker, 8, (str(tmp_path),), timeout=600)
+    assert [r[0] for r in res] == list(range(8))
+    line = json.loads([ln for ln in res[0][1].splitlines() if ln.startswith("{")][-1])
+    for rank, out, den, prep, coll, timed in res:
+        assert den == 3 * 3 and prep == 3, (rank, den, prep)
+        assert rank == 0 or out.strip() == ""
+        names = [c[0] for c in coll]
+        assert names == ["all_gather_object", "barrier", "broadcast", "barrier", "barrier", "all_reduce", "all_gather", "barrier"], (rank, names)
+        (bcast,) = [c for c in coll if c[0] == "broadcast"]
+        assert bcast[1] == line["weight_broadcast_bytes"] > 1_000_000, (rank, bcast)
+        assert timed is not None and not [c for c in timed if isinstance(c, tuple)], (rank, timed)      # zero collectives inside
+        assert timed.count("dvd_engine_denoise_step") == 2 * 3 and timed.count("dvd_unwarp_u8_batch") == 2
+    assert line["n_gpus"] == 8 and line["scaling"] == "weak" and line["config"]["parallelism"].startswith("dp8")
+    assert line["weight_broadcast_ms"] is not None and line["collectives"]["data_path"] == 0
+    assert [p["rank"] for p in line["per_rank"]] == list(range(8)) and all(p["documents_per_s"] > 0 for p in line["per_rank"])
+    assert len(line["ranks_seen"]["ranks"]) == 8
+    assert abs(line["value"] - 8 * 3 * 2 / (line["ms_per_step"] * 2 / 1e3)) < 0.05 * line["value"]
+    slowest = max(p["seconds"] for p in line["per_rank"])
+    assert abs(slowest - line["ms_per_step"] * 2 / 1e3) < 0.05 * slowest + 1e-3      # the value uses the MAX over ranks
 
 
 def test_bench_main_two_ranks(tmp_path):
     import json
     res = _spawn_ranks(_bench_main_worker, 2, (str(tmp_path),))
-    (r0, out0, den0, prep0), (r1, out1, den1, prep1) = res
+    (r0, out0, den0, prep0, _, _), (r1, out1, den1, prep1, _, _) = res
     assert den0 == den1 == 3 * 3 and prep0 == prep1 == 3        # (1 warm-up + 2 timed) x 3 DDIM steps on EVERY rank
     assert out1.strip() == ""                                     # only rank 0 prints
     lines = [ln for ln in out0.splitlines() if ln.startswith("{")]
@@ -377,3 +438,40 @@ def test_bench_launcher_ends_a_hung_rank(tmp_path, monkeypatch):
     dt = time.monotonic() - t0
     assert rc > 0 and rc in (124, 128 + 9, 128 + 15), rc
     assert dt < 60, dt
+
+
+def test_bench_launcher_retries_only_the_rendezvous_race(tmp_path, monkeypatch):
+    """the retry must fire for the port race it exists for - rank 0 ALONE dies at once (EADDRINUSE), the others sit
+    in the store's connect - and must NOT re-run a job whose ranks all fail by themselves (a bad argument would be printed three
+    times).  Fake ranks: on the first attempt rank 0 exits 98 at once while rank 1 waits; on the second attempt (a marker file
+    exists) both exit 0.  Then: every rank exits 5 at once -> reported after ONE attempt."""
+    import importlib.util
+    (tmp_path / "sitecustomize.py").write_text(
+        'import os, sys, time\n'
+        'mode = os.environ.get("DVD_TEST_RACE")\n'
+        'if mode and "RANK" in os.environ:\n'
+        '    mark = os.path.join(os.environ["DVD_TEST_DIR"], "attempts_" + os.environ["RANK"])\n'
+        '    n = len(open(mark).read()) if os.path.exists(mark) else 0\n'
+        '    open(mark, "a").write("x")\n'
+        '    if mode == "race":\n'
+        '        if n == 0 and os.environ["RANK"] == "0": os._exit(98)\n'
+        '        if n == 0: time.sleep(300)\n'
+        '        os._exit(0)\n'
+        '    os._exit(5)\n')
+    monkeypatch.setenv("PYTHONPATH", os.pathsep.join([str(tmp_path), ROOT, os.environ.get("PYTHONPATH", "")]))
+    monkeypatch.setenv("DVD_TEST_DIR", str(tmp_path))
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        monkeypatch.delenv(k, raising=False)
+    spec = importlib.util.spec_from_file_location("bench_launcher2", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    monkeypatch.setenv("DVD_TEST_RACE", "race")
+    t0 = time.monotonic()
+    assert bench.launch_ranks(2, ["--gpus", "2"]) == 0
+    assert time.monotonic() - t0 < 40                                         # the short grace, not the 20 s one
+    assert (tmp_path / "attempts_0").read_text() == "xx" and (tmp_path / "attempts_1").read_text() == "xx"
+    for f in ("attempts_0", "attempts_1"):
+        (tmp_path / f).unlink()
+    monkeypatch.setenv("DVD_TEST_RACE", "all_fail")
+    assert bench.launch_ranks(2, ["--gpus", "2"]) == 5
+    assert (tmp_path / "attempts_0").read_text() == "x"                        # ONE attempt
