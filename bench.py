@@ -397,7 +397,9 @@ def main(argv=None):
                                              "launches_timed": len(unwarp_events),
                                              "avg_launch_ms": round(ms_u8_doc, 4),
                                              "achieved_GBps": round(6 * FH * FW * B / (ms_u8_doc * 1e-3) / 1e9, 1),
-                                             "note": "VALU-bound at 6 B/px (~150 VALU ops per pixel), not HBM-bound"}}
+                                             "note": "bound by its dependent chain per pixel (coarse-flow loads -> taps -> gather -> blend -> "
+                                                     "store), not by HBM and not by its instruction count: hoisting a third of the "
+                                                     "VALU work out of the rows made it slower (profiles/r6_u8_band_variants.txt)"}}
             # HBM-side bytes of that kernel from the committed PMC passes (FETCH_SIZE / WRITE_SIZE in separate rocprofv3
             # runs, 2*FETCH + WRITE: every streaming access of the kernel is 16 bytes per lane) - attached only when the
             # record was taken on this kernel at this launch shape

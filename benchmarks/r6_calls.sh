@@ -31,5 +31,23 @@ print('bench', d['value'], d['ms_per_step'], 'attn', d['roofline']['achieved'], 
 print({k:v for k,v in d.items() if k in ('kernel_shares','gemm')})
 PY
 ;;
+6)   # PRICING the 16x16x32 MFMA shape for the 384 x 256 GEMM: two 16x16x32 MFMAs per 32x32x16 (garbage math, same FLOPs, LDS reads, DMA)
+( for rep in 1 2; do for mode in plain f32; do
+    echo "== 32x32x16 (product loop) $mode"; timeout 300 python benchmarks/gemm_time.py 5 $mode --lab 2>&1 | grep TF
+    echo "== 16x16x32 pricing (DVD_GEMM_T384_DBG=6) $mode"; DVD_GEMM_T384_DBG=6 timeout 300 python benchmarks/gemm_time.py 5 $mode --lab 2>&1 | grep TF
+  done; done ) | tee $O/c6_gemm_m16_pricing.txt
+;;
+7)   # the fused u8 tail as a column-block walk: bytes vs the row / scalar kernels, then the rates
+timeout 900 python -m pytest tests/test_gpu_ops.py -x -q 2>&1 | tail -5 | tee $O/c7_ops_pytest.txt
+( echo "== product (band kernel)"; timeout 300 python benchmarks/warp_time.py 8 --lab 2>&1 | grep -v Warning
+  echo "== DVD_WARP_U8_ROWS=1 (round 3's row kernel)"; DVD_WARP_U8_ROWS=1 timeout 300 python benchmarks/warp_time.py 8 --lab 2>&1 | grep -v Warning ) | tee $O/c7_warp_time.txt
+;;
+8)   # band height x unrolling of the u8 band kernel
+( for ub in 2 4 8 16; do for un in 0 1; do
+    if [ $un = 1 ]; then export DVD_WARP_U8_UNROLL=1; else unset DVD_WARP_U8_UNROLL; fi
+    echo "== UB=$ub unroll=$un"; DVD_WARP_U8_UB=$ub timeout 300 python benchmarks/warp_time.py 8 --lab 2>&1 | grep "unwarp_u8"
+  done; done; unset DVD_WARP_U8_UNROLL
+  echo "== rows"; DVD_WARP_U8_ROWS=1 timeout 300 python benchmarks/warp_time.py 8 --lab 2>&1 | grep "unwarp_u8" ) | tee $O/c8_u8_band_variants.txt
+;;
 *) echo "unknown call $1"; exit 2;;
 esac

@@ -366,7 +366,7 @@ __device__ __forceinline__ void packed_f16(const GemmArgs& p, const floatx16 (&a
 //   0 f16 output only: packed_f16       1 f32 output only: direct_f32       2 f32 output only + residual: direct_f32
 //   3 anything else without residual: the staged generic path       4 ... with residual
 // FULL: M % 384 == 0, no row masks.  DBG (lab): 1 no LDS-DMA in the loop, 2 no fragment reads, 3 no barrier, 4 MFMAs only,
-// 5 s_memtime stamps
+// 5 s_memtime stamps, 6 two 16x16x32 MFMAs per 32x32x16 (pricing, garbage math)
 template <int DBG, int FL, bool FULL>
 __global__ void __launch_bounds__(512, 2) gemm_nt_t384_kernel(GemmArgs p) {
   using namespace t384;
@@ -466,6 +466,7 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_t384_kernel(GemmArgs p) {
         else if constexpr (DBG == 2) t384_loop_xt_noread(T384_ARGS, Anext, Bnext);
         else if constexpr (DBG == 3) t384_loop_xt_nobar(T384_ARGS, Anext, Bnext);
         else if constexpr (DBG == 4) t384_loop_xt_mfmaonly(T384_ARGS, Anext, Bnext);
+        else if constexpr (DBG == 6) t384_loop_xt_m16(T384_ARGS, Anext, Bnext);
         else
 #endif
           t384_loop_xt(T384_ARGS, Anext, Bnext);
@@ -475,6 +476,7 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_t384_kernel(GemmArgs p) {
         else if constexpr (DBG == 2) t384_loop_noread(T384_ARGS);
         else if constexpr (DBG == 3) t384_loop_nobar(T384_ARGS);
         else if constexpr (DBG == 4) t384_loop_mfmaonly(T384_ARGS);
+        else if constexpr (DBG == 6) t384_loop_m16(T384_ARGS);
         else
 #endif
           t384_loop(T384_ARGS);
@@ -550,7 +552,7 @@ int launch_gemm_t384(const GemmArgs& p, int batch, int dbg, void* stream) {
   if (const auto bit = DeviceOnce::current_bit(); once_t.need(bit)) {
     allow_lds<0>();
 #ifdef DVD_LAB
-    allow_lds<1>(); allow_lds<2>(); allow_lds<3>(); allow_lds<4>(); allow_lds<5>();
+    allow_lds<1>(); allow_lds<2>(); allow_lds<3>(); allow_lds<4>(); allow_lds<5>(); allow_lds<6>();
 #endif
     once_t.done(bit);
   }
@@ -571,6 +573,7 @@ int launch_gemm_t384(const GemmArgs& p, int batch, int dbg, void* stream) {
     case 3: launch_fl<3>(p, fl, full, grid, st); break;
     case 4: launch_fl<4>(p, fl, full, grid, st); break;
     case 5: launch_fl<5>(p, fl, full, grid, st); break;
+    case 6: launch_fl<6>(p, fl, full, grid, st); break;      // round 6: the 16x16x32 PRICING ablation (garbage math)
     default: launch_fl<0>(p, fl, full, grid, st);
   }
 #else

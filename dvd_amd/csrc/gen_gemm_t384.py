@@ -58,6 +58,37 @@ def acc(m, n):
     return f"%[c{m}{n}]"
 
 
+# "m16" (round 6, PRICING ablation, lab only): every v_mfma_f32_32x32x16_f16 replaced by TWO v_mfma_f32_16x16x32_f16 on quads of the
+# same accumulator (garbage math: the fragments keep their 32x32x16 layout; same FLOPs, the register-file traffic, MFMA issue
+# count and LDS reads a real 16x16x32 loop would have).  The accumulators are then PINNED to physical registers
+# ("={a[0:15]}" ...: rows m = 1, 2 in a[0:127], row m = 0 in v[24:87]) so that the statement can name their quads.
+ACC_V0 = 24
+
+
+def acc_quad(m, n, q):
+    if m == 0:
+        lo = ACC_V0 + 16 * n + 4 * q
+        return f"v[{lo}:{lo + 3}]"
+    lo = 16 * (4 * (m - 1) + n) + 4 * q
+    return f"a[{lo}:{lo + 3}]"
+
+
+def acc_pin(m, n):
+    if m == 0:
+        return f"{{v[{ACC_V0 + 16 * n}:{ACC_V0 + 16 * n + 15}]}}"
+    lo = 16 * (4 * (m - 1) + n)
+    return f"{{a[{lo}:{lo + 15}]}}"
+
+
+def mfma(e, m, n, a_quad, b_quad, first, phase):
+    if "m16" in ABL:
+        for q in (2 * phase, 2 * phase + 1):
+            d = acc_quad(m, n, q)
+            e.add(f"v_mfma_f32_16x16x32_f16 {d}, {vq(a_quad)}, {vq(b_quad)}, {'0' if first else d}")
+    else:
+        e.add(f"{MF} {acc(m, n)}, {vq(a_quad)}, {vq(b_quad)}, {'0' if first else acc(m, n)}")
+
+
 class Emit:
     """instruction list + the in-order LDS queue (counted lgkmcnt) + the shift state of the four read bases"""
 
@@ -132,7 +163,7 @@ def iteration(e, slot, first=False, dma=True, vm=5, last=False, barrier=None):
         n, m = divmod(i, 3)
         e.need(AX + 4 * m)
         e.need(BQ + 4 * n)
-        e.add(f"{MF} {acc(m, n)}, {vq(AX + 4 * m)}, {vq(BQ + 4 * n)}, {'0' if first else acc(m, n)}")
+        mfma(e, m, n, AX + 4 * m, BQ + 4 * n, first, 0)
         for kind, k in rd1.get(i, ()):
             if kind == "a":
                 e.read(AY + 4 * k, "fa1", slot, 2048 * k)
@@ -149,7 +180,7 @@ def iteration(e, slot, first=False, dma=True, vm=5, last=False, barrier=None):
         n, m = divmod(i, 3)
         e.need(AY + 4 * m)
         e.need(BQ + 4 * n)
-        e.add(f"{MF} {acc(m, n)}, {vq(AY + 4 * m)}, {vq(BQ + 4 * n)}, {acc(m, n)}")
+        mfma(e, m, n, AY + 4 * m, BQ + 4 * n, first and "m16" in ABL, 1)
         if not last:
             for kind, k in rd2.get(i, ()):
                 if kind == "a":
@@ -215,7 +246,8 @@ def loop_stmt(xt=False):
     return e
 
 
-VARIANTS = [("", ()), ("nodma", ("dma",)), ("noread", ("read",)), ("nobar", ("bar",)), ("mfmaonly", ("dma", "read", "bar"))]
+VARIANTS = [("", ()), ("nodma", ("dma",)), ("noread", ("read",)), ("nobar", ("bar",)), ("mfmaonly", ("dma", "read", "bar")),
+            ("m16", ("m16",))]
 
 
 def emit_loop(w, sfx, xt=False):
@@ -226,7 +258,10 @@ def emit_loop(w, sfx, xt=False):
     w("    unsigned fb1" + (", const char* anext, const char* bnext" if xt else "") + ") {")
     w("  asm volatile(")
     w(loop_stmt(xt).text())
-    w("      : " + ", ".join(f'[c{m}{n}] "=&{"v" if m == 0 else "a"}"(acc[{4 * m + n}])' for m in range(3) for n in range(4)) + ",")
+    if "m16" in ABL:
+        w("      : " + ", ".join(f'[c{m}{n}] "={acc_pin(m, n)}"(acc[{4 * m + n}])' for m in range(3) for n in range(4)) + ",")
+    else:
+        w("      : " + ", ".join(f'[c{m}{n}] "=&{"v" if m == 0 else "a"}"(acc[{4 * m + n}])' for m in range(3) for n in range(4)) + ",")
     w('        [fa0] "+v"(fa0), [fa1] "+v"(fa1), [fb0] "+v"(fb0), [fb1] "+v"(fb1)')
     w('      : [asrc] "s"(asrc), [bsrc] "s"(bsrc), [nloop] "s"(nloop), [pda] "s"(pda), [pdb] "s"(pdb), [va0] "v"(va0), [va1] "v"(va1),')
     w('        [va2] "v"(va2), [vb0] "v"(vb0), [vb1] "v"(vb1)' + (', [anext] "s"(anext), [bnext] "s"(bnext)' if xt else ""))

@@ -494,34 +494,47 @@ __device__ __forceinline__ float interp_sum(float a, float b, float c, float d, 
   return fmaf(t0, ly0, __fmul_rn(t1, ly1));
 }
 
-__device__ __forceinline__ void flow_grid_at(const float* __restrict__ flow, const UpParams& p, int i, int j,
-                                             float& gx, float& gy) {
+// The per-AXIS terms of one output coordinate: the flow's and the 512-grid base's source indices and lambdas, and the base
+// grid's two values k / 511 (an IEEE division each).  They depend on the column (or the row) alone, so a kernel that walks
+// down a column block computes its x terms ONCE (unwarp_u8_band_kernel); flow_grid_at composes them per pixel.
+struct AxisTerm {
+  int f0, f1;            // flow rows / columns
+  float l0, l1;          // ... and their lambdas
+  float bl0, bl1;        // lambdas of the 512-grid base
+  float c0, c1;          // its two values: index / 511
+};
+__device__ __forceinline__ AxisTerm axis_term(float scale, float bscale, int dst, int g) {
+  AxisTerm t;
+  interp_axis(scale, dst, g, t.f0, t.f1, t.l0, t.l1);
+  int b0, b1;
+  interp_axis(bscale, dst, 512, b0, b1, t.bl0, t.bl1);
+  t.c0 = __fdiv_rn((float)b0, 511.f);
+  t.c1 = __fdiv_rn((float)b1, 511.f);
+  return t;
+}
+__device__ __forceinline__ void flow_grid_from(const float* __restrict__ flow, const UpParams& p, const AxisTerm& y,
+                                               const AxisTerm& x, float& gx, float& gy) {
   // sample = F.interpolate(flow, (H, W), bilinear, align_corners=True)                       (evaluation.py:301)
-  int y0, y1, x0, x1;
-  float ly0, ly1, lx0, lx1;
-  interp_axis(p.sy, i, p.g, y0, y1, ly0, ly1);
-  interp_axis(p.sx, j, p.g, x0, x1, lx0, lx1);
   const int gg = p.g * p.g;
   float v[2];
 #pragma unroll
   for (int ch = 0; ch < 2; ++ch) {
     const float* f = flow + ch * gg;
-    v[ch] = interp_sum(f[y0 * p.g + x0], f[y0 * p.g + x1], f[y1 * p.g + x0], f[y1 * p.g + x1], lx0, lx1, ly0, ly1, p.small);
+    v[ch] = interp_sum(f[y.f0 * p.g + x.f0], f[y.f0 * p.g + x.f1], f[y.f1 * p.g + x.f0], f[y.f1 * p.g + x.f1], x.l0, x.l1, y.l0,
+                       y.l1, p.small);
   }
   // base = F.interpolate(coords_grid_tensor((512, 512)) / 511., (H, W), bilinear, align_corners=True)   (evaluation.py:304):
   // channel 0 holds column / 511, channel 1 row / 511 of the 512 x 512 grid - interpolated like any other image, so the
   // value is NOT j / (W - 1) to the last bit
-  int yb0, yb1, xb0, xb1;
-  float lby0, lby1, lbx0, lbx1;
-  interp_axis(p.sby, i, 512, yb0, yb1, lby0, lby1);
-  interp_axis(p.sbx, j, 512, xb0, xb1, lbx0, lbx1);
-  const float cx0 = __fdiv_rn((float)xb0, 511.f), cx1 = __fdiv_rn((float)xb1, 511.f);
-  const float cy0 = __fdiv_rn((float)yb0, 511.f), cy1 = __fdiv_rn((float)yb1, 511.f);
-  const float bx = interp_sum(cx0, cx1, cx0, cx1, lbx0, lbx1, lby0, lby1, p.small);
-  const float by = interp_sum(cy0, cy0, cy1, cy1, lbx0, lbx1, lby0, lby1, p.small);
+  const float bx = interp_sum(x.c0, x.c1, x.c0, x.c1, x.bl0, x.bl1, y.bl0, y.bl1, p.small);
+  const float by = interp_sum(y.c0, y.c0, y.c1, y.c1, x.bl0, x.bl1, y.bl0, y.bl1, p.small);
   // sample = (((sample + base) * 1) * 2 - 1) * 0.987                                         (evaluation.py:306)
   gx = __fmul_rn(__fsub_rn(__fmul_rn(__fmul_rn(__fadd_rn(v[0], bx), 1.f), 2.f), 1.f), p.scale);
   gy = __fmul_rn(__fsub_rn(__fmul_rn(__fmul_rn(__fadd_rn(v[1], by), 1.f), 2.f), 1.f), p.scale);
+}
+__device__ __forceinline__ void flow_grid_at(const float* __restrict__ flow, const UpParams& p, int i, int j,
+                                             float& gx, float& gy) {
+  flow_grid_from(flow, p, axis_term(p.sy, p.sby, i, p.g), axis_term(p.sx, p.sbx, j, p.g), gx, gy);
 }
 
 __global__ void __launch_bounds__(256) unwarp_grid_kernel(const float* __restrict__ flow, float* __restrict__ grid,
@@ -711,6 +724,73 @@ __global__ void __launch_bounds__(256) unwarp_u8_rows_kernel(const float* __rest
   *reinterpret_cast<PackedU3*>(out + ((size_t)i * p.w + j0) * 3) = o;
 }
 
+#ifdef DVD_LAB
+// Round 6, MEASURED AND REJECTED - lab only (DVD_WARP_U8_UB = 2 | 4 | 8 | 16, DVD_WARP_U8_UNROLL): the same
+// tail walking DOWN a column block.  unwarp_u8_rows_kernel spends ~150 VALU instructions per pixel for 6 bytes of traffic, and
+// a third of them are the per-COLUMN terms of the up-sampling (two source-index / lambda computations and two IEEE divisions by
+// 511 per pixel) that every row recomputes; here a wave keeps its 256 columns (4 per lane) and loops over UBT rows - the
+// column terms computed once, the row terms once per row and lane.  Same operations in the same order on the same values
+// (flow_grid_from): the same bytes (tests/test_gpu_ops.py).  And SLOWER the taller the band (8 x 3508 x 2480, MI355X,
+// profiles/r6_u8_band_variants.txt): rows 0.441 ms, UBT 2: 0.496, 4: 0.543, 8: 0.628, 16: 0.755, unrolled or not.  So the
+// instruction count is NOT what bounds the row kernel (round 5 called it VALU-bound): a pixel is one dependent chain - coarse-flow
+// loads -> taps -> source gather -> blend -> store - and the kernel runs at the rate its resident waves overlap those chains;
+// a wave that walks 8 rows holds its registers 8 chains long and there are 8x fewer waves to overlap.
+constexpr int UB = 8;
+template <int UBT, bool UNROLL>
+__global__ void __launch_bounds__(256) unwarp_u8_band_kernel(const float* __restrict__ flow, const uint8_t* __restrict__ src,
+                                                             uint8_t* __restrict__ out, UpParams p) {
+  flow += (size_t)blockIdx.z * 2 * p.g * p.g;        // one document per grid z (batched launch)
+  src += (size_t)blockIdx.z * 3 * p.h * p.w;
+  out += (size_t)blockIdx.z * 3 * p.h * p.w;
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int i0 = (blockIdx.y * 4 + wv) * UBT;
+  if (i0 >= p.h) return;
+  const uint32_t j0 = (blockIdx.x * 64 + lane) * 4;
+  if (j0 >= (uint32_t)p.w) return;
+  const uint32_t last_base = (uint32_t)p.h * (uint32_t)p.w * 3u - 12u;
+  AxisTerm xt[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) xt[k] = axis_term(p.sx, p.sbx, (int)(j0 + k), p.g);
+  const int i1 = min(i0 + UBT, p.h);
+#pragma unroll(UNROLL ? UBT : 1)
+  for (int i = i0; i < i1; ++i) {
+    const AxisTerm yt = axis_term(p.sy, p.sby, i, p.g);
+    PTaps t[4];
+    uint32_t ulo[4], uhi[4], dlo[4], dhi[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float gx, gy;
+      flow_grid_from(flow, p, yt, xt[k], gx, gy);
+      t[k] = make_ptaps(gx, gy, p.h, p.w, p.w);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      load_rgb_pair(src, (uint32_t)t[k].r0 * 3u, last_base, ulo[k], uhi[k]);
+      load_rgb_pair(src, (uint32_t)t[k].r1 * 3u, last_base, dlo[k], dhi[k]);
+    }
+    uint32_t ob[12];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float ul[3] = {(float)(ulo[k] & 255u), (float)((ulo[k] >> 8) & 255u), (float)((ulo[k] >> 16) & 255u)};
+      const float ur[3] = {(float)(ulo[k] >> 24), (float)(uhi[k] & 255u), (float)((uhi[k] >> 8) & 255u)};
+      const float dl[3] = {(float)(dlo[k] & 255u), (float)((dlo[k] >> 8) & 255u), (float)((dlo[k] >> 16) & 255u)};
+      const float dr[3] = {(float)(dlo[k] >> 24), (float)(dhi[k] & 255u), (float)((dhi[k] >> 8) & 255u)};
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) {
+        const float a = tap_sum(ul[ch], t[k].a00, ur[ch], t[k].a01, dl[ch], t[k].a10, dr[ch], t[k].a11);
+        ob[k * 3 + ch] = (uint32_t)(int)a & 255u;           // truncation, as numpy .astype(uint8) for 0 <= a < 256
+      }
+    }
+    PackedU3 o;
+    o.a = ob[0] | (ob[1] << 8) | (ob[2] << 16) | (ob[3] << 24);
+    o.b = ob[4] | (ob[5] << 8) | (ob[6] << 16) | (ob[7] << 24);
+    o.c = ob[8] | (ob[9] << 8) | (ob[10] << 16) | (ob[11] << 24);
+    *reinterpret_cast<PackedU3*>(out + ((size_t)i * p.w + j0) * 3) = o;
+  }
+}
+#endif  // DVD_LAB
+
 static UpParams make_up(int g, int h, int w, float scale) {
   UpParams p;
   p.g = g;
@@ -852,6 +932,21 @@ extern "C" int dvd_unwarp_u8_batch(const float* flow, int g, const uint8_t* src_
   DVD_REQUIRE(n >= 0 && n <= 65535, "unwarp: bad batch %d", n);
   if (n == 0) return DVD_OK;
   if (w % 4 == 0 && (size_t)h * w * 3 < (1ull << 32) && (size_t)h * w * 3 >= 12 && !scalar_warp()) {
+#ifdef DVD_LAB
+    if (const char* e = getenv("DVD_WARP_U8_UB")) {      // lab: band height x unrolled or not
+      const int ub = atoi(e);
+      const bool un = getenv("DVD_WARP_U8_UNROLL") != nullptr;
+      const UpParams up = make_up(g, h, w, scale);
+      dim3 grd(cdiv(w, 256), cdiv(h, 4 * ub), n);
+#define UBL(U_, N_) unwarp_u8_band_kernel<U_, N_><<<grd, 256, 0, (hipStream_t)stream>>>(flow, src_hwc, out_hwc, up)
+      if (ub == 2) { if (un) UBL(2, true); else UBL(2, false); }
+      else if (ub == 4) { if (un) UBL(4, true); else UBL(4, false); }
+      else if (ub == 16) { if (un) UBL(16, true); else UBL(16, false); }
+      else { if (un) UBL(8, true); else UBL(8, false); }
+#undef UBL
+      return check_launch("unwarp_u8(lab band)");
+    }
+#endif
     dim3 grd(cdiv(w, 256), cdiv(h, 4), n);
     unwarp_u8_rows_kernel<<<grd, 256, 0, (hipStream_t)stream>>>(flow, src_hwc, out_hwc, make_up(g, h, w, scale));
     return check_launch("unwarp_u8");

@@ -184,6 +184,25 @@ def test_unwarp_fast_equals_fallback(ops, lab, hw):
     assert (f_fast == 0).any() and (f_fast > 0).any()        # zero padding was exercised
 
 
+@pytest.mark.parametrize("hw", [(97, 132), (64, 4), (31, 128), (5, 8), (3508, 2480)])
+def test_unwarp_u8_band_kernel_equals_the_row_kernel(ops, lab, monkeypatch, hw):
+    """Round 6 (measured and rejected, lab only): the fused u8 tail walking down a column block (column terms of the up-sampling
+    computed once per lane; DVD_WARP_U8_UB) against the product's one-row-per-wave kernel and the one-pixel-per-lane fallback: the
+    same bytes - the per-axis split of the up-sampling (AxisTerm / flow_grid_from, which every kernel now shares) changes no bit -
+    on heights that are not a multiple of the band, two documents per launch, borders out of range."""
+    H, W = hw
+    G = 16 if H < 1000 else 288
+    flow = torch.from_numpy(synth.uniform("ub/flow", (2, 2, G, G), -0.12, 0.12, 9)).cuda()
+    src = torch.from_numpy((synth.uniform("ub/src", (2, H, W, 3), 0, 256, 9)).astype(np.uint8)).cuda()
+    rows = ops.unwarp_u8_batch(flow, src)
+    monkeypatch.setenv("DVD_WARP_U8_UB", "8")
+    band = ops.unwarp_u8_batch(flow, src)
+    monkeypatch.delenv("DVD_WARP_U8_UB")
+    monkeypatch.setenv("DVD_WARP_SCALAR", "1")
+    scalar = ops.unwarp_u8_batch(flow, src)
+    assert torch.equal(band, rows) and torch.equal(band, scalar)
+
+
 def test_unwarp_full_size_fast_equals_fallback(ops, lab):
     H, W, G = 3508, 2480, 288
     ctrl = torch.from_numpy(synth.uniform("uwf/ctrl", (1, 2, 6, 6), -0.05, 0.05, 1))
