@@ -49,5 +49,48 @@ timeout 900 python -m pytest tests/test_gpu_ops.py -x -q 2>&1 | tail -5 | tee $O
   done; done; unset DVD_WARP_U8_UNROLL
   echo "== rows"; DVD_WARP_U8_ROWS=1 timeout 300 python benchmarks/warp_time.py 8 --lab 2>&1 | grep "unwarp_u8" ) | tee $O/c8_u8_band_variants.txt
 ;;
+9)   # the 384 x 256 GEMM on v_mfma_f32_16x16x32_f16: parity, then A/B against round 5's loop (lab switch DVD_GEMM_T384_M32)
+timeout 900 python -m pytest tests/test_gpu_gemm.py -x -q -k "t384" 2>&1 | tail -15 | tee $O/c9_t384x_pytest.txt
+( for rep in 1 2; do for mode in plain f32 res; do
+    echo "== 16x16x32 $mode"; timeout 300 python benchmarks/gemm_time.py 5 $mode --lab 2>&1 | grep TF
+    echo "== 32x32x16 (DVD_GEMM_T384_M32) $mode"; DVD_GEMM_T384_M32=1 timeout 300 python benchmarks/gemm_time.py 5 $mode --lab 2>&1 | grep TF
+  done; done ) | tee $O/c9_t384x_ab.txt
+( DVD_GEMM_T384_DBG=5 timeout 300 python benchmarks/gemm_t384_stamps.py 1536 1536 f16; DVD_GEMM_T384_DBG=5 DVD_GEMM_T384_M32=1 timeout 300 python benchmarks/gemm_t384_stamps.py 1536 1536 f16 ) 2>&1 | grep -v Warn | tee $O/c9_t384x_stamps.txt
+;;
+10)  # product library with the 16x16x32 GEMM loop: gemm / engine / dropin suites, A/B, a short bench
+timeout 2400 python -m pytest tests/test_gpu_gemm.py tests/test_gpu_engine.py tests/test_gpu_dropin.py tests/test_gpu_tokens.py tests/test_gpu_ops.py -x -q 2>&1 | tail -12 | tee $O/c10_pytest.txt
+( for rep in 1 2; do for mode in plain f32 res; do
+    echo "== 16x16x32 $mode"; timeout 300 python benchmarks/gemm_time.py 5 $mode --lab 2>&1 | grep TF
+    echo "== 32x32x16 (DVD_GEMM_T384_M32) $mode"; DVD_GEMM_T384_M32=1 timeout 300 python benchmarks/gemm_time.py 5 $mode --lab 2>&1 | grep TF
+  done; done ) > $O/c10_t384x_ab.txt; tail -16 $O/c10_t384x_ab.txt
+timeout 900 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-other-configs 2>$O/c10_bench.err | tail -1 > $O/c10_bench.json
+python - <<'PY'
+import json
+d=json.loads(open('gpurun_out/r6/c10_bench.json').read())
+print('bench', d['value'], d['ms_per_step'], 'attn', d['roofline']['achieved'], d['roofline']['frac'])
+PY
+;;
+11)  # per-kernel split of one bench batch-step (rocprofv3 --kernel-trace --stats), mid-round
+export TMPDIR=/tmp
+cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$GRAFT_REPO_ROOT/gpurun_out/r6/prof_mid" -o bench -- python3 "$GRAFT_REPO_ROOT/bench.py" --steps 1 --warmup 0 --no-cpu-baseline --no-other-configs > "$GRAFT_REPO_ROOT/gpurun_out/r6/prof_mid_bench.json" 2> "$GRAFT_REPO_ROOT/gpurun_out/r6/prof_mid_bench.err"; echo "prof rc=$?"
+cd "$GRAFT_REPO_ROOT"
+python benchmarks/stats_summary.py "$(find gpurun_out/r6/prof_mid -name '*kernel_stats.csv' | head -1)" gpurun_out/r6/prof_mid_bench.json "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-other-configs (round 6, mid-round)" > gpurun_out/r6/prof_mid_summary.txt 2>&1
+sed -n 1,24p gpurun_out/r6/prof_mid_summary.txt | cut -c1-150; tail -12 gpurun_out/r6/prof_mid_summary.txt | cut -c1-200
+find gpurun_out/r6/prof_mid -name '*kernel_stats.csv' -exec cp {} gpurun_out/r6/prof_mid_kernel_stats.csv \;
+find gpurun_out/r6/prof_mid -name '*.csv' ! -name '*kernel_stats.csv' -delete 2>/dev/null
+;;
+12)  # stamps of the residual / f32 / f16 flavours, 16x16x32 vs 32x32x16 (lab), + quick parity
+timeout 600 python -m pytest tests/test_gpu_gemm.py -x -q -k "t384" 2>&1 | tail -3
+( for mode in res f32 f16; do
+    echo "== 16x16x32 $mode"; DVD_GEMM_T384_DBG=5 timeout 300 python benchmarks/gemm_t384_stamps.py 1536 2048 $mode 2>&1 | grep -v Warn | grep -v amdgpu
+    echo "== 32x32x16 $mode"; DVD_GEMM_T384_DBG=5 DVD_GEMM_T384_M32=1 timeout 300 python benchmarks/gemm_t384_stamps.py 1536 2048 $mode 2>&1 | grep -v Warn | grep -v amdgpu
+  done
+  for mode in plain res; do echo "== 16x16x32 $mode"; timeout 300 python benchmarks/gemm_time.py 5 $mode --lab 2>&1 | grep TF; done ) | tee $O/c12_t384x_stamps.txt
+;;
+13)  # residual-window depth of the 16x16x32 kernel's residual epilogue (compile-time T384_RES_DEPTH; benchmarks/lab/alt/)
+( echo "== depth 3 (product)"; timeout 300 python benchmarks/gemm_time.py 7 res --lab 2>&1 | grep TF
+  for d in 4 5 6; do echo "== depth $d"; timeout 300 python benchmarks/gemm_time.py 7 res --lib benchmarks/lab/alt/libdvd_res_d$d.so 2>&1 | grep TF; done
+  echo "== depth 3 (product)"; timeout 300 python benchmarks/gemm_time.py 7 res --lab 2>&1 | grep TF ) | tee $O/c13_res_depth.txt
+;;
 *) echo "unknown call $1"; exit 2;;
 esac

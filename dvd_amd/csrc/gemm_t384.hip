@@ -29,6 +29,41 @@ __device__ __forceinline__ const char* uniform_ptr(const char* q) {      // tell
   const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
   return (const char*)(((unsigned long long)hi << 32) | lo);
 }
+// X16 (round 6): the accumulators come out of the 16x16x32 loop as 16 x 16 quads (gen_gemm_t384.py, x_iteration): register
+// 4 q + j of a 32 x 32 block, q = 2 mi + ni, is row 16 mi + 4 g + j, column 16 ni + c for lane (c = l & 15, g = l >> 4).  One
+// v_permlane16_swap_b32 of the registers (mi, ni = 0, j) and (mi, ni = 1, j) - [x0 x1 x2 x3], [y0 y1 y2 y3] by 16-lane group ->
+// [x0 y0 x2 y2], [x1 y1 x3 y3] (benchmarks/lab/permlane_lab.hip) - leaves register i = 8 mi + 4 y + j holding, for lane
+// (r = l & 31, h = l >> 5), row 16 mi + 4 y + j + 8 h and column r: two rows of 32 consecutive columns per register, the shape
+// every epilogue below was written for (the 32x32x16 layout: row 8 (i >> 2) + (i & 3) + 4 h).
+template <bool X16> __device__ __forceinline__ constexpr int acc_row(int i, int h) {
+  return X16 ? 16 * (i >> 3) + 4 * ((i >> 2) & 1) + (i & 3) + 8 * h : cd_row(i, h);
+}
+template <bool X16> constexpr int HROWS = X16 ? 8 : 4;        // row distance between the two lane halves of a register
+// As asm statements: with __builtin_amdgcn_permlane16_swap this hipcc drops the instruction's SECOND result (it re-uses the source
+// register for the next swap's operand: found on the ISA - rows 4-7 / 12-15 of every block came out as copies of rows 0-3 / 8-11).
+// Four independent swaps per statement (one half tile: registers j and 4 + j), one s_nop pair around them: the VALU-write ->
+// permlane-read and permlane-write -> VALU-read hazards the compiler would pad itself.
+__device__ __forceinline__ void swap16x4(float& x0, float& y0, float& x1, float& y1, float& x2, float& y2, float& x3, float& y3) {
+  asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3\n\tv_permlane16_swap_b32 %4, %5\n\t"
+      "v_permlane16_swap_b32 %6, %7\n\ts_nop 1"
+      : "+v"(x0), "+v"(y0), "+v"(x1), "+v"(y1), "+v"(x2), "+v"(y2), "+v"(x3), "+v"(y3));
+}
+template <bool X16> __device__ __forceinline__ floatx16 rows32(const floatx16& t) {
+  floatx16 o = t;
+  if constexpr (X16) {
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+      float x[4], y[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { x[j] = o[8 * mi + j]; y[j] = o[8 * mi + 4 + j]; }
+      swap16x4(x[0], y[0], x[1], y[1], x[2], y[2], x[3], y[3]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { o[8 * mi + j] = x[j]; o[8 * mi + 4 + j] = y[j]; }
+    }
+  }
+  return o;
+}
+
 __device__ __forceinline__ void dma_piece(const char* gb, unsigned voff, unsigned lds) {
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %0" ::"s"(gb), "s"(lds), "v"(voff) : "memory");
 }
@@ -38,22 +73,24 @@ __device__ __forceinline__ void dma_piece(const char* gb, unsigned voff, unsigne
 // the bits are gemm_nt_big_kernel's.  The residual rows ride a rolling window that runs ACROSS the six blocks of a wave tile
 // (slot g % 2 of global iteration g = 4 block + it): a load is always issued before the stores it overlaps, so waiting
 // for it never waits for a store (vmcnt retires in order and counts stores); the column biases come from LDS.
-__device__ __forceinline__ void stage2(float* stage, const floatx16& t0, const floatx16& t1, int lane) {
+template <bool X16>
+__device__ __forceinline__ void stage2(float* stage, const floatx16& a0, const floatx16& a1, int lane) {
   const int r = lane & 31, h = lane >> 5;
+  const floatx16 t0 = rows32<X16>(a0), t1 = rows32<X16>(a1);
 #pragma unroll
-  for (int i = 0; i < 16; ++i) stage[cd_row(i, h) * 64 + r] = t0[i];
+  for (int i = 0; i < 16; ++i) stage[acc_row<X16>(i, h) * 64 + r] = t0[i];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) stage[cd_row(i, h) * 64 + 32 + r] = t1[i];
+  for (int i = 0; i < 16; ++i) stage[acc_row<X16>(i, h) * 64 + 32 + r] = t1[i];
 }
 
-template <int EPI, int BLK>
+template <int EPI, int BLK, bool X16>
 __device__ __forceinline__ void block(const GemmArgs& p, float* stage, const float* stage_bias, const floatx16& t0, const floatx16& t1,
                                       int row_w, int col_w, int lane_in, float* C32, _Float16* C16, const float* res, bool has_bias,
                                       floatx4 (&rs0)[2], floatx4 (&rs1)[2]) {
   constexpr int MB = BLK >> 1, NB = BLK & 1;
   int lane = lane_in;
   asm volatile("" : "+v"(lane));           // per-block addressing is recomputed here, not hoisted above the six blocks and spilled
-  if constexpr (BLK >= 2) stage2(stage, t0, t1, lane);
+  if constexpr (BLK >= 2) stage2<X16>(stage, t0, t1, lane);
   const int c8 = (lane & 7) * 8;
   const int col = col_w + 64 * NB + c8;
   float bc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -114,15 +151,15 @@ __device__ __forceinline__ void block(const GemmArgs& p, float* stage, const flo
   }
 }
 
-template <int EPI>
+template <int EPI, bool X16>
 __device__ __forceinline__ void epilogue(const GemmArgs& p, float* stage, const floatx16 (&acc)[12], int row_w, int col_w, int lane,
                                          float* C32, _Float16* C16, const float* bias, const float* res) {
   // the four accumulators that live in VGPRs (row m = 0) go to the two staging areas first: 64 registers free for what follows
   float* const sa = stage;
   float* const sb = stage + 32 * 64;
   float* const sbias = stage + 2 * 32 * 64;
-  stage2(sa, acc[0], acc[1], lane);
-  stage2(sb, acc[2], acc[3], lane);
+  stage2<X16>(sa, acc[0], acc[1], lane);
+  stage2<X16>(sb, acc[2], acc[3], lane);
   if (bias) {                               // the wave's 128 column biases -> LDS: no global load inside the store sequence
     if (lane < 32) *(floatx4*)(sbias + 4 * lane) = *(const floatx4*)(bias + col_w + 4 * lane);
   }
@@ -136,12 +173,12 @@ __device__ __forceinline__ void epilogue(const GemmArgs& p, float* stage, const 
     }
   }
   const bool hb = bias != nullptr;
-  block<EPI, 0>(p, sa, sbias, acc[0], acc[1], row_w, col_w, lane, C32, C16, res, hb, rs0, rs1);
-  block<EPI, 1>(p, sb, sbias, acc[2], acc[3], row_w, col_w, lane, C32, C16, res, hb, rs0, rs1);
-  block<EPI, 2>(p, sa, sbias, acc[4], acc[5], row_w, col_w, lane, C32, C16, res, hb, rs0, rs1);
-  block<EPI, 3>(p, sb, sbias, acc[6], acc[7], row_w, col_w, lane, C32, C16, res, hb, rs0, rs1);
-  block<EPI, 4>(p, sa, sbias, acc[8], acc[9], row_w, col_w, lane, C32, C16, res, hb, rs0, rs1);
-  block<EPI, 5>(p, sb, sbias, acc[10], acc[11], row_w, col_w, lane, C32, C16, res, hb, rs0, rs1);
+  block<EPI, 0, X16>(p, sa, sbias, acc[0], acc[1], row_w, col_w, lane, C32, C16, res, hb, rs0, rs1);
+  block<EPI, 1, X16>(p, sb, sbias, acc[2], acc[3], row_w, col_w, lane, C32, C16, res, hb, rs0, rs1);
+  block<EPI, 2, X16>(p, sa, sbias, acc[4], acc[5], row_w, col_w, lane, C32, C16, res, hb, rs0, rs1);
+  block<EPI, 3, X16>(p, sb, sbias, acc[6], acc[7], row_w, col_w, lane, C32, C16, res, hb, rs0, rs1);
+  block<EPI, 4, X16>(p, sa, sbias, acc[8], acc[9], row_w, col_w, lane, C32, C16, res, hb, rs0, rs1);
+  block<EPI, 5, X16>(p, sb, sbias, acc[10], acc[11], row_w, col_w, lane, C32, C16, res, hb, rs0, rs1);
 }
 
 // ---- fast epilogue 1: f32 output (optional residual, optional ReLU / bias), NO LDS.  Register i of a 32 x 32 accumulator is
@@ -155,7 +192,7 @@ __device__ __forceinline__ void epilogue(const GemmArgs& p, float* stage, const 
 typedef __attribute__((address_space(1))) float gfloat;
 typedef __attribute__((address_space(1))) char gchar;
 
-template <bool RES, bool FULL>
+template <bool RES, bool FULL, bool X16>
 __device__ __forceinline__ void direct_f32(const GemmArgs& p, const floatx16 (&acc)[12], int row_w, int col_w, int lane, float* C32,
                                            const float* bias, const float* res) {
   const int r = lane & 31, h = lane >> 5;
@@ -167,10 +204,13 @@ __device__ __forceinline__ void direct_f32(const GemmArgs& p, const floatx16 (&a
   const bool relu = p.act == 2;
   // every address = wave-uniform base of the half tile and row (SGPR pair) + ONE per-lane 32-bit offset (row 4 h, column r):
   // global_load/store_dword v, v_off, s[base]
-  const unsigned oc = (unsigned)((4 * h) * p.ldc + r) * 4u, orr = (unsigned)((4 * h) * p.ldres + r) * 4u;
+  const unsigned oc = (unsigned)((HROWS<X16> * h) * p.ldc + r) * 4u, orr = (unsigned)((HROWS<X16> * h) * p.ldres + r) * 4u;
   const gchar* cb = (const gchar*)uniform_ptr((const char*)(C32 + (size_t)row_w * p.ldc + col_w));
   const gchar* rb = RES ? (const gchar*)uniform_ptr((const char*)(res + (size_t)row_w * p.ldres + col_w)) : nullptr;
-  const int rows_left = p.M - row_w - 4 * h;          // rows of this lane half that exist (ragged last row tile)
+  const int rows_left = p.M - row_w - HROWS<X16> * h;          // rows of this lane half that exist (ragged last row tile)
+  // row (within the half tile of 16) of register k of a step, lane half 0: 32x32x16 layout (k & 3) + 8 (k >> 2); X16 (after
+  // the permlane16 swap) (k & 3) + 4 (k >> 2)
+  auto krow = [](int k) { return (k & 3) + (X16 ? 4 : 8) * (k >> 2); };
   // half tiles (registers 8 u .. 8 u + 7 of accumulator t): 24 steps; the residual of a step is requested T384_RES_DEPTH steps
   // before it is used, always before the stores of the step that issues it (waiting for a load also waits for every OLDER
   // store: vmcnt retires in order and counts stores).  Two steps ahead a step cost 1375 cycles = 33 k per tile
@@ -186,7 +226,7 @@ __device__ __forceinline__ void direct_f32(const GemmArgs& p, const floatx16 (&a
     const int t = s >> 1, u = s & 1, m = t >> 2, n = t & 3;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      const int ro = 32 * m + 16 * u + (k & 3) + 8 * (k >> 2);
+      const int ro = 32 * m + 16 * u + krow(k);
       const gchar* sb = rb + ((size_t)ro * p.ldres + 32 * n) * 4;               // wave-uniform
       dst[k] = (FULL || ro < rows_left) ? *(const gfloat*)(sb + (size_t)orr) : 0.f;
     }
@@ -203,17 +243,22 @@ __device__ __forceinline__ void direct_f32(const GemmArgs& p, const floatx16 (&a
     if constexpr (RES) {
       if (s + D < 24) load_res(s + D, rv[(s + D) % W]);
     }
-    float v[8];
+    float v[8], a8[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a8[k] = acc[t][8 * u + k];
+    if constexpr (X16) {                           // two 16 x 16 quads -> rows of 32 columns (see rows32)
+      swap16x4(a8[0], a8[4], a8[1], a8[5], a8[2], a8[6], a8[3], a8[7]);
+    }
 #pragma unroll
     for (int k = 0; k < 8; ++k) {                 // (no `+ 0.f`: an accumulator that starts at +0 is never -0; bv = 0 without a bias)
-      float x = acc[t][8 * u + k] + bv[n];
+      float x = a8[k] + bv[n];
       x = relu ? fmaxf(x, 0.f) : x;
       if constexpr (RES) x += rv[s % W][k];
       v[k] = x;
     }
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-      const int ro = 32 * m + 16 * u + (k & 3) + 8 * (k >> 2);
+      const int ro = 32 * m + 16 * u + krow(k);
       gchar* sb = const_cast<gchar*>(cb) + ((size_t)ro * p.ldc + 32 * n) * 4;    // wave-uniform
 #ifdef DVD_LAB
       if (p.debug & 0x200) {                       // lab (DVD_GEMM_T384_NT): streaming stores - are they acknowledged sooner?
@@ -305,7 +350,7 @@ __device__ __forceinline__ void phased_res_f32(const GemmArgs& p, const floatx16
 // the accumulator layout (a lane = one column); neighbouring lanes then trade one value per register PAIR through a DPP
 // quad permute, so that an even lane holds (row a: columns r, r + 1) and its odd neighbour (row a + 1: columns r - 1, r) as
 // one packed dword each: a global_store_dword writes four 64-byte row segments, 8 stores per 32 x 32 accumulator.
-template <bool FULL>
+template <bool FULL, bool X16>
 __device__ __forceinline__ void packed_f16(const GemmArgs& p, const floatx16 (&acc)[12], int row_w, int col_w, int lane,
                                            _Float16* C16, const float* bias) {
   const int r = lane & 31, h = lane >> 5;
@@ -327,7 +372,7 @@ __device__ __forceinline__ void packed_f16(const GemmArgs& p, const floatx16 (&a
   // per-lane byte offsets of the 8 packed registers of a tile (register pair (2 j, 2 j + 1) = rows a, a + 1): the same for all tiles
   unsigned oc[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) oc[j] = (unsigned)((cd_row(2 * j, h) + sub) * p.ldc16 + 2 * lc) * 2u;
+  for (int j = 0; j < 8; ++j) oc[j] = (unsigned)((acc_row<X16>(2 * j, h) + sub) * p.ldc16 + 2 * lc) * 2u;
   const gchar* cb = (const gchar*)uniform_ptr((const char*)(C16 + (size_t)row_w * p.ldc16 + col_w));
   const int rows_left = p.M - row_w;
 #pragma unroll
@@ -336,8 +381,11 @@ __device__ __forceinline__ void packed_f16(const GemmArgs& p, const floatx16 (&a
     __builtin_amdgcn_sched_barrier(0);     // one accumulator at a time: the scheduler must not pull all twelve read-outs forward
     // (the old kernel's `+ 0.f`s are dropped: an accumulator that starts at +0 is never -0, so they change no bit)
     float v[16];
+    {
+      const floatx16 a32 = rows32<X16>(acc[t]);
 #pragma unroll
-    for (int i = 0; i < 16; ++i) v[i] = acc[t][i] + bv[n];      // bv = 0 without a bias: x + 0 = x for every x that is not -0
+      for (int i = 0; i < 16; ++i) v[i] = a32[i] + bv[n];       // bv = 0 without a bias: x + 0 = x for every x that is not -0
+    }
     if (act == 1) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) v[i] = gelu_tanh(v[i]);
@@ -355,7 +403,7 @@ __device__ __forceinline__ void packed_f16(const GemmArgs& p, const floatx16 (&a
       const unsigned pw = __builtin_bit_cast(unsigned, own);
       const unsigned qw = (unsigned)__builtin_amdgcn_mov_dpp((int)pw, 0xB1, 0xF, 0xF, true);
       const unsigned pk = (unsigned)__builtin_amdgcn_ds_bpermute(bp_src, (int)__builtin_amdgcn_perm(qw, pw, sel));
-      const int ro = 32 * m + cd_row(2 * j, h) + sub;
+      const int ro = 32 * m + acc_row<X16>(2 * j, h) + sub;
       if (FULL || ro < rows_left) *(__attribute__((address_space(1))) unsigned*)(sb + (size_t)oc[j]) = pk;
     }
   }
@@ -367,7 +415,7 @@ __device__ __forceinline__ void packed_f16(const GemmArgs& p, const floatx16 (&a
 //   3 anything else without residual: the staged generic path       4 ... with residual
 // FULL: M % 384 == 0, no row masks.  DBG (lab): 1 no LDS-DMA in the loop, 2 no fragment reads, 3 no barrier, 4 MFMAs only,
 // 5 s_memtime stamps, 6 two 16x16x32 MFMAs per 32x32x16 (pricing, garbage math)
-template <int DBG, int FL, bool FULL>
+template <int DBG, int FL, bool FULL, bool X16>
 __global__ void __launch_bounds__(512, 2) gemm_nt_t384_kernel(GemmArgs p) {
   using namespace t384;
   // XT: the ring never drains between the tiles of a workgroup (gen_gemm_t384.py, loop_stmt(xt=True)): the next tile's first
@@ -419,22 +467,27 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_t384_kernel(GemmArgs p) {
       asm volatile("" : "+v"(lane_l));
 #define lane lane_l
       // fragment read bases in slot 0: row r of the wave's first 32-row block, chunk (2 s + h) ^ ((r >> 2) & 3)
-      const unsigned ch = (unsigned)((((lane >> 5) ^ (((lane & 31) >> 2) & 3))) * 16);
-      const unsigned fa0 = lds0 + (96 * wr + (lane & 31)) * 64 + ch, fa1 = fa0 ^ 32;
-      const unsigned fb0 = lds0 + BOFF + (128 * wc + (lane & 31)) * 64 + ch, fb1 = fb0 ^ 32;
+      // X16: fragment = 16 rows x 64 B, lane l reads chunk (l >> 4) of row (l & 15); image swizzle (-(row >> 2)) & 3 (gen_gemm_t384.py)
+      const unsigned ch = X16 ? (unsigned)(((lane >> 4) ^ ((0u - (unsigned)((lane & 15) >> 2)) & 3u)) * 16)
+                              : (unsigned)((((lane >> 5) ^ (((lane & 31) >> 2) & 3))) * 16);
+      const int frow = X16 ? (lane & 15) : (lane & 31);
+      const unsigned fa0 = lds0 + (96 * wr + frow) * 64 + ch, fa1 = fa0 ^ 32;
+      const unsigned fb0 = lds0 + BOFF + (128 * wc + frow) * 64 + ch, fb1 = fb0 ^ 32;
       unsigned va[3], vb[2];
       const int pos = lane & 3;
+      auto swz = [](int row) { return X16 ? (int)((0u - (unsigned)(row >> 2)) & 3u) : ((row >> 2) & 3); };
 #pragma unroll
       for (int i = 0; i < 3; ++i) {
         const int row = 16 * (3 * wave + i) + (lane >> 2);
         const int ra = FULL ? row : min(bm0 + row, p.M - 1) - bm0;
-        va[i] = (unsigned)ra * (unsigned)(p.lda * 2) + (pos ^ ((row >> 2) & 3)) * 16;
+        va[i] = (unsigned)ra * (unsigned)(p.lda * 2) + (pos ^ swz(row)) * 16;
       }
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int row = 16 * (2 * wave + i) + (lane >> 2);
-        vb[i] = (unsigned)row * (unsigned)(p.ldb * 2) + (pos ^ ((row >> 2) & 3)) * 16;     // N % 256 == 0: never clamped
+        vb[i] = (unsigned)row * (unsigned)(p.ldb * 2) + (pos ^ swz(row)) * 16;     // N % 256 == 0: never clamped
       }
+      (void)fa1; (void)fb1;
       const char* Atile = uniform_ptr((const char*)(A + (size_t)bm0 * p.lda));
       const char* Btile = uniform_ptr((const char*)(B + (size_t)bn0 * p.ldb));
       if (!XT || first) {
@@ -453,7 +506,18 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_t384_kernel(GemmArgs p) {
       if constexpr (DBG == 5) t1 = __builtin_amdgcn_s_memtime();
 #endif
 #define T384_ARGS acc, Atile + 3 * 64, Btile + 3 * 64, nloop, pda, pdb, va[0], va[1], va[2], vb[0], vb[1], fa0, fa1, fb0, fb1
-      if constexpr (XT) {
+#define T384X_ARGS acc, Atile + 3 * 64, Btile + 3 * 64, nloop, pda, pdb, va[0], va[1], va[2], vb[0], vb[1], fa0, fb0
+      if constexpr (X16 && XT) {
+        const int vnext = vid + (int)gridDim.x < nwg ? vid + (int)gridDim.x : vid;
+        int tm2, tn2;
+        tile_coords(vnext, p.ntm, p.ntn, tm2, tn2, p.walk);
+        tm2 = __builtin_amdgcn_readfirstlane(tm2); tn2 = __builtin_amdgcn_readfirstlane(tn2);
+        const char* Anext = uniform_ptr((const char*)(A + (size_t)tm2 * 384 * p.lda));
+        const char* Bnext = uniform_ptr((const char*)(B + (size_t)tn2 * 256 * p.ldb));
+        t384x_loop_xt(T384X_ARGS, Anext, Bnext);
+      } else if constexpr (X16) {
+        t384x_loop(T384X_ARGS);
+      } else if constexpr (XT) {
         // the next tile of this workgroup (the last one re-loads its own first half slabs: valid addresses, never read)
         const int vnext = vid + (int)gridDim.x < nwg ? vid + (int)gridDim.x : vid;
         int tm2, tn2;
@@ -482,6 +546,7 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_t384_kernel(GemmArgs p) {
           t384_loop(T384_ARGS);
       }
 #undef T384_ARGS
+#undef T384X_ARGS
 #undef lane
     }
     if constexpr (!XT) {
@@ -500,17 +565,19 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_t384_kernel(GemmArgs p) {
       const int lane_e = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
       float* stage = (float*)smem + wave * STAGE;
       const int row_w = bm0 + 96 * wr, col_w = bn0 + 128 * wc;
-      if constexpr (FL == 0) packed_f16<FULL>(p, acc, row_w, col_w, lane_e, C16, bias);
-      else if constexpr (FL == 1) direct_f32<false, FULL>(p, acc, row_w, col_w, lane_e, C32, bias, res);
+      if constexpr (FL == 0) packed_f16<FULL, X16>(p, acc, row_w, col_w, lane_e, C16, bias);
+      else if constexpr (FL == 1) direct_f32<false, FULL, X16>(p, acc, row_w, col_w, lane_e, C32, bias, res);
       else if constexpr (FL == 2) {
 #ifdef DVD_LAB
-        if (p.debug & 0x400) phased_res_f32<FULL>(p, acc, row_w, col_w, lane_e, C32, bias, res);    // lab: the phased form (measured equal)
-        else
+        if constexpr (!X16) {
+          if (p.debug & 0x400) { phased_res_f32<FULL>(p, acc, row_w, col_w, lane_e, C32, bias, res); }    // lab: the phased form (measured equal)
+          else direct_f32<true, FULL, X16>(p, acc, row_w, col_w, lane_e, C32, bias, res);
+        } else
 #endif
-          direct_f32<true, FULL>(p, acc, row_w, col_w, lane_e, C32, bias, res);
+          direct_f32<true, FULL, X16>(p, acc, row_w, col_w, lane_e, C32, bias, res);
       }
-      else if constexpr (FL == 3) epilogue<0>(p, stage, acc, row_w, col_w, lane_e, C32, C16, bias, res);
-      else epilogue<1>(p, stage, acc, row_w, col_w, lane_e, C32, C16, bias, res);
+      else if constexpr (FL == 3) epilogue<0, X16>(p, stage, acc, row_w, col_w, lane_e, C32, C16, bias, res);
+      else epilogue<1, X16>(p, stage, acc, row_w, col_w, lane_e, C32, C16, bias, res);
     }
 #ifdef DVD_LAB
     if constexpr (DBG == 5) {
@@ -527,9 +594,9 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_t384_kernel(GemmArgs p) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template <int DBG>
+template <int DBG, bool X16>
 static void launch_fl(const GemmArgs& p, int fl, bool full, dim3 grid, hipStream_t st) {
-#define T384_GO(FL_, FULL_) gemm_nt_t384_kernel<DBG, FL_, FULL_><<<grid, 512, t384::LDS_BYTES, st>>>(p)
+#define T384_GO(FL_, FULL_) gemm_nt_t384_kernel<DBG, FL_, FULL_, X16><<<grid, 512, t384::LDS_BYTES, st>>>(p)
   if (full) {
     switch (fl) { case 0: T384_GO(0, true); break; case 1: T384_GO(1, true); break; case 2: T384_GO(2, true); break;
                   case 3: T384_GO(3, true); break; default: T384_GO(4, true); }
@@ -539,20 +606,27 @@ static void launch_fl(const GemmArgs& p, int fl, bool full, dim3 grid, hipStream
   }
 #undef T384_GO
 }
-template <int DBG>
+template <int DBG, bool X16>
 static void allow_lds() {
-#define T384_AL(FL_, FULL_) (void)hipFuncSetAttribute((const void*)gemm_nt_t384_kernel<DBG, FL_, FULL_>, hipFuncAttributeMaxDynamicSharedMemorySize, t384::LDS_BYTES)
+#define T384_AL(FL_, FULL_) (void)hipFuncSetAttribute((const void*)gemm_nt_t384_kernel<DBG, FL_, FULL_, X16>, hipFuncAttributeMaxDynamicSharedMemorySize, t384::LDS_BYTES)
   T384_AL(0, true); T384_AL(1, true); T384_AL(2, true); T384_AL(3, true); T384_AL(4, true);
   T384_AL(0, false); T384_AL(1, false); T384_AL(2, false); T384_AL(3, false); T384_AL(4, false);
 #undef T384_AL
 }
 
+// T384_X16: the product's K loop.  1 = v_mfma_f32_16x16x32_f16 (round 6), 0 = round 5's 32x32x16 loop (bit-identical to
+// gemm_nt_big_kernel).  The lab build carries both (DVD_GEMM_T384_M32=1 selects the old one) and the timing ablations of the old one.
+#ifndef T384_X16
+#define T384_X16 1
+#endif
 int launch_gemm_t384(const GemmArgs& p, int batch, int dbg, void* stream) {
   static DeviceOnce once_t;
   if (const auto bit = DeviceOnce::current_bit(); once_t.need(bit)) {
-    allow_lds<0>();
+    allow_lds<0, T384_X16 != 0>();
 #ifdef DVD_LAB
-    allow_lds<1>(); allow_lds<2>(); allow_lds<3>(); allow_lds<4>(); allow_lds<5>(); allow_lds<6>();
+    allow_lds<0, T384_X16 == 0>();
+    allow_lds<1, false>(); allow_lds<2, false>(); allow_lds<3, false>(); allow_lds<4, false>(); allow_lds<5, false>(); allow_lds<6, false>();
+    allow_lds<5, true>();
 #endif
     once_t.done(bit);
   }
@@ -567,18 +641,24 @@ int launch_gemm_t384(const GemmArgs& p, int batch, int dbg, void* stream) {
   const int fl = (p.C16 && !p.C32 && !p.res) ? 0 : (p.C32 && !p.C16 && p.act != 1) ? (p.res ? 2 : 1) : (p.res ? 4 : 3);
   const bool full = p.M % 384 == 0;
 #ifdef DVD_LAB
+  const bool use_x16 = getenv("DVD_GEMM_T384_M32") ? false : (getenv("DVD_GEMM_T384_X16") ? true : (T384_X16 != 0));
+  if (use_x16) {
+    if (dbg == 5) launch_fl<5, true>(p, fl, full, grid, st);
+    else launch_fl<0, true>(p, fl, full, grid, st);
+    return check_launch("gemm_nt(t384 x16)");
+  }
   switch (dbg) {
-    case 1: launch_fl<1>(p, fl, full, grid, st); break;
-    case 2: launch_fl<2>(p, fl, full, grid, st); break;
-    case 3: launch_fl<3>(p, fl, full, grid, st); break;
-    case 4: launch_fl<4>(p, fl, full, grid, st); break;
-    case 5: launch_fl<5>(p, fl, full, grid, st); break;
-    case 6: launch_fl<6>(p, fl, full, grid, st); break;      // round 6: the 16x16x32 PRICING ablation (garbage math)
-    default: launch_fl<0>(p, fl, full, grid, st);
+    case 1: launch_fl<1, false>(p, fl, full, grid, st); break;
+    case 2: launch_fl<2, false>(p, fl, full, grid, st); break;
+    case 3: launch_fl<3, false>(p, fl, full, grid, st); break;
+    case 4: launch_fl<4, false>(p, fl, full, grid, st); break;
+    case 5: launch_fl<5, false>(p, fl, full, grid, st); break;
+    case 6: launch_fl<6, false>(p, fl, full, grid, st); break;      // round 6: the 16x16x32 PRICING ablation (garbage math)
+    default: launch_fl<0, false>(p, fl, full, grid, st);
   }
 #else
   (void)dbg;
-  launch_fl<0>(p, fl, full, grid, st);
+  launch_fl<0, T384_X16 != 0>(p, fl, full, grid, st);
 #endif
   return check_launch("gemm_nt(t384)");
 }

@@ -197,6 +197,138 @@ def iteration(e, slot, first=False, dma=True, vm=5, last=False, barrier=None):
         e.add(f"s_addc_u32 s{S_B + 1}, s{S_B + 1}, 0")
 
 
+# ================================================================================================
+# Round 6: the same tile, ring and DMA schedule on v_mfma_f32_16x16x32_f16 ("x16": functions t384x_loop / t384x_loop_xt).
+# Priced first (ablation "m16" above: two 16x16x32 per 32x32x16, garbage math): +5-7 % wall on the f16 flavour, +4-6 % on the
+# f32 one under the board's power cap (profiles/r6_gemm_m16_pricing.txt) - the shape that moved the decoder attention in round 4.
+#
+# A half slab is ONE k-step of 32: 6 A fragments (16 rows each) x 8 B fragments (16 columns each) = 48 MFMAs per wave, each
+# 16 x 16 x 32; fragment = 16 rows x 64 bytes, lane l reads the 16-byte chunk (l >> 4) of row (l & 15) - the same bytes per MFMA-FLOP
+# from LDS as before (14 ds_read_b128 per half slab).  MFMA order: a outer (A fragment), n inner: A[a] is used by 8 consecutive
+# MFMAs and dead after them - a ring of TWO quads, A[a + 1] read one block ahead - while the 8 B fragments stay resident for the
+# whole half slab (32 registers) and are re-loaded in place for the next one, each right behind its last MFMA of block a = 5
+# (8 MFMAs = 128 issue cycles ahead of its next use).  2 + 8 quads = the 40 fragment registers v[88:127] of the old plan.
+# LDS image: chunk c of row r at position c ^ ((-(r >> 2)) & 3): conflict-free for this read's lane groups ({0-3,12-15,20-27}, ...:
+# per row residue the four lanes of a group hold positions {s0, 1^s1, 1^s2, s3} with s = (0,3,2,1) = all different); the old
+# image ((r >> 2) & 3) is 2-way conflicted for it.  The swizzle is applied to the LDS-DMA's per-lane SOURCE offsets (kernel).
+# Accumulators: 12 floatx16 PINNED to physical registers (rows m = 1, 2: a[0:127]; row m = 0: v[24:87]) so the statement can
+# name their quads; quad q = 2 mi + ni of accumulator (m, nb) is the 16 x 16 tile at rows 32 m + 16 mi, columns 32 nb + 16 ni:
+# lane (c = l & 15, g = l >> 4), register j = row 4 g + j, column c.  The epilogues turn two quads into rows of 32 columns with
+# v_permlane16_swap_b32 (kernel).  Per accumulator element the products are summed in ascending k, 32 per MFMA: NOT the bits of
+# the 32x32x16 kernels (16 per MFMA) - parity is the oracle's tolerance, and the kernel choice never depends on M.
+# ================================================================================================
+AR, BR = 88, 96                    # A ring: 2 quads v[88:95]; B fragments: 8 quads v[96:127]
+MF16 = "v_mfma_f32_16x16x32_f16"
+
+
+def xquad(a, n):
+    m, mi, nb, ni = a >> 1, a & 1, n >> 1, n & 1
+    return acc_quad(m, nb, 2 * mi + ni)
+
+
+def x_prime(e):
+    """slot 0's fragments in the order block 5 of an iteration issues the next half slab's: B0, A0, B1 .. B7"""
+    e.read(BR, "fb0", 0, 0)
+    e.read(AR, "fa0", 0, 0)
+    for n in range(1, 8):
+        e.read(BR + 4 * n, "fb0", 0, 1024 * n)
+
+
+def x_iteration(e, slot, first=False, dma=True, vm=5, last=False, barrier=None):
+    if barrier is None:
+        barrier = not last
+    nslot = (slot + 1) % RING
+    pc = 0
+    pieces_at = {(3, 1), (3, 3), (3, 5), (3, 7), (4, 1)}          # (block, gap): the wave's 5 pieces of half slab j + 3
+    for a in range(6):
+        if a == 3:
+            if vm is not None and "dma" not in ABL:
+                e.add(f"s_waitcnt vmcnt({vm})")
+            if barrier and "bar" not in ABL:
+                e.add("s_barrier")
+        for n in range(8):
+            e.need(AR + 4 * (a & 1))
+            e.need(BR + 4 * n)
+            d = xquad(a, n)
+            e.add(f"{MF16} {d}, {vq(AR + 4 * (a & 1))}, {vq(BR + 4 * n)}, {'0' if first else d}")
+            if a < 5 and n == 0:
+                e.read(AR + 4 * ((a + 1) & 1), "fa0", slot, 1024 * (a + 1))       # A[a + 1] of this half slab
+            if a == 5 and not last:
+                e.read(BR + 4 * n, "fb0", nslot, 1024 * n)                         # B[n] of the next half slab, in place
+                if n == 0:
+                    e.read(AR, "fa0", nslot, 0)                                    # ... and its A[0]
+            if dma and (a, n) in pieces_at:
+                piece(e, pc, (slot + RING - 1) % RING)
+                pc += 1
+    if dma and "dma" not in ABL:
+        e.add(f"s_add_u32 s{S_A}, s{S_A}, 64")
+        e.add(f"s_addc_u32 s{S_A + 1}, s{S_A + 1}, 0")
+        e.add(f"s_add_u32 s{S_B}, s{S_B}, 64")
+        e.add(f"s_addc_u32 s{S_B + 1}, s{S_B + 1}, 0")
+
+
+def x_loop_stmt(xt=False):
+    """the structure of loop_stmt (first block | steady block x nloop | final block; K = 128 (2 + nloop)) on x_iteration"""
+    e = Emit()
+    e.add(f"s_mov_b64 s[{S_A}:{S_A + 1}], %[asrc]")
+    e.add(f"s_mov_b64 s[{S_B}:{S_B + 1}], %[bsrc]")
+    e.add(f"s_mov_b32 s{S_CNT}, %[nloop]")
+    x_prime(e)
+    for s in range(4):
+        x_iteration(e, s, first=(s == 0))
+    e.add(f"s_cmp_eq_u32 s{S_CNT}, 0")
+    e.add("s_cbranch_scc1 .Lt384x_final_%=")
+    e.label(".Lt384x_loop_%=")
+    entry = dict(e.shift)
+    e.done = -1
+    for s in range(4):
+        x_iteration(e, s)
+    e.add(f"s_sub_u32 s{S_CNT}, s{S_CNT}, 1")
+    e.add(f"s_cmp_lg_u32 s{S_CNT}, 0")
+    e.add("s_cbranch_scc1 .Lt384x_loop_%=")
+    assert e.shift == entry, (e.shift, entry)
+    e.label(".Lt384x_final_%=")
+    e.done = -1
+    x_iteration(e, 0)
+    if xt:
+        if "dma" not in ABL:
+            e.add(f"s_mov_b64 s[{S_A}:{S_A + 1}], %[anext]")
+            e.add(f"s_mov_b64 s[{S_B}:{S_B + 1}], %[bnext]")
+        x_iteration(e, 1)
+        x_iteration(e, 2)
+        x_iteration(e, 3, last=True, barrier=True)
+        if "dma" not in ABL:
+            e.add("s_waitcnt vmcnt(10)")
+        if "bar" not in ABL:
+            e.add("s_barrier")
+    else:
+        x_iteration(e, 1, dma=False)
+        x_iteration(e, 2, dma=False, vm=0)
+        x_iteration(e, 3, dma=False, vm=None, last=True)
+    e.add("s_nop 15")
+    e.add("s_nop 7")
+    return e
+
+
+def emit_x_loop(w, sfx, xt=False):
+    name = f"t384x_loop{'_xt' if xt else ''}{sfx}"
+    w(f"// ---- the 16x16x32 K loop {name}: acc[4 m + nb] = the 32 x 32 block (m, nb) as four 16 x 16 quads (2 mi + ni), written from 0")
+    w(f"__device__ __forceinline__ void {name}(floatx16 (&acc)[12], const char* asrc, const char* bsrc, int nloop, unsigned pda,")
+    w("    unsigned pdb, unsigned va0, unsigned va1, unsigned va2, unsigned vb0, unsigned vb1, unsigned fa0, unsigned fb0"
+      + (", const char* anext, const char* bnext" if xt else "") + ") {")
+    w("  asm volatile(")
+    w(x_loop_stmt(xt).text())
+    w("      : " + ", ".join(f'[c{m}{n}] "=&{acc_pin(m, n)}"(acc[{4 * m + n}])' for m in range(3) for n in range(4)) + ",")
+    w('        [fa0] "+v"(fa0), [fb0] "+v"(fb0)')
+    w('      : [asrc] "s"(asrc), [bsrc] "s"(bsrc), [nloop] "s"(nloop), [pda] "s"(pda), [pdb] "s"(pdb), [va0] "v"(va0), [va1] "v"(va1),')
+    w('        [va2] "v"(va2), [vb0] "v"(vb0), [vb1] "v"(vb1)' + (', [anext] "s"(anext), [bnext] "s"(bnext)' if xt else ""))
+    clob = ['"memory"', '"scc"'] + [f'"{r}"' for r in SGPR_CLOBBERS] + [f'"v{i}"' for i in range(AX, 128)]
+    rows = [", ".join(clob[i:i + 16]) for i in range(0, len(clob), 16)]
+    w("      : " + ",\n        ".join(rows) + ");")
+    w("}")
+    w("")
+
+
 def loop_stmt(xt=False):
     """first block (half slabs 0-3) | steady block x nloop | final block.  K = 128 (2 + nloop).
     xt = False: the tile's own prologue has put half slabs 0-2 into slots 0-2; the final block issues no pieces after its first
@@ -259,7 +391,7 @@ def emit_loop(w, sfx, xt=False):
     w("  asm volatile(")
     w(loop_stmt(xt).text())
     if "m16" in ABL:
-        w("      : " + ", ".join(f'[c{m}{n}] "={acc_pin(m, n)}"(acc[{4 * m + n}])' for m in range(3) for n in range(4)) + ",")
+        w("      : " + ", ".join(f'[c{m}{n}] "=&{acc_pin(m, n)}"(acc[{4 * m + n}])' for m in range(3) for n in range(4)) + ",")
     else:
         w("      : " + ", ".join(f'[c{m}{n}] "=&{"v" if m == 0 else "a"}"(acc[{4 * m + n}])' for m in range(3) for n in range(4)) + ",")
     w('        [fa0] "+v"(fa0), [fa1] "+v"(fa1), [fb0] "+v"(fb0), [fb1] "+v"(fb1)')
@@ -284,6 +416,14 @@ def emit():
         ABL.update(abl)
         emit_loop(out.append if not name else lab.append, "" if not name else "_" + name)
         emit_loop(out.append if not name else lab.append, "" if not name else "_" + name, xt=True)
+    ABL.clear()
+    emit_x_loop(out.append, "")
+    emit_x_loop(out.append, "", xt=True)
+    for name, abl in VARIANTS[1:5]:
+        ABL.clear()
+        ABL.update(abl)
+        emit_x_loop(lab.append, "_" + name)
+        emit_x_loop(lab.append, "_" + name, xt=True)
     ABL.clear()
     w("// clang-format on")
     head = ["// GENERATED by dvd_amd/csrc/gen_gemm_t384.py --lab - do not edit.  TIMING ABLATIONS of the t384 K loop (lab builds only:",

@@ -433,8 +433,10 @@ def test_gemm_t384_kernel(ops, lab, monkeypatch, M, N, K):
     """Round 5's 384 x 256 kernel (gemm_nt_t384_kernel: 4-slot half-slab ring, generated K loop; N % 256 == 0, K % 128 == 0,
     K >= 256) on full and ragged row tiles (M % 384 != 0, M < one tile), the ring's shortest K (first + final block only) and the
     steady loop: exact integers, random data vs float64, plain / bias + ReLU -> f16 / bias + GELU -> f16 / residual / bias +
-    ReLU + residual (in place) epilogues - and THE SAME BITS as gemm_nt_big_kernel (lab switch DVD_GEMM_NO_T384), which runs
-    the same MFMA sequence per accumulator and the same epilogue arithmetic."""
+    ReLU + residual (in place) epilogues.  Round 6: the product loop runs on v_mfma_f32_16x16x32_f16 (16 x 16 accumulator
+    quads, turned into rows of 32 columns by v_permlane16_swap in every epilogue): exact on integers, float64-close on random
+    data, and its five epilogues agree with each other bit for bit; round 5's 32x32x16 loop (lab switch DVD_GEMM_T384_M32) still
+    has THE SAME BITS as gemm_nt_big_kernel (DVD_GEMM_NO_T384): same MFMA sequence per accumulator, same epilogue arithmetic."""
     rng = np.random.RandomState(M + N + K)
     ai = torch.from_numpy(rng.randint(-4, 5, (M, K)).astype(np.float32)).half()
     bi = torch.from_numpy(rng.randint(-4, 5, (N, K)).astype(np.float32)).half()
@@ -462,18 +464,30 @@ def test_gemm_t384_kernel(ops, lab, monkeypatch, M, N, K):
         torch.cuda.synchronize()
         return [t.cpu() for t in (o32, o16, g16, r32, br32, both, both16)]
 
-    new = run_all()
-    tol = 1e-4 * K ** 0.5
-    assert (new[0].double() - ref).abs().max().item() < tol
-    assert (new[1].double() - torch.relu(ref + bias.cpu().double())).abs().max().item() < 4e-2
-    assert (new[2].double() - torch.nn.functional.gelu(ref + bias.cpu().double(), approximate="tanh")).abs().max().item() < 4e-2
-    assert (new[3].double() - (ref + res.cpu().double())).abs().max().item() < tol + 1e-5
-    assert (new[4].double() - (torch.relu(ref + bias.cpu().double()) + res.cpu().double())).abs().max().item() < tol + 1e-5
-    assert (new[5].double() - (ref + bias.cpu().double())).abs().max().item() < tol + 1e-5
+    def check(outs, what):
+        tol = 1e-4 * K ** 0.5
+        assert (outs[0].double() - ref).abs().max().item() < tol, what
+        assert (outs[1].double() - torch.relu(ref + bias.cpu().double())).abs().max().item() < 4e-2, what
+        assert (outs[2].double() - torch.nn.functional.gelu(ref + bias.cpu().double(), approximate="tanh")).abs().max().item() < 4e-2, what
+        assert (outs[3].double() - (ref + res.cpu().double())).abs().max().item() < tol + 1e-5, what
+        assert (outs[4].double() - (torch.relu(ref + bias.cpu().double()) + res.cpu().double())).abs().max().item() < tol + 1e-5, what
+        assert (outs[5].double() - (ref + bias.cpu().double())).abs().max().item() < tol + 1e-5, what
+        # one accumulator, five epilogues (LDS-free f32 / f16, residual, the staged generic form): the same sums everywhere
+        assert torch.equal(outs[3], outs[0] + res.cpu()), what                                   # residual flavour = plain + res
+        assert torch.equal(outs[4], torch.relu(outs[0] + bias.cpu()) + res.cpu()), what
+        assert torch.equal(outs[5], outs[0] + bias.cpu()), what                                  # staged generic form
+        assert torch.equal(outs[6], outs[5].half()) and torch.equal(outs[1], torch.relu(outs[5]).half()), what
+
+    new = run_all()                                    # the product loop: v_mfma_f32_16x16x32_f16 (round 6)
+    check(new, "16x16x32 loop")
+    monkeypatch.setenv("DVD_GEMM_T384_M32", "1")       # round 5's 32x32x16 loop (lab)
+    m32 = run_all()
+    check(m32, "32x32x16 loop")
+    assert (new[0] - m32[0]).abs().max().item() < 1e-4 * K ** 0.5          # other MFMA shape, other summation grouping: close
     monkeypatch.setenv("DVD_GEMM_NO_T384", "1")
     old = run_all()
-    for i, (x, y) in enumerate(zip(new, old)):
-        assert torch.equal(x, y), f"output {i}: t384 and the 256 x 256 kernel must give the same bits"
+    for i, (x, y) in enumerate(zip(m32, old)):
+        assert torch.equal(x, y), f"output {i}: the 32x32x16 t384 loop and the 256 x 256 kernel must give the same bits"
 
 
 def test_gemm_t384_batched_weights_on_a_side(ops, lab, monkeypatch):
@@ -486,10 +500,14 @@ def test_gemm_t384_batched_weights_on_a_side(ops, lab, monkeypatch):
     ops.gemm_nt(w, x, out16=out, batch=Bn, N=N, strides={"B": N * K, "C16": M * N})
     ref = torch.einsum("mk,bnk->bmn", w.cpu().double(), x.cpu().double())
     assert (out.cpu().double() - ref).abs().max().item() < 4e-2
+    monkeypatch.setenv("DVD_GEMM_T384_M32", "1")
+    m32 = torch.zeros_like(out)
+    ops.gemm_nt(w, x, out16=m32, batch=Bn, N=N, strides={"B": N * K, "C16": M * N})
+    assert (m32.cpu().double() - ref).abs().max().item() < 4e-2
     monkeypatch.setenv("DVD_GEMM_NO_T384", "1")
     old = torch.zeros_like(out)
     ops.gemm_nt(w, x, out16=old, batch=Bn, N=N, strides={"B": N * K, "C16": M * N})
-    assert torch.equal(out.cpu(), old.cpu())
+    assert torch.equal(m32.cpu(), old.cpu())
 
 
 @pytest.mark.parametrize("M,N,K", [(2048, 1536, 1536), (2048, 384, 384), (300, 200, 128), (1024, 1088, 64), (77, 130, 192),
