@@ -92,5 +92,17 @@ timeout 600 python -m pytest tests/test_gpu_gemm.py -x -q -k "t384" 2>&1 | tail 
   for d in 4 5 6; do echo "== depth $d"; timeout 300 python benchmarks/gemm_time.py 7 res --lib benchmarks/lab/alt/libdvd_res_d$d.so 2>&1 | grep TF; done
   echo "== depth 3 (product)"; timeout 300 python benchmarks/gemm_time.py 7 res --lab 2>&1 | grep TF ) | tee $O/c13_res_depth.txt
 ;;
+14)  # the whole GPU suite + smoke at the current commit
+python -c "import __graft_entry__ as g; g.smoke()" > $O/c14_smoke.log 2>&1; echo "smoke rc=$?"; tail -1 $O/c14_smoke.log
+( time python -m pytest tests -q -m gpu --durations=12 ) > $O/c14_gpu_tests.log 2>&1; echo "gpu tests rc=$?"
+grep -E "passed|failed|^real" $O/c14_gpu_tests.log | tail -3; grep -E "peaked|ddpm_g160" $O/c14_gpu_tests.log | head
+;;
+15)  # schedule variants of the 16x16x32 loop (generator switches T384X_PIECES / T384X_BAR; benchmarks/lab/alt/libdvd_t384x_v*.so)
+timeout 300 python -m pytest tests/test_gpu_engine.py -q -k "ddpm_g160 or peaked" -s 2>&1 | grep -E "ddpm_g160|peaked|passed|failed" | cut -c1-600 | tee $O/c15_traces.txt
+( for rep in 1 2; do
+    echo "== product (pieces 3.1,3.3,3.5,3.7,4.1; barrier before block 3)"; timeout 300 python benchmarks/gemm_time.py 7 plain --lab 2>&1 | grep TF
+    for v in 1 2 3 4; do echo "== v$v"; timeout 300 python benchmarks/gemm_time.py 7 plain --lib benchmarks/lab/alt/libdvd_t384x_v$v.so 2>&1 | grep TF; done
+  done ) | tee $O/c15_t384x_sched.txt
+;;
 *) echo "unknown call $1"; exit 2;;
 esac

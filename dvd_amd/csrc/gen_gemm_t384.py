@@ -239,9 +239,15 @@ def x_iteration(e, slot, first=False, dma=True, vm=5, last=False, barrier=None):
         barrier = not last
     nslot = (slot + 1) % RING
     pc = 0
-    pieces_at = {(3, 1), (3, 3), (3, 5), (3, 7), (4, 1)}          # (block, gap): the wave's 5 pieces of half slab j + 3
+    # (block, gap) of the wave's 5 pieces of half slab j + 3, and the block in front of which the barrier sits: experiment
+    # switches of the generator (T384X_PIECES, T384X_BAR), not product options.  Measured (profiles/r6_gemm_t384x_sched.txt,
+    # f16 flavour, four shapes, two rounds): barrier before block 3 + a piece every 2nd gap 1177 / 1145 / 1194 TF/s (c1 / fc / c2);
+    # before block 2 + a piece every 4th gap (this default) 1186-1194 / 1162-1174 / 1208-1215; before block 1 within 1 % of it.
+    pieces_at = {tuple(int(v) for v in it.split(".")) for it in os.environ.get("T384X_PIECES", "2.1,2.5,3.1,3.5,4.1").split(",")}
+    bar_at = int(os.environ.get("T384X_BAR", "2"))
+    assert all(b >= bar_at for b, _ in pieces_at) and len(pieces_at) == 5
     for a in range(6):
-        if a == 3:
+        if a == bar_at:
             if vm is not None and "dma" not in ABL:
                 e.add(f"s_waitcnt vmcnt({vm})")
             if barrier and "bar" not in ABL:
