@@ -41,7 +41,7 @@ import torch.distributed as dist  # noqa: E402
 
 PEAK_F16_TFLOPS = 2500.0      # dense f16/bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0         # HBM3E, same guide
-PROFILE_ROUND = "r5"          # which profiles/<round>_pmc_*.json this bench.py's kernels were measured for
+PROFILE_ROUND = "r6"          # which profiles/<round>_pmc_*.json this bench.py's kernels were measured for
 HID, DEC, FFN = 384, 1536, 2048
 
 

@@ -104,5 +104,24 @@ timeout 300 python -m pytest tests/test_gpu_engine.py -q -k "ddpm_g160 or peaked
     for v in 1 2 3 4; do echo "== v$v"; timeout 300 python benchmarks/gemm_time.py 7 plain --lib benchmarks/lab/alt/libdvd_t384x_v$v.so 2>&1 | grep TF; done
   done ) | tee $O/c15_t384x_sched.txt
 ;;
+final)  # round-6 evidence at HEAD: smoke(), whole GPU suite, PMC passes, the driver's bench invocation, rocprofv3 kernel stats
+F=gpurun_out/final6; mkdir -p $F
+export TMPDIR=/tmp
+python -c "import __graft_entry__ as g; g.smoke()" > $F/smoke.log 2>&1; echo "smoke rc=$?"; tail -1 $F/smoke.log
+( time python -m pytest tests -q -m gpu --durations=12 ) > $F/gpu_tests.log 2>&1; echo "gpu tests rc=$?"
+grep -E "passed|failed|^real" $F/gpu_tests.log | tail -3
+bash benchmarks/pmc_round.sh r6 > $F/pmc_round.log 2>&1; echo "pmc rc=$?"
+cp gpurun_out/pmc_r6/r6_pmc_*.json gpurun_out/pmc_r6/r6_pmc_*.txt profiles/ 2>/dev/null
+( time python bench.py --gpus 1 --steps 20 --warmup 5 ) > $F/bench_driverlike.json 2> $F/bench_driverlike.err; echo "bench rc=$?"
+grep real $F/bench_driverlike.err
+python -c "
+import json; d=json.loads(open('$F/bench_driverlike.json').read().strip().splitlines()[-1]); print('bench', d['value'], d['ms_per_step'], d['roofline']['achieved'], d['roofline']['frac'], d['roofline'].get('traffic'), d['roofline_unwarp']['achieved'], d['roofline_unwarp']['frac'], d['cpu_baseline']['value'], d['cpu_baseline']['cores']); print({k: (v['value'], v['parity']['ok'] if v.get('parity') else None) for k, v in d['other_configs'].items()})"
+cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d "$GRAFT_REPO_ROOT/$F/prof" -o bench -- python3 "$GRAFT_REPO_ROOT/bench.py" --steps 1 --warmup 0 --no-cpu-baseline --no-other-configs > "$GRAFT_REPO_ROOT/$F/prof_bench.json" 2> "$GRAFT_REPO_ROOT/$F/prof_bench.err"; echo "prof rc=$?"
+cd "$GRAFT_REPO_ROOT"
+python benchmarks/stats_summary.py "$(find $F/prof -name '*kernel_stats.csv' | head -1)" $F/prof_bench.json "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-other-configs (round 6)" > $F/prof_summary.txt 2>&1
+find $F/prof -name '*kernel_stats.csv' -exec cp {} $F/kernel_stats.csv \;
+find $F/prof -name '*.csv' ! -name '*kernel_stats.csv' -delete 2>/dev/null
+sed -n 3,12p $F/prof_summary.txt | cut -c1-130; tail -4 $F/prof_summary.txt
+;;
 *) echo "unknown call $1"; exit 2;;
 esac
