@@ -382,7 +382,7 @@ def main(argv=None):
             ms = sum(a.elapsed_time(b) for a, b in evs) / len(evs)
             ms_u8_doc = sum(a.elapsed_time(b) for a, b in ev8[1:]) / (len(ev8) - 1)
             bytes_alg = 32 * FH * FW * B
-            gs_kernel = "grid_sample_lds_kernel<32, 2048, 0>"
+            gs_kernel = "grid_sample_lds_kernel<32, 2048, 0, 0>"
             roof_unwarp = {"kernel": f"{gs_kernel} (drop-in register_model2 contract, f32, LDS-staged 32x32 tiles, {B} "
                                      "documents per launch)", "bound": "hbm", "achieved": round(bytes_alg / (ms * 1e-3) / 1e9, 1),
                            "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(bytes_alg / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
