@@ -166,15 +166,17 @@ def run_evaluation_docunet(settings, logger, val_loader, diffusion, model, pretr
                                        th.zeros(nb, 256, G, G, device=device))
         th.cuda.synchronize()
         times.append((time.time() - t0) / nb)
-        # :301-306 + viz :75-77 - one launch for the batch when its documents share a full-resolution size
-        if all("src_u8" in d for d in batch):
-            if len({tuple(d["src_u8"].shape) for d in batch}) == 1:
-                outs = ops.unwarp_u8_batch(flow.contiguous(), stack("src_u8"))
-            else:
-                outs = [ops.unwarp_u8(flow[j:j + 1].contiguous(), dev_t(d["src_u8"]).contiguous()) for j, d in enumerate(batch)]
-        else:       # a float source that is not a byte image: the fused f32 tail, truncated like numpy's astype(uint8)
-            outs = [ops.unwarp_f32(flow[j:j + 1].contiguous(), d["source_vis"].to(device).float()[None].contiguous())
-                    .to(th.uint8) for j, d in enumerate(batch)]
+        # :301-306 + viz :75-77 - one launch for the batch when its documents are byte images of one full-resolution size
+        if all("src_u8" in d for d in batch) and len({tuple(d["src_u8"].shape) for d in batch}) == 1:
+            outs = ops.unwarp_u8_batch(flow.contiguous(), stack("src_u8"))
+        else:
+            outs = []
+            for j, d in enumerate(batch):
+                fj = flow[j:j + 1].contiguous()
+                if "src_u8" in d:
+                    outs.append(ops.unwarp_u8(fj, dev_t(d["src_u8"]).contiguous()))
+                else:   # a float source that is not a byte image: the fused f32 tail, truncated like numpy's astype(uint8)
+                    outs.append(ops.unwarp_f32(fj, d["source_vis"].to(device).float()[None].contiguous()).to(th.uint8))
         for j, d in enumerate(batch):
             out = outs[j]
             results.append((d["path"], out))

@@ -49,6 +49,8 @@ CASES = {
     # are ~8 h of oracle on all 8 cores of the build box (114 s per step), G = 160 is ~1.5 h.
     "ddim_g96_s50_peaked": (96, 50, 1, "peaked", "ddim", [0, 7, 14, 21, 28, 35, 42, 49]),
     "ddpm_g160_s250_tame": (160, 250, 1, "tame", "ddpm", list(range(0, 250, 25)) + [249]),
+    # ... and the longest ancestral chain the build box affords at the REAL grid: 100 steps at G = 288 (~3.5 h of oracle on 7 cores)
+    "ddpm_g288_s100_tame": (288, 100, 1, "tame", "ddpm", [0, 24, 49, 74, 99]),
 }
 PEAK_LOGIT_GAIN = 12.0
 
