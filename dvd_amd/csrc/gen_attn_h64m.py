@@ -430,5 +430,6 @@ if __name__ == "__main__":
     if arg == "--check":
         sys.exit(0 if os.path.exists(ppath) and open(ppath).read() == prod else 1)
     path, text = (lpath, lab) if arg == "--lab" else (ppath, prod)
-    open(path, "w").write(text)
+    if not (os.path.exists(path) and open(path).read() == text):      # identical content keeps its mtime (make)
+        open(path, "w").write(text)
     print(f"wrote {path}: {text.count(chr(10))} lines")
