@@ -123,5 +123,11 @@ find $F/prof -name '*kernel_stats.csv' -exec cp {} $F/kernel_stats.csv \;
 find $F/prof -name '*.csv' ! -name '*kernel_stats.csv' -delete 2>/dev/null
 sed -n 3,12p $F/prof_summary.txt | cut -c1-130; tail -4 $F/prof_summary.txt
 ;;
+18)  # the residual epilogue's loads alone (lab: DVD_GEMM_T384_NOSTORE) against loads + stores and stores alone (f32 flavour): stamps
+( echo "== residual (loads + stores)"; DVD_GEMM_T384_DBG=5 timeout 300 python benchmarks/gemm_t384_stamps.py 1536 2048 res 2>&1 | grep -v Warn | grep -v amdgpu
+  echo "== residual, stores never taken (loads alone)"; DVD_GEMM_T384_NOSTORE=1 DVD_GEMM_T384_DBG=5 timeout 300 python benchmarks/gemm_t384_stamps.py 1536 2048 res 2>&1 | grep -v Warn | grep -v amdgpu
+  echo "== f32 flavour (stores alone)"; DVD_GEMM_T384_DBG=5 timeout 300 python benchmarks/gemm_t384_stamps.py 1536 2048 f32 2>&1 | grep -v Warn | grep -v amdgpu
+  for v in "" DVD_GEMM_T384_NOSTORE; do echo "== wall, $v"; env ${v:+$v=1} timeout 300 python benchmarks/gemm_time.py 5 res --lab 2>&1 | grep TF; done ) | tee $O/c18_res_loads_alone.txt
+;;
 *) echo "unknown call $1"; exit 2;;
 esac

@@ -2273,6 +2273,7 @@ extern "C" int dvd_gemm_nt(const dvd_gemm_desc* d, void* stream) {
     if (const char* e = getenv("DVD_GEMM_T384_WALK")) p.walk = atoi(e);
     if (getenv("DVD_GEMM_T384_NT")) p.debug |= 0x200;
     if (getenv("DVD_GEMM_T384_RES_PHASED")) p.debug |= 0x400;
+    if (getenv("DVD_GEMM_T384_NOSTORE")) p.debug |= 0x800;
 #endif
     return launch_gemm_t384(p, d->batch, tdbg, stream);
   }

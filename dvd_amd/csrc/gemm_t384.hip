@@ -261,7 +261,9 @@ __device__ __forceinline__ void direct_f32(const GemmArgs& p, const floatx16 (&a
       const int ro = 32 * m + 16 * u + krow(k);
       gchar* sb = const_cast<gchar*>(cb) + ((size_t)ro * p.ldc + 32 * n) * 4;    // wave-uniform
 #ifdef DVD_LAB
-      if (p.debug & 0x200) {                       // lab (DVD_GEMM_T384_NT): streaming stores - are they acknowledged sooner?
+      if (p.debug & 0x800) {                       // lab (DVD_GEMM_T384_NOSTORE): the residual epilogue's loads alone (garbage output):
+        if (v[k] == 123.456f) *(gfloat*)(sb + (size_t)oc) = v[k];      // the store exists, its condition never holds
+      } else if (p.debug & 0x200) {                // lab (DVD_GEMM_T384_NT): streaming stores - are they acknowledged sooner?
         if (FULL || ro < rows_left) __builtin_nontemporal_store(v[k], (gfloat*)(sb + (size_t)oc));
       } else
 #endif
