@@ -129,5 +129,17 @@ sed -n 3,12p $F/prof_summary.txt | cut -c1-130; tail -4 $F/prof_summary.txt
   echo "== f32 flavour (stores alone)"; DVD_GEMM_T384_DBG=5 timeout 300 python benchmarks/gemm_t384_stamps.py 1536 2048 f32 2>&1 | grep -v Warn | grep -v amdgpu
   for v in "" DVD_GEMM_T384_NOSTORE; do echo "== wall, $v"; env ${v:+$v=1} timeout 300 python benchmarks/gemm_time.py 5 res --lab 2>&1 | grep TF; done ) | tee $O/c18_res_loads_alone.txt
 ;;
+19)  # the residual epilogue in two phases (loads into the accumulators, then stores) against the interleaved form
+     # (compile-time T384_RES_TWOPHASE=0: benchmarks/lab/alt/libdvd_res_interleaved.so - one epilogue per kernel instance)
+timeout 600 python -m pytest tests/test_gpu_gemm.py -x -q -k "t384" 2>&1 | tail -3
+( for rep in 1 2; do
+    echo "== two-phase (product rule, lab build)"; timeout 300 python benchmarks/gemm_time.py 7 res --lab 2>&1 | grep TF
+    echo "== two-phase, window depth 2 (alt build)"; timeout 300 python benchmarks/gemm_time.py 7 res --lib benchmarks/lab/alt/libdvd_res_twophase_d2.so 2>&1 | grep TF
+    echo "== interleaved (alt build)"; timeout 300 python benchmarks/gemm_time.py 7 res --lib benchmarks/lab/alt/libdvd_res_interleaved.so 2>&1 | grep TF
+  done
+  echo "== f32 flavour"; timeout 300 python benchmarks/gemm_time.py 7 f32 --lab 2>&1 | grep TF
+  echo "== stamps two-phase"; DVD_GEMM_T384_DBG=5 timeout 300 python benchmarks/gemm_t384_stamps.py 1536 2048 res 2>&1 | grep -v Warn | grep -v amdgpu
+) | tee $O/c19_res_twophase.txt
+;;
 *) echo "unknown call $1"; exit 2;;
 esac

@@ -189,6 +189,10 @@ __device__ __forceinline__ void epilogue(const GemmArgs& p, float* stage, const 
 #ifndef T384_RES_DEPTH
 #define T384_RES_DEPTH 3      // half tiles between a residual load and its use (direct_f32)
 #endif
+#ifndef T384_RES_TWOPHASE
+#define T384_RES_TWOPHASE 0   // the residual flavour's epilogue: 0 = interleaved loads and stores (product), 1 = two phases (round 6:
+                              // measured and rejected, see twophase_res_f32)
+#endif
 typedef __attribute__((address_space(1))) float gfloat;
 typedef __attribute__((address_space(1))) char gchar;
 
@@ -268,6 +272,117 @@ __device__ __forceinline__ void direct_f32(const GemmArgs& p, const floatx16 (&a
       } else
 #endif
       if (FULL || ro < rows_left) *(gfloat*)(sb + (size_t)oc) = v[k];
+    }
+  }
+}
+
+// ---- the residual flavour in TWO PHASES (round 6; MEASURED AND REJECTED - compiled only with -DT384_RES_TWOPHASE=1).
+// gfx950 has ONE in-order vmcnt for loads and stores, so in the interleaved form above every wait for a residual value also
+// waits for the acknowledgement of every older store of the wave; the kernel with its stores never taken is 0.3 ms per launch
+// faster (profiles/r6_gemm_res_loads_alone.txt).  Here the accumulators themselves are the buffer that would break the coupling:
+// phase A reads the residual (the same window) and writes relu(acc + bias) + residual BACK INTO THE ACCUMULATOR REGISTERS (one
+// asm statement per half tile with the eight registers as in/out operands: as compiled C++ the update spilled ~50 registers
+// into the K loop) - no store is issued, a wait stands behind loads only; phase B is the f32 flavour's store stream.  Same
+// arithmetic per element: same bits (tested).  Measured (profiles/r6_gemm_res_twophase.txt, one epilogue per build): fc 1.97-1.98
+// ms with a 3-step window, 1.90-1.93 with 2 steps (fewer spill reloads inside the store stream), against 1.90-1.92 interleaved - no
+// gain.  So the 0.3 ms are not the load-behind-store waits either: taking the stores away removes 2 GB of writes per launch from a
+// kernel whose every phase runs against the power cap and the fabric, which a re-ordering inside the epilogue does not.
+template <bool FULL, bool X16>
+__device__ __forceinline__ void twophase_res_f32(const GemmArgs& p, floatx16 (&acc)[12], int row_w, int col_w, int lane, float* C32,
+                                                 const float* bias, const float* res) {
+  const int r = lane & 31, h = lane >> 5;
+  float bv[4] = {0.f, 0.f, 0.f, 0.f};
+  if (bias) {
+#pragma unroll
+    for (int n = 0; n < 4; ++n) bv[n] = bias[col_w + 32 * n + r];
+  }
+  const bool relu = p.act == 2;
+  const float lo = relu ? 0.f : -__builtin_inff();
+  const unsigned oc = (unsigned)((HROWS<X16> * h) * p.ldc + r) * 4u, orr = (unsigned)((HROWS<X16> * h) * p.ldres + r) * 4u;
+  const gchar* cb = (const gchar*)uniform_ptr((const char*)(C32 + (size_t)row_w * p.ldc + col_w));
+  const gchar* rb = (const gchar*)uniform_ptr((const char*)(res + (size_t)row_w * p.ldres + col_w));
+  const int rows_left = p.M - row_w - HROWS<X16> * h;
+  auto krow = [](int k) { return (k & 3) + (X16 ? 4 : 8) * (k >> 2); };
+  constexpr int D = T384_RES_DEPTH, W = D + 1;
+  float rv[W][8];
+  auto load_res = [&](int s, float (&dst)[8]) {
+    const int t = s >> 1, u = s & 1, m = t >> 2, n = t & 3;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int ro = 32 * m + 16 * u + krow(k);
+      const gchar* sb = rb + ((size_t)ro * p.ldres + 32 * n) * 4;               // wave-uniform
+      dst[k] = (FULL || ro < rows_left) ? *(const gfloat*)(sb + (size_t)orr) : 0.f;
+    }
+  };
+#pragma unroll
+  for (int s = 0; s < D; ++s) load_res(s, rv[s]);
+#pragma unroll
+  for (int s = 0; s < 24; ++s) {                     // phase A: loads only
+    const int t = s >> 1, u = s & 1, n = t & 3;
+    __builtin_amdgcn_sched_barrier(0);
+    if (s + D < 24) load_res(s + D, rv[(s + D) % W]);
+    float a8[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) a8[k] = acc[t][8 * u + k];
+    if constexpr (X16) {
+      // ONE statement per half tile updates its eight accumulator registers IN PLACE (they are its in/out operands, in whichever
+      // file they live: "+a" for the AGPR-resident rows m = 1, 2, "+v" for row m = 0): swap to rows of 32 columns, + bias,
+      // max with lo (0 for ReLU, -inf otherwise: max(x, -inf) = x), + residual.  As compiled C++ the same update made the
+      // compiler keep old and new values of the 192 accumulators alive side by side and spill ~50 registers into the K loop.
+      const float* q = rv[s % W];
+      if (t >= 4) {
+        float t0, t1, t2, t3, t4, t5, t6, t7;
+        asm volatile(
+            "v_accvgpr_read_b32 %8, %0\n\tv_accvgpr_read_b32 %9, %1\n\tv_accvgpr_read_b32 %10, %2\n\tv_accvgpr_read_b32 %11, %3\n\t"
+            "v_accvgpr_read_b32 %12, %4\n\tv_accvgpr_read_b32 %13, %5\n\tv_accvgpr_read_b32 %14, %6\n\tv_accvgpr_read_b32 %15, %7\n\t"
+            "s_nop 1\n\t"
+            "v_permlane16_swap_b32 %8, %12\n\tv_permlane16_swap_b32 %9, %13\n\tv_permlane16_swap_b32 %10, %14\n\tv_permlane16_swap_b32 %11, %15\n\t"
+            "s_nop 1\n\t"
+            "v_add_f32 %8, %8, %16\n\tv_add_f32 %9, %9, %16\n\tv_add_f32 %10, %10, %16\n\tv_add_f32 %11, %11, %16\n\t"
+            "v_add_f32 %12, %12, %16\n\tv_add_f32 %13, %13, %16\n\tv_add_f32 %14, %14, %16\n\tv_add_f32 %15, %15, %16\n\t"
+            "v_max_f32 %8, %8, %17\n\tv_max_f32 %9, %9, %17\n\tv_max_f32 %10, %10, %17\n\tv_max_f32 %11, %11, %17\n\t"
+            "v_max_f32 %12, %12, %17\n\tv_max_f32 %13, %13, %17\n\tv_max_f32 %14, %14, %17\n\tv_max_f32 %15, %15, %17\n\t"
+            "v_add_f32 %8, %8, %18\n\tv_add_f32 %9, %9, %19\n\tv_add_f32 %10, %10, %20\n\tv_add_f32 %11, %11, %21\n\t"
+            "v_add_f32 %12, %12, %22\n\tv_add_f32 %13, %13, %23\n\tv_add_f32 %14, %14, %24\n\tv_add_f32 %15, %15, %25\n\t"
+            "v_accvgpr_write_b32 %0, %8\n\tv_accvgpr_write_b32 %1, %9\n\tv_accvgpr_write_b32 %2, %10\n\tv_accvgpr_write_b32 %3, %11\n\t"
+            "v_accvgpr_write_b32 %4, %12\n\tv_accvgpr_write_b32 %5, %13\n\tv_accvgpr_write_b32 %6, %14\n\tv_accvgpr_write_b32 %7, %15"
+            : "+a"(a8[0]), "+a"(a8[1]), "+a"(a8[2]), "+a"(a8[3]), "+a"(a8[4]), "+a"(a8[5]), "+a"(a8[6]), "+a"(a8[7]),
+              "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7)
+            : "v"(bv[n]), "v"(lo), "v"(q[0]), "v"(q[1]), "v"(q[2]), "v"(q[3]), "v"(q[4]), "v"(q[5]), "v"(q[6]), "v"(q[7]));
+      } else {
+        asm volatile(
+            "s_nop 1\n\t"
+            "v_permlane16_swap_b32 %0, %4\n\tv_permlane16_swap_b32 %1, %5\n\tv_permlane16_swap_b32 %2, %6\n\tv_permlane16_swap_b32 %3, %7\n\t"
+            "s_nop 1\n\t"
+            "v_add_f32 %0, %0, %8\n\tv_add_f32 %1, %1, %8\n\tv_add_f32 %2, %2, %8\n\tv_add_f32 %3, %3, %8\n\t"
+            "v_add_f32 %4, %4, %8\n\tv_add_f32 %5, %5, %8\n\tv_add_f32 %6, %6, %8\n\tv_add_f32 %7, %7, %8\n\t"
+            "v_max_f32 %0, %0, %9\n\tv_max_f32 %1, %1, %9\n\tv_max_f32 %2, %2, %9\n\tv_max_f32 %3, %3, %9\n\t"
+            "v_max_f32 %4, %4, %9\n\tv_max_f32 %5, %5, %9\n\tv_max_f32 %6, %6, %9\n\tv_max_f32 %7, %7, %9\n\t"
+            "v_add_f32 %0, %0, %10\n\tv_add_f32 %1, %1, %11\n\tv_add_f32 %2, %2, %12\n\tv_add_f32 %3, %3, %13\n\t"
+            "v_add_f32 %4, %4, %14\n\tv_add_f32 %5, %5, %15\n\tv_add_f32 %6, %6, %16\n\tv_add_f32 %7, %7, %17"
+            : "+v"(a8[0]), "+v"(a8[1]), "+v"(a8[2]), "+v"(a8[3]), "+v"(a8[4]), "+v"(a8[5]), "+v"(a8[6]), "+v"(a8[7])
+            : "v"(bv[n]), "v"(lo), "v"(q[0]), "v"(q[1]), "v"(q[2]), "v"(q[3]), "v"(q[4]), "v"(q[5]), "v"(q[6]), "v"(q[7]));
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) acc[t][8 * u + k] = a8[k];
+    } else {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        float x = a8[k] + bv[n];
+        x = relu ? fmaxf(x, 0.f) : x;
+        acc[t][8 * u + k] = x + rv[s % W][k];
+      }
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < 24; ++s) {                     // phase B: stores only
+    const int t = s >> 1, u = s & 1, m = t >> 2, n = t & 3;
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int ro = 32 * m + 16 * u + krow(k);
+      gchar* sb = const_cast<gchar*>(cb) + ((size_t)ro * p.ldc + 32 * n) * 4;    // wave-uniform
+      if (FULL || ro < rows_left) *(gfloat*)(sb + (size_t)oc) = acc[t][8 * u + k];
     }
   }
 }
@@ -576,7 +691,12 @@ __global__ void __launch_bounds__(512, 2) gemm_nt_t384_kernel(GemmArgs p) {
           else direct_f32<true, FULL, X16>(p, acc, row_w, col_w, lane_e, C32, bias, res);
         } else
 #endif
-          direct_f32<true, FULL, X16>(p, acc, row_w, col_w, lane_e, C32, bias, res);
+        {
+          // ONE residual epilogue per kernel instance (two inlined side by side spill into each other and into the K loop:
+          // measured).  T384_RES_TWOPHASE = 0 compiles round 5's interleaved form instead (benchmarks/lab/alt/ A/B builds).
+          if constexpr (T384_RES_TWOPHASE != 0) twophase_res_f32<FULL, X16>(p, acc, row_w, col_w, lane_e, C32, bias, res);
+          else direct_f32<true, FULL, X16>(p, acc, row_w, col_w, lane_e, C32, bias, res);
+        }
       }
       else if constexpr (FL == 3) epilogue<0, X16>(p, stage, acc, row_w, col_w, lane_e, C32, C16, bias, res);
       else epilogue<1, X16>(p, stage, acc, row_w, col_w, lane_e, C32, C16, bias, res);
