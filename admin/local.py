@@ -54,6 +54,7 @@ _DEFAULTS = {
     "num_synthetic_docs": 4,
     "full_res": (1024, 768), # synthetic full-resolution source size (H, W)
     "conditioning_dir": "",   # directory of per-document conditioning .npz files (skips ingest + pre-stage nets)
+    "num_workers": 0,         # DataLoader workers of the image-directory path (they only decode; the reference: 8)
     # run the pre-stage conditioning nets (GeoTr_Seg_Inf.msk, Seg, line UNet; reference evaluation.py:162-216) on the
     # document images, as the reference does; False = synthetic documents carry random conditioning tensors
     "use_prestage_nets": True,
