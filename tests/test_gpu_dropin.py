@@ -484,3 +484,41 @@ def test_run_evaluation_docunet_on_a_reference_shaped_loader(tmp_path, monkeypat
     got = run_evaluation_docunet(s, logger, items, diffusion, model, dewarp, line, seg)
     for (pa, a), (pb, b) in zip(want, got):
         assert pa == pb and torch.equal(a, b), pa
+
+
+def test_plugin_run_on_an_image_directory(tmp_path, monkeypatch):
+    """val_TDiff.run(settings) on a benchmark DIRECTORY, the reference's main route (val_TDiff.py:93-104: env.eval_dataset_name
+    = 'docunet', env.eval_dataset = the directory): Doc_benchmark behind a DataLoader, decode in the loader, ingest + pre-stage
+    nets + sampler + fused tail on the GPU, PNGs where the reference writes them.  The documents equal, byte for byte, the ones
+    run_evaluation_docunet gives for the same decoded arrays handed over directly."""
+    from PIL import Image
+    from dvd_amd import logger, val_TDiff
+    from train_settings.dvd.evaluation import run_evaluation_docunet
+    monkeypatch.chdir(tmp_path)
+    os.makedirs("bench_dir")
+    arrays = []
+    for i in range(3):
+        img = synth.smooth_image(f"dir{i}/image", 120, 88, seed=1234)
+        arrays.append(np.ascontiguousarray((img.transpose(1, 2, 0) * 255.0).astype(np.uint8)))
+        Image.fromarray(arrays[-1]).save(f"bench_dir/doc_{i}.png")
+    (tmp_path / "bench_dir" / "README.txt").write_text("not an image")
+    s = _settings("dir_run", grid=16, steps=3, batch=2)
+    s.env.eval_dataset_name, s.env.eval_dataset = "docunet", "bench_dir"
+    s.env.use_prestage_nets, s.env.synthetic_weights_if_missing, s.env.visualize = True, True, True
+    torch.manual_seed(0)
+    got = val_TDiff.run(s)
+    assert [p for p, _ in got] == [os.path.join("bench_dir", f"doc_{i}.png") for i in range(3)]
+    for (p, img), arr in zip(got, arrays):
+        assert img.dtype == torch.uint8 and tuple(img.shape) == arr.shape
+        png = tmp_path / "vis_hp" / "docunet" / "dir_run" / "dewarped_pred" / f"warped_{os.path.basename(p)[:-4]}.png"
+        assert np.array_equal(np.asarray(Image.open(png)), img.cpu().numpy())
+    # the same documents through run_evaluation_docunet directly (same seeds, same synthetic weights)
+    s2, model, diffusion = build(16, 3)
+    s2.env.batch_docs, s2.env.visualize, s2.env.eval_dataset_name, s2.name = 2, False, "docunet", "direct"
+    s2.env.synthetic_weights_if_missing = True
+    dewarp, seg, line = val_TDiff.load_prestage_models(s2.env)
+    torch.manual_seed(0)
+    want = run_evaluation_docunet(s2, logger, [{"image_u8": a, "path": f"d{i}"} for i, a in enumerate(arrays)], diffusion, model,
+                                  dewarp, line, seg)
+    for (_, a), (_, b) in zip(want, got):
+        assert torch.equal(a, b)
