@@ -522,3 +522,34 @@ def test_plugin_run_on_an_image_directory(tmp_path, monkeypatch):
                                   dewarp, line, seg)
     for (_, a), (_, b) in zip(want, got):
         assert torch.equal(a, b)
+
+
+def test_run_sample_lr_dewarping_called_as_the_reference_calls_it_vs_golden(monkeypatch):
+    """evaluation.py:247-265: `sample = run_sample_lr_dewarping(settings, logger, diffusion, model, radius, source, feature_size,
+    raw_corr, init_flow, c20, source_64, pyramid, mask_x, seg_map_all, textline_map, init_feat)` - sixteen POSITIONAL arguments in
+    the reference's order - against golden G3 (the real reference's 3-step loop at G = 64).  The function draws its own x_T
+    (noise=None, gaussian_diffusion.py:562,569): the two draws are answered with the golden's x_T so that the result is comparable."""
+    import dvd_amd.gaussian_diffusion as gd
+    from dvd_amd import logger
+    from train_settings.dvd.evaluation import run_sample_lr_dewarping
+    g = np.load(os.path.join(GOLD, "loop_g64_s3.npz"))
+    s, model, diffusion = build(64, 3)
+    doc = {k: torch.from_numpy(v)[None].cuda() for k, v in synth.synth_document(0, 64, 1234).items()}
+    x_T = torch.from_numpy(g["x_T"]).cuda()
+    real_randn = torch.randn
+    draws = []
+
+    def fake_randn(*shape, **kw):
+        shape = tuple(shape[0]) if len(shape) == 1 and not isinstance(shape[0], int) else tuple(shape)
+        draws.append(shape)
+        return x_T.clone() if shape == tuple(x_T.shape) else real_randn(*shape, **kw)
+    monkeypatch.setattr(gd.th, "randn", fake_randn)
+    radius, raw_corr, c20, source_64, pyramid = 4, None, None, None, None
+    init_flow = torch.zeros(1, 2, 64, 64, device="cuda")
+    init_feat = torch.zeros(1, 256, 64, 64, device="cuda")
+    sample = run_sample_lr_dewarping(s, logger, diffusion, model, radius, doc["y512"], 64, raw_corr, init_flow, c20, source_64,
+                                     pyramid, doc["mask_cat"], doc["mask_y512"], doc["line_msk"], init_feat)
+    assert draws == [(1, 2, 64, 64), (2, 2, 64, 64)], draws              # the discarded draw (:562), then x_T for n_batch = 2 (:569)
+    assert tuple(sample.shape) == (1, 2, 64, 64) and float(sample.abs().max()) <= 1.0
+    err = float(np.sqrt(((sample.cpu().numpy() - np.clip(g["sample"], -1, 1)) ** 2).mean()))
+    assert err < 2.7e-4, err
