@@ -493,7 +493,8 @@ def other_configs(dev, blob288, H, FH, FW, want_cpu=True, legs=("cfg4", "ns32", 
     parity figure (the headline fields of the line are untouched):
       configs[4]  16 documents, 50-step DDIM, G = 288, + 3508x2480 unwarp: ONE whole batch;
       ns32        north_star's stated target point: 32 documents, 50-step DDIM, G = 288, + unwarp: ONE whole batch (round 6);
-      configs[3]  250-step DDPM ancestral sampling at G = 288 at its STATED 32 documents (x H hypotheses = 64 samples, one
+      configs[3]  (parity since round 6: the fused step vs the oracle AND document 0 of the batch after all 250 steps == itself alone)
+                  250-step DDPM ancestral sampling at G = 288 at its STATED 32 documents (x H hypotheses = 64 samples, one
                   engine batch, ~5.5 minutes; round 5) - unless the process has already run longer than CFG3_FULL_DEADLINE_S,
                   in which case 4 documents are run and the leg says so (the loop is strictly per-document work, so
                   documents/s at 4 per batch is a lower bound of the rate at 32);
@@ -595,6 +596,7 @@ def other_configs(dev, blob288, H, FH, FW, want_cpu=True, legs=("cfg4", "ns32", 
         eng = Engine(G, B, H, device=dev)
         eng.bind_blob(blob288)
         cond = docs(B, G)
+        noise_state = gen.get_state()            # the leg's x_T and noise table can be re-drawn (the single-document re-run below)
         x_T = torch.randn(B * H, 2, G, G, device=dev, generator=gen)
         tab = schedule.Tables(schedule.named_betas("cosine", 250))
         last = {}
@@ -621,13 +623,32 @@ def other_configs(dev, blob288, H, FH, FW, want_cpu=True, legs=("cfg4", "ns32", 
             err = float((got - ref).abs().max())
             par = {"what": "fused DDPM step (t = 125, FIXED_LARGE) on this run's tensors vs the oracle's p_mean_variance + "
                            "noise line", "max_abs": err, "ok": bool(err < 1e-5)}
+        # ... and of the whole 250-step chain: document 0 of the batch must have the bits it has when sampled ALONE with the same
+        # x_T and the same noise table (re-drawn from the saved generator state; one engine of one document: ~1/32 of the leg)
+        del eng
+        torch.cuda.empty_cache()
+        gen.set_state(noise_state)
+        x_T1 = torch.randn(B * H, 2, G, G, device=dev, generator=gen)[:H].contiguous()
+        eng1 = Engine(G, 1, H, device=dev)
+        eng1.bind_blob(blob288)
+        eng1.prepare(*[c[:1].contiguous() for c in cond])
+        flow1 = sampler.sample(eng1, tab, x_T1, sampler="ddpm",
+                               noise_fn=lambda i: torch.randn(B * H, 2, G, G, device=dev, generator=gen)[:H].contiguous())
+        chain_same = bool(torch.equal(flow1[0], flow[0]))
+        if par is None:
+            par = {"what": "", "ok": True}
+        par["what"] = (par["what"] + "; " if par["what"] else "") + \
+            "document 0 of the batch after all 250 ancestral steps == the same document sampled alone (bit for bit)"
+        par["chain_batch_equals_single"] = chain_same
+        par["ok"] = bool(par["ok"] and chain_same)
+        del eng1, flow1, x_T1
         out["configs[3]"] = {"workload": (f"BASELINE configs[3]: batch={B} documents x {H} hypotheses" if B == 32 else
                                           f"BASELINE configs[3] at batch={B} instead of 32 documents (x {H} hypotheses; the run "
                                           f"was past {CFG3_FULL_DEADLINE_S} s when this leg started)") +
                                          ": 250-step DDPM ancestral sampling, 288x288 grid (no unwarp in this configuration)",
                              "batches_timed": 1, "ms_per_batch": round(dt * 1e3, 1), "value": round(B / dt, 5),
                              "unit": "documents/s", "finite": bool(torch.isfinite(flow).all()), "parity": par}
-        del eng, cond, x_T, flow, last
+        del cond, x_T, flow, last
         torch.cuda.empty_cache()
 
     if "native" not in legs:

@@ -208,7 +208,7 @@ def _engine_rollout(eng, steps, smp, xT, noises, **opts):
 TRACE_CASES = ["ddim_g16_s50_plain", "ddim_g16_s50_tame", "ddim_g72_s25_tame", "ddim_g96_s50_tame", "ddim_g96_s50_plain",
                "ddpm_g16_s25_tame", "ddpm_g16_s250_tame", "ddpm_g72_s40_tame", "ddim_g288_s50_tame",
                "ddpm_g288_s10_tame", "ddim_g288_s50_plain", "ddim_g96_s50_peaked", "ddpm_g160_s250_tame",
-               "ddpm_g288_s100_tame"]
+               "ddpm_g288_s100_tame", "ddim_g288_s50_peaked"]
 
 
 @pytest.mark.parametrize("name", TRACE_CASES)

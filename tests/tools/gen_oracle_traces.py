@@ -51,6 +51,8 @@ CASES = {
     "ddpm_g160_s250_tame": (160, 250, 1, "tame", "ddpm", list(range(0, 250, 25)) + [249]),
     # ... and the longest ancestral chain the build box affords at the REAL grid: 100 steps at G = 288 (~3.5 h of oracle on 7 cores)
     "ddpm_g288_s100_tame": (288, 100, 1, "tame", "ddpm", [0, 24, 49, 74, 99]),
+    # the peaked-attention family on the HEADLINE kernels (r64x / h64x generated loops with their deferred-rescale blocks, T = 20 736)
+    "ddim_g288_s50_peaked": (288, 50, 1, "peaked", "ddim", [0, 28, 49]),
 }
 PEAK_LOGIT_GAIN = 12.0
 
