@@ -5,7 +5,11 @@ usage: python benchmarks/attn_ab.py [B=16] [rounds=7] [hd=256] [variant=ENV[,ENV
        e.g.  python benchmarks/attn_ab.py 16 7 256 r64p= r64old=DVD_ATTN_R64OLD"""
 import os, sys, statistics
 sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__))); import _lab; _lab.use_lab()
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__))); import _lab
+if "--lib" in sys.argv:                      # another build of the library (benchmarks/lab/alt/: generator experiments)
+    _lab.which()
+else:
+    _lab.use_lab()
 import torch
 from dvd_amd import ops
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16

@@ -49,6 +49,9 @@ MF = "v_mfma_f32_16x16x32_f16"
 # = the 256 registers of a wave at two per SIMD.  The rare block scales the l tiles like the O^T tiles; after the loop l is read
 # from a[64 + 4 qb], complete (no cross-lane reduction).  Generated as a second body (prefix h64l) beside the round-4 one.
 LM = False
+L_SPREAD = os.environ.get("H64X_L_SPREAD") == "1"     # experiment switch of the generator (not a product option): one row-sum
+#                                                        MFMA behind each PV group instead of four at the end of phase 2 - measured
+#                                                        equal (8.52-8.56 vs 8.57 ms at the bench shape, two rounds), not adopted
 PFX = "h64x"
 ABL = set()        # timing ablations (lab builds only; garbage results): "valu", "dma", "read", "wait", "bar"
 
@@ -266,8 +269,11 @@ def tile(s, var):
                 advance(s, "v")
             if qb == 3 and g == 2:
                 s.add(f"s_add_i32 s{S_TC}, s{S_TC}, 1")
-            emit_gap(s, gaps[4 * g + qb])
-    if LM:                                                    # the row sums: O^T's fifth dim block, A = ones (no fragment read)
+            emit_gap(s, gaps[(5 * g + qb) if (LM and L_SPREAD) else (4 * g + qb)])
+        if LM and L_SPREAD:                                   # experiment (H64X_L_SPREAD=1): one row-sum MFMA behind each PV group
+            s.add(f"{MF} {lreg(g)}, %[ones], {pfrag(g)}, {lreg(g)}")
+            emit_gap(s, gaps[5 * g + 4])
+    if LM and not L_SPREAD:                                   # the row sums: O^T's fifth dim block, A = ones (no fragment read)
         for qb in range(4):
             s.add(f"{MF} {lreg(qb)}, %[ones], {pfrag(qb)}, {lreg(qb)}")
             emit_gap(s, gaps[16 + qb])
